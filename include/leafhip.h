@@ -1,0 +1,157 @@
+/*
+ * leafhip.h — C ABI of libleafhip.so: the MI355X (gfx950) hot path of leaffliction.
+ *
+ * The reference (Kiripiro/leaffliction) is pure Python and has no FFI; the
+ * boundary each entry point replaces is the third-party library call the
+ * reference makes on its hot path.  Each declaration cites
+ * the reference call site (path:line under the reference tree) it stands in for.
+ *
+ * Conventions (last row):
+ *  - every buffer is a caller-owned DEVICE pointer (torch tensors on the host
+ *    side); the library never allocates, frees or synchronises;
+ *  - all work is enqueued on the hipStream_t passed as `stream` (void* here so
+ *    that the header needs no HIP include; 0 = the null stream);
+ *  - return value: 0 = LF_OK, negative = error (see lf_last_error());
+ *    nothing throws or exits across the ABI; the library is re-entrant and
+ *    keeps no mutable global state beyond the thread-local error string;
+ *  - integer / byte results are bit-exact with the reference's CPU path;
+ *    float tolerances are stated per function.
+ *
+ * Image layouts: "HWC u8" = [N][H][W][3] uint8 interleaved RGB (what
+ * np.array(PIL.Image) yields); "NCHW f32" = [N][C][H][W] float.
+ */
+#ifndef LEAFHIP_H
+#define LEAFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_OK 0
+#define LF_ERR_INVALID (-1)   /* bad argument (null pointer, non-positive dim, unsupported size) */
+#define LF_ERR_LAUNCH (-2)    /* HIP reported a launch error */
+#define LF_ERR_WORKSPACE (-3) /* workspace too small */
+
+#define LF_VERSION 100
+
+typedef void* lf_stream_t;
+
+int lf_version(void);
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* lf_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* A1 — augmentation / input side (uint8, bit-exact)                          */
+/* ------------------------------------------------------------------------- */
+
+/* u8 HWC -> f32 NCHW with exact x/255.0f, optional per-channel (x-mean)/denom.
+ * Replaces np.array(img) + ImageTransforms.normalize_array
+ * (srcs/utils/image_utils.py:117-130) and, when mean/denom are non-null, the
+ * keras Normalization layer (srcs/model/cnn.py:84-86): denom[c] =
+ * max(sqrt(var[c]), eps) is computed by the caller; mean3/denom3 are HOST pointers to
+ * 3 floats (model constants passed by value into the launch).  Bit-exact vs numpy f32. */
+int lf_pack_hwc_u8_to_nchw_f32(const uint8_t* in, float* out, int n, int h, int w,
+                               const float* mean3, const float* denom3, lf_stream_t stream);
+
+/* Per-image, per-channel 256-bin histogram: hist[n][c][v] (int32).
+ * Replaces PIL Image.histogram() inside ImageOps.autocontrast
+ * (srcs/preprocessing/image_augmenter.py:127).  `hist` is overwritten. */
+int lf_hist_u8(const uint8_t* in, int32_t* hist, int n, int h, int w, lf_stream_t stream);
+
+/* autocontrast LUT from histograms: lut[n][c][256] u8, cutoff[n] in percent.
+ * Restates PIL ImageOps.autocontrast's cut / lo / hi / scale / offset
+ * arithmetic in IEEE double (image_augmenter.py:127).  Bit-exact. */
+int lf_autocontrast_lut(const int32_t* hist, const double* cutoff, uint8_t* lut, int n,
+                        lf_stream_t stream);
+
+/* out[n][y][x][c] = lut[n][c][in[n][y][x][c]]  (PIL Image.point(lut)). */
+int lf_lut_apply_u8(const uint8_t* in, const uint8_t* lut, uint8_t* out, int n, int h, int w,
+                    lf_stream_t stream);
+
+/* ImageAugmenter.flip (image_augmenter.py:20-31): mode[n] = 0 -> FLIP_LEFT_RIGHT,
+ * 1 -> FLIP_TOP_BOTTOM. */
+int lf_flip_u8(const uint8_t* in, uint8_t* out, const int32_t* mode, int n, int h, int w,
+               lf_stream_t stream);
+
+/* ImageAugmenter.distortion's noise add (image_augmenter.py:121-124):
+ * out = (u8)(in + (u8)(int)noise) with uint8 wrap-around, noise in float64
+ * exactly as np.random.normal returned it (same shape as the image). */
+int lf_noise_wrap_add_u8(const uint8_t* in, const double* noise, uint8_t* out, size_t nbytes,
+                         lf_stream_t stream);
+
+/* Same op with the noise drawn on the device: counter-based Philox4x32-10 +
+ * Box-Muller N(0, sigma) keyed by (seed, byte index).  Statistically, not
+ * bit-wise, equal to the numpy stream; used for the synthetic C3 pass. */
+int lf_noise_philox_add_u8(const uint8_t* in, uint8_t* out, size_t nbytes, uint64_t seed,
+                           float sigma, lf_stream_t stream);
+
+/* apply_mask (srcs/utils/mask_utils.py:67-79) and blur.py:74-75:
+ * out = mask > 127 ? img : color (color 0 or 255), mask is [N][H][W] u8. */
+int lf_mask_composite_u8(const uint8_t* img, const uint8_t* mask, uint8_t* out, int n, int h,
+                         int w, int color, lf_stream_t stream);
+
+/* cv2.cvtColor(rgb, COLOR_RGB2HSV) on uint8 (hist.py:184, blur.py:44):
+ * OpenCV's 8-bit fixed-point path, H in [0,180).  Parity unpinned (no cv2). */
+int lf_rgb2hsv_u8(const uint8_t* rgb, uint8_t* hsv, size_t npixels, lf_stream_t stream);
+
+/* cv2.cvtColor(rgb, COLOR_RGB2GRAY) on uint8 (blur.py:27):
+ * (4899 R + 9617 G + 1868 B + 8192) >> 14. */
+int lf_rgb2gray_u8(const uint8_t* rgb, uint8_t* gray, size_t npixels, lf_stream_t stream);
+
+/* cv2.GaussianBlur(img, (k,k), sigma) on uint8 with BORDER_REFLECT_101
+ * (blur.py:61,72): separable, both passes fused through LDS, OpenCV's 8.8
+ * fixed-point kernel (kq[k] uint16, sum 256).  channels = 1 or 3. ksize odd <= 31. */
+int lf_gauss_blur_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int channels,
+                     const uint16_t* kq, int ksize, lf_stream_t stream);
+
+/* HSV colour-region statistics of apply_histogram_filter (hist.py:22-67,
+ * 181-189, 248-256): per image, with leaf = (s>10)&(v>15)&(v<245):
+ * counts[n][0] = leaf pixels, [1..8] = the 8 predicate counts,
+ * [9..13] = the 5 hue-range counts; hsv_hist[n][3][256] = histograms of H,S,V
+ * over leaf pixels.  Input is RGB HWC u8 (the HSV conversion is fused). int64-free:
+ * all counters int32. */
+#define LF_HSV_NCOUNTS 14
+int lf_hsv_region_stats(const uint8_t* rgb, int32_t* counts, int32_t* hsv_hist, int n, int h,
+                        int w, lf_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Geometric ops (Pillow semantics, bit-exact; coordinates in IEEE double)    */
+/* ------------------------------------------------------------------------- */
+
+/* Image.transform(size, AFFINE|PERSPECTIVE, coeffs, BICUBIC) (image_augmenter.py:44-94).
+ * coeffs[n][8] double (affine uses the first 6, a6 = a7 = 0), output same size,
+ * outside pixels black.  */
+int lf_warp_bicubic_u8(const uint8_t* in, uint8_t* out, const double* coeffs, int perspective,
+                       int n, int h, int w, lf_stream_t stream);
+
+/* Image.rotate(angle, expand=True, fillcolor="white") NEAREST path
+ * (image_augmenter.py:37): Pillow's 16.16 fixed-point affine.  fix6[n][6] are the
+ * int32 fixed-point coefficients a0,a1,a2',a3,a4,a5' computed on the host exactly as
+ * Pillow's affine_fixed does.  in: [n][h][w][3].  The output is a ragged batch (the
+ * expanded canvas depends on the angle): image i writes ohw[i] = (oh, ow) pixels,
+ * packed RGB, at byte offset out_off[i] of `out`; pixels whose source falls outside
+ * get `fill`.  max_out_pixels = max_i oh*ow sizes the grid. */
+int lf_affine_nearest_fixed_u8(const uint8_t* in, uint8_t* out, const int32_t* fix6,
+                               const int32_t* ohw, const int64_t* out_off, int n, int h, int w,
+                               int max_out_pixels, int fill, lf_stream_t stream);
+
+/* Pillow two-pass separable resample with 8-bit intermediates and 22-bit
+ * fixed-point coefficients (Image.resize(..., LANCZOS), image_utils.py:109-114,
+ * image_augmenter.py:110).  bounds/coefficients are computed on the host exactly as
+ * Resample.c's precompute_coeffs + normalize_coeffs_8bpc do; a crop box is folded into
+ * them (xmin/ymin index the uncropped image).
+ * Horizontal pass: in [n][h][w][3] -> tmp [n][h][ow][3]; vertical: -> out [n][oh][ow][3].
+ * xbounds [ow][2] = (xmin, count), xk [ow][kx]; ybounds [oh][2], yk [oh][ky] (int32);
+ * with per_image_coeffs != 0 each table has a leading [n] dimension. */
+int lf_resample_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int n, int h, int w, int oh,
+                   int ow, const int32_t* xbounds, const int32_t* xk, int kx,
+                   const int32_t* ybounds, const int32_t* yk, int ky, int per_image_coeffs,
+                   lf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEAFHIP_H */

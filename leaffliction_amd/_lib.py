@@ -1,0 +1,78 @@
+"""ctypes binding of libleafhip.so (the C ABI declared in include/leafhip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a symbol is
+absent, importing/using it raises.  `load()` only dlopens the library (no GPU needed, so
+the CPU test-suite can check the export table); every call goes through `call()` which
+turns a negative return code into a `LeafHipError` carrying `lf_last_error()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB = None
+
+LIB_PATH = Path(__file__).resolve().parent / "libleafhip.so"
+
+c_void_p, c_int, c_size_t, c_u64, c_float, c_double = (
+    C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.c_float, C.c_double)
+P = c_void_p  # every device/host buffer crosses the ABI as a raw pointer
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/leafhip.h
+SIGNATURES = {
+    "lf_version": [],
+    "lf_last_error": [],
+    "lf_pack_hwc_u8_to_nchw_f32": [P, P, c_int, c_int, c_int, P, P, P],
+    "lf_hist_u8": [P, P, c_int, c_int, c_int, P],
+    "lf_autocontrast_lut": [P, P, P, c_int, P],
+    "lf_lut_apply_u8": [P, P, P, c_int, c_int, c_int, P],
+    "lf_flip_u8": [P, P, P, c_int, c_int, c_int, P],
+    "lf_noise_wrap_add_u8": [P, P, P, c_size_t, P],
+    "lf_noise_philox_add_u8": [P, P, c_size_t, c_u64, c_float, P],
+    "lf_mask_composite_u8": [P, P, P, c_int, c_int, c_int, c_int, P],
+    "lf_rgb2hsv_u8": [P, P, c_size_t, P],
+    "lf_rgb2gray_u8": [P, P, c_size_t, P],
+    "lf_gauss_blur_u8": [P, P, c_int, c_int, c_int, c_int, P, c_int, P],
+    "lf_hsv_region_stats": [P, P, P, c_int, c_int, c_int, P],
+    "lf_warp_bicubic_u8": [P, P, P, c_int, c_int, c_int, c_int, P],
+    "lf_affine_nearest_fixed_u8": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "lf_resample_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int,
+                       c_int, P],
+}
+_RESTYPES = {"lf_last_error": C.c_char_p}
+
+
+class LeafHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libleafhip.so and bind every declared symbol.  Raises if anything is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = Path(os.environ.get("LEAFHIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise LeafHipError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C leaffliction_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(str(path))
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise LeafHipError(f"libleafhip.so does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _LIB = lib
+    return lib
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.lf_last_error()
+        raise LeafHipError(f"{name} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc

@@ -1,0 +1,852 @@
+// libleafhip — augmentation / input-side kernels (uint8, HBM-bound, bit-exact).
+//
+// All kernels are written for gfx950 (MI355X): 64-lane waves, 256-thread
+// workgroups, 12- or 16-byte per-lane global accesses so that one wave
+// instruction moves 768 B / 1 KiB of contiguous memory, LDS for per-image tables
+// and histograms.  No kernel here is GEMM-shaped; the bound is HBM (or VALU for the
+// 15x15 blur) — see DESIGN.md §kernels.
+//
+// This translation unit is compiled with -ffp-contract=off: the double-precision
+// arithmetic below restates Python / Pillow expressions whose mul and add round
+// separately.
+#include "lf_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ unsigned byte_of(unsigned w, int i) { return (w >> (8 * i)) & 0xffu; }
+
+// ---------------------------------------------------------------------------
+// pack: u8 HWC -> f32 NCHW, x/255 (+ optional per-channel normalisation)
+// ---------------------------------------------------------------------------
+// One thread = 4 pixels = 12 input bytes (3 dwords) -> one float4 per plane.
+template <bool NORM>
+__global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t* __restrict__ in,
+                                                      float* __restrict__ out, unsigned hw4,
+                                                      float m0, float m1, float m2, float d0,
+                                                      float d1, float d2) {
+    const unsigned n = blockIdx.y;
+    const size_t hw = (size_t)hw4 * 4;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (size_t)n * hw * 3);
+    float* dst = out + (size_t)n * hw * 3;
+    for (unsigned g = blockIdx.x * kBlock + threadIdx.x; g < hw4; g += gridDim.x * kBlock) {
+        const unsigned w0 = src[3 * g + 0], w1 = src[3 * g + 1], w2 = src[3 * g + 2];
+        float r[4] = {(float)byte_of(w0, 0), (float)byte_of(w0, 3), (float)byte_of(w1, 2),
+                      (float)byte_of(w2, 1)};
+        float gch[4] = {(float)byte_of(w0, 1), (float)byte_of(w1, 0), (float)byte_of(w1, 3),
+                        (float)byte_of(w2, 2)};
+        float b[4] = {(float)byte_of(w0, 2), (float)byte_of(w1, 1), (float)byte_of(w2, 0),
+                      (float)byte_of(w2, 3)};
+        float4 o0, o1, o2;
+        float* pr = reinterpret_cast<float*>(&o0);
+        float* pg = reinterpret_cast<float*>(&o1);
+        float* pb = reinterpret_cast<float*>(&o2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float vr = __fdiv_rn(r[i], 255.0f), vg = __fdiv_rn(gch[i], 255.0f),
+                  vb = __fdiv_rn(b[i], 255.0f);
+            if (NORM) {
+                vr = __fdiv_rn(__fsub_rn(vr, m0), d0);
+                vg = __fdiv_rn(__fsub_rn(vg, m1), d1);
+                vb = __fdiv_rn(__fsub_rn(vb, m2), d2);
+            }
+            pr[i] = vr;
+            pg[i] = vg;
+            pb[i] = vb;
+        }
+        reinterpret_cast<float4*>(dst)[g] = o0;
+        reinterpret_cast<float4*>(dst + hw)[g] = o1;
+        reinterpret_cast<float4*>(dst + 2 * hw)[g] = o2;
+    }
+}
+
+// Generic fallback (H*W not a multiple of 4): one thread per pixel.
+template <bool NORM>
+__global__ __launch_bounds__(kBlock) void pack_scalar_kernel(const uint8_t* __restrict__ in,
+                                                             float* __restrict__ out, size_t hw,
+                                                             float m0, float m1, float m2,
+                                                             float d0, float d1, float d2) {
+    const unsigned n = blockIdx.y;
+    const uint8_t* src = in + (size_t)n * hw * 3;
+    float* dst = out + (size_t)n * hw * 3;
+    const float m[3] = {m0, m1, m2}, d[3] = {d0, d1, d2};
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < hw;
+         p += (size_t)gridDim.x * kBlock) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = __fdiv_rn((float)src[3 * p + c], 255.0f);
+            if (NORM) v = __fdiv_rn(__fsub_rn(v, m[c]), d[c]);
+            dst[(size_t)c * hw + p] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// hist: per image, per channel 256-bin histogram (int32, exact)
+// ---------------------------------------------------------------------------
+// grid = (splits, n).  Each wave owns a private 3x256 LDS histogram so that the
+// 64 lanes of one ds_add only collide with each other; the four copies are summed
+// and flushed with one global atomic per bin per workgroup.
+constexpr int kHistCopies = kBlock / 64;
+
+__global__ __launch_bounds__(kBlock) void hist_kernel(const uint8_t* __restrict__ in,
+                                                      int32_t* __restrict__ hist, size_t nbytes) {
+    __shared__ unsigned lh[kHistCopies][768];
+    const unsigned n = blockIdx.y;
+    for (int i = threadIdx.x; i < kHistCopies * 768; i += kBlock) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    unsigned* my = lh[threadIdx.x >> 6];
+    const uint8_t* base = in + (size_t)n * nbytes;
+    // 16-byte aligned middle part [a0, a1) of this image's bytes; head/tail are scalar.
+    const size_t addr = reinterpret_cast<size_t>(base);
+    size_t head = (16 - (addr & 15)) & 15;
+    if (head > nbytes) head = nbytes;
+    const size_t nchunks = (nbytes - head) / 16;
+    const uint4* mid = reinterpret_cast<const uint4*>(base + head);
+    const unsigned hc = (unsigned)(head % 3);
+    for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < nchunks;
+         q += (size_t)gridDim.x * kBlock) {
+        const uint4 v = mid[q];
+        // channel of byte 0 of this chunk: (head + 16 q) % 3 = (hc + q) % 3
+        const unsigned r = (hc + (unsigned)(q % 3)) % 3;
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            unsigned c = r + (j % 3);
+            c = c >= 3 ? c - 3 : c;
+            atomicAdd(&my[c * 256 + byte_of(w[j >> 2], j & 3)], 1u);
+        }
+    }
+    if (blockIdx.x == 0) {
+        const size_t tail0 = head + nchunks * 16;
+        for (size_t i = threadIdx.x; i < head; i += kBlock)
+            atomicAdd(&my[(i % 3) * 256 + base[i]], 1u);
+        for (size_t i = tail0 + threadIdx.x; i < nbytes; i += kBlock)
+            atomicAdd(&my[(i % 3) * 256 + base[i]], 1u);
+    }
+    __syncthreads();
+    int32_t* gh = hist + (size_t)n * 768;
+    for (int i = threadIdx.x; i < 768; i += kBlock) {
+        unsigned s = 0;
+#pragma unroll
+        for (int k = 0; k < kHistCopies; ++k) s += lh[k][i];
+        if (s) atomicAdd(&gh[i], (int32_t)s);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// autocontrast LUT (Pillow ImageOps.autocontrast arithmetic, IEEE double)
+// ---------------------------------------------------------------------------
+// Python's float floor division x // y for y > 0 (CPython floatobject.c _float_div_mod).
+__device__ double py_floordiv(double vx, double wx) {
+    double mod = fmod(vx, wx);
+    double div = __ddiv_rn(__dsub_rn(vx, mod), wx);
+    if (mod != 0.0) {
+        if ((wx < 0) != (mod < 0)) {
+            div = __dsub_rn(div, 1.0);
+        }
+    }
+    if (div != 0.0) {
+        double f = floor(div);
+        if (__dsub_rn(div, f) > 0.5) f = __dadd_rn(f, 1.0);
+        return f;
+    }
+    return copysign(0.0, __ddiv_rn(vx, wx));
+}
+
+// One thread per (image, channel); 256-entry scans are tiny next to the image passes.
+__global__ void autocontrast_lut_kernel(const int32_t* __restrict__ hist,
+                                        const double* __restrict__ cutoff,
+                                        uint8_t* __restrict__ lut, int total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int n = t / 3;
+    const int32_t* hsrc = hist + (size_t)t * 256;
+    uint8_t* dst = lut + (size_t)t * 256;
+    int h[256];
+    long long npx = 0;
+    for (int i = 0; i < 256; ++i) {
+        h[i] = hsrc[i];
+        npx += h[i];
+    }
+    const double co = cutoff[n];
+    if (co != 0.0) {
+        // cut = int(n * cutoff // 100)
+        long long cut = (long long)py_floordiv(__dmul_rn((double)npx, co), 100.0);
+        for (int lo = 0; lo < 256; ++lo) {
+            if (cut > h[lo]) {
+                cut -= h[lo];
+                h[lo] = 0;
+            } else {
+                h[lo] -= (int)cut;
+                cut = 0;
+            }
+            if (cut <= 0) break;
+        }
+        cut = (long long)py_floordiv(__dmul_rn((double)npx, co), 100.0);
+        for (int hi = 255; hi >= 0; --hi) {
+            if (cut > h[hi]) {
+                cut -= h[hi];
+                h[hi] = 0;
+            } else {
+                h[hi] -= (int)cut;
+                cut = 0;
+            }
+            if (cut <= 0) break;
+        }
+    }
+    int lo = 0, hi = 255;
+    for (lo = 0; lo < 256; ++lo)
+        if (h[lo]) break;
+    if (lo == 256) lo = 255;  // Python: loop variable keeps its last value
+    for (hi = 255; hi >= 0; --hi)
+        if (h[hi]) break;
+    if (hi < 0) hi = 0;
+    if (hi <= lo) {
+        for (int i = 0; i < 256; ++i) dst[i] = (uint8_t)i;
+    } else {
+        const double scale = __ddiv_rn(255.0, (double)(hi - lo));
+        const double offset = __dmul_rn(-(double)lo, scale);
+        for (int i = 0; i < 256; ++i) {
+            int v = (int)__dadd_rn(__dmul_rn((double)i, scale), offset);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            dst[i] = (uint8_t)v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LUT apply (Image.point)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void lut_apply_kernel(const uint8_t* __restrict__ in,
+                                                           const uint8_t* __restrict__ lut,
+                                                           uint8_t* __restrict__ out,
+                                                           size_t nbytes) {
+    __shared__ uint8_t sl[768];
+    const unsigned n = blockIdx.y;
+    for (int i = threadIdx.x; i < 768; i += kBlock) sl[i] = lut[(size_t)n * 768 + i];
+    __syncthreads();
+    const uint8_t* src = in + (size_t)n * nbytes;
+    uint8_t* dst = out + (size_t)n * nbytes;
+    const size_t nchunks = nbytes / 16;  // caller guarantees 16-byte aligned images
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < nchunks;
+         q += (size_t)gridDim.x * kBlock) {
+        const uint4 v = s4[q];
+        const unsigned r = (unsigned)(q % 3);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        unsigned o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            unsigned c = r + (j % 3);
+            c = c >= 3 ? c - 3 : c;
+            o[j >> 2] |= (unsigned)sl[c * 256 + byte_of(w[j >> 2], j & 3)] << (8 * (j & 3));
+        }
+        d4[q] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = nchunks * 16 + threadIdx.x; i < nbytes; i += kBlock)
+            dst[i] = sl[(i % 3) * 256 + src[i]];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void lut_apply_scalar_kernel(const uint8_t* __restrict__ in,
+                                                                  const uint8_t* __restrict__ lut,
+                                                                  uint8_t* __restrict__ out,
+                                                                  size_t nbytes) {
+    __shared__ uint8_t sl[768];
+    const unsigned n = blockIdx.y;
+    for (int i = threadIdx.x; i < 768; i += kBlock) sl[i] = lut[(size_t)n * 768 + i];
+    __syncthreads();
+    const uint8_t* src = in + (size_t)n * nbytes;
+    uint8_t* dst = out + (size_t)n * nbytes;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nbytes;
+         i += (size_t)gridDim.x * kBlock)
+        dst[i] = sl[(i % 3) * 256 + src[i]];
+}
+
+// ---------------------------------------------------------------------------
+// flip
+// ---------------------------------------------------------------------------
+// One thread = 4 pixels (12 bytes).  w % 4 == 0.
+__global__ __launch_bounds__(kBlock) void flip_kernel(const uint8_t* __restrict__ in,
+                                                      uint8_t* __restrict__ out,
+                                                      const int32_t* __restrict__ mode, int h,
+                                                      int w4) {
+    const unsigned n = blockIdx.y;
+    const int m = mode[n];
+    const size_t img = (size_t)h * w4 * 3;  // dwords per image
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in) + (size_t)n * img;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out) + (size_t)n * img;
+    const unsigned total = (unsigned)h * w4;
+    for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
+        const unsigned y = t / w4, g = t - y * w4;
+        if (m == 0) {  // FLIP_LEFT_RIGHT: reverse the pixel order of the mirrored group
+            const uint32_t* s = src + ((size_t)y * w4 + (w4 - 1 - g)) * 3;
+            const unsigned w0 = s[0], w1 = s[1], w2 = s[2];
+            const unsigned o0 = byte_of(w2, 1) | byte_of(w2, 2) << 8 | byte_of(w2, 3) << 16 |
+                                byte_of(w1, 2) << 24;
+            const unsigned o1 = byte_of(w1, 3) | byte_of(w2, 0) << 8 | byte_of(w0, 3) << 16 |
+                                byte_of(w1, 0) << 24;
+            const unsigned o2 = byte_of(w1, 1) | byte_of(w0, 0) << 8 | byte_of(w0, 1) << 16 |
+                                byte_of(w0, 2) << 24;
+            uint32_t* d = dst + (size_t)t * 3;
+            d[0] = o0;
+            d[1] = o1;
+            d[2] = o2;
+        } else {  // FLIP_TOP_BOTTOM
+            const uint32_t* s = src + ((size_t)(h - 1 - y) * w4 + g) * 3;
+            uint32_t* d = dst + (size_t)t * 3;
+            d[0] = s[0];
+            d[1] = s[1];
+            d[2] = s[2];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void flip_scalar_kernel(const uint8_t* __restrict__ in,
+                                                             uint8_t* __restrict__ out,
+                                                             const int32_t* __restrict__ mode,
+                                                             int h, int w) {
+    const unsigned n = blockIdx.y;
+    const int m = mode[n];
+    const size_t img = (size_t)h * w * 3;
+    const uint8_t* src = in + (size_t)n * img;
+    uint8_t* dst = out + (size_t)n * img;
+    const size_t total = (size_t)h * w;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * kBlock) {
+        const size_t y = t / w, x = t - y * w;
+        const size_t s = m == 0 ? (y * w + (w - 1 - x)) : ((h - 1 - y) * w + x);
+        dst[3 * t] = src[3 * s];
+        dst[3 * t + 1] = src[3 * s + 1];
+        dst[3 * t + 2] = src[3 * s + 2];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// noise add with uint8 wrap-around
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void noise_add_kernel(const uint8_t* __restrict__ in,
+                                                           const double* __restrict__ noise,
+                                                           uint8_t* __restrict__ out, size_t n) {
+    // numpy float64 -> uint8 astype on x86-64: truncate toward zero, keep the low 8 bits.
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kBlock) {
+        const long long t = (long long)noise[i];
+        out[i] = (uint8_t)(in[i] + (uint8_t)t);
+    }
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t* r) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+// One thread = 4 bytes: one Philox block -> two Box-Muller pairs.
+__global__ __launch_bounds__(kBlock) void noise_philox_kernel(const uint8_t* __restrict__ in,
+                                                              uint8_t* __restrict__ out,
+                                                              size_t nwords, size_t nbytes,
+                                                              uint64_t seed, float sigma) {
+    for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < nwords;
+         q += (size_t)gridDim.x * kBlock) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 0u, 0u, (uint32_t)seed,
+                      (uint32_t)(seed >> 32), r);
+        float z[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float u1 = ((float)(r[2 * k] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float u2 = ((float)(r[2 * k + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float rad = sigma * __fsqrt_rn(-2.0f * __logf(u1));
+            float s, c;
+            __sincosf(6.283185307179586f * u2, &s, &c);
+            z[2 * k] = rad * c;
+            z[2 * k + 1] = rad * s;
+        }
+        const size_t b = q * 4;
+        if (b + 4 <= nbytes) {
+            const unsigned v = reinterpret_cast<const uint32_t*>(in)[q];
+            unsigned o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o |= ((byte_of(v, j) + (unsigned)(int)z[j]) & 0xffu) << (8 * j);
+            reinterpret_cast<uint32_t*>(out)[q] = o;
+        } else {
+            for (size_t i = b; i < nbytes; ++i) out[i] = (uint8_t)(in[i] + (uint8_t)(int)z[i - b]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// mask-and-composite
+// ---------------------------------------------------------------------------
+// One thread = 4 pixels: 12 image bytes + 4 mask bytes.
+__global__ __launch_bounds__(kBlock) void composite_kernel(const uint8_t* __restrict__ img,
+                                                           const uint8_t* __restrict__ mask,
+                                                           uint8_t* __restrict__ out, size_t npx4,
+                                                           unsigned fill) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(img);
+    const uint32_t* m = reinterpret_cast<const uint32_t*>(mask);
+    uint32_t* d = reinterpret_cast<uint32_t*>(out);
+    const unsigned f4 = fill * 0x01010101u;
+    for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < npx4;
+         g += (size_t)gridDim.x * kBlock) {
+        const unsigned mk = m[g];
+        const unsigned w0 = s[3 * g], w1 = s[3 * g + 1], w2 = s[3 * g + 2];
+        // per-pixel keep masks expanded to the byte lanes each pixel occupies
+        const unsigned k0 = byte_of(mk, 0) > 127, k1 = byte_of(mk, 1) > 127,
+                       k2 = byte_of(mk, 2) > 127, k3 = byte_of(mk, 3) > 127;
+        const unsigned m0 = (k0 ? 0x00ffffffu : 0u) | (k1 ? 0xff000000u : 0u);
+        const unsigned m1 = (k1 ? 0x0000ffffu : 0u) | (k2 ? 0xffff0000u : 0u);
+        const unsigned m2 = (k2 ? 0x000000ffu : 0u) | (k3 ? 0xffffff00u : 0u);
+        d[3 * g] = (w0 & m0) | (f4 & ~m0);
+        d[3 * g + 1] = (w1 & m1) | (f4 & ~m1);
+        d[3 * g + 2] = (w2 & m2) | (f4 & ~m2);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void composite_scalar_kernel(const uint8_t* __restrict__ img,
+                                                                  const uint8_t* __restrict__ mask,
+                                                                  uint8_t* __restrict__ out,
+                                                                  size_t start, size_t npx,
+                                                                  unsigned fill) {
+    for (size_t p = start + (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx;
+         p += (size_t)gridDim.x * kBlock) {
+        const bool keep = mask[p] > 127;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 * p + c] = keep ? img[3 * p + c] : (uint8_t)fill;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// OpenCV 8-bit colour conversions
+// ---------------------------------------------------------------------------
+// OpenCV RGB2HSV_b (imgproc color_hsv): hsv_shift = 12, tables
+// sdiv[i] = cvRound((255<<12)/i), hdiv180[i] = cvRound((180<<12)/(6 i)), [0] = 0.
+__device__ __forceinline__ void build_hsv_tables(int* sdiv, int* hdiv) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        if (i == 0) {
+            sdiv[0] = 0;
+            hdiv[0] = 0;
+        } else {
+            sdiv[i] = __double2int_rn(__ddiv_rn(1044480.0, (double)i));
+            hdiv[i] = __double2int_rn(__ddiv_rn(737280.0, __dmul_rn(6.0, (double)i)));
+        }
+    }
+}
+
+__device__ __forceinline__ void rgb2hsv_px(int r, int g, int b, const int* sdiv, const int* hdiv,
+                                           int& h, int& s, int& v) {
+    v = max(r, max(g, b));
+    const int vmin = min(r, min(g, b));
+    const int diff = v - vmin;
+    const int vr = v == r ? -1 : 0;
+    const int vg = v == g ? -1 : 0;
+    s = (diff * sdiv[v] + (1 << 11)) >> 12;
+    h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    h = (h * hdiv[diff] + (1 << 11)) >> 12;
+    h += h < 0 ? 180 : 0;
+}
+
+__device__ __forceinline__ void unpack4(unsigned w0, unsigned w1, unsigned w2, int* r, int* g,
+                                        int* b) {
+    r[0] = byte_of(w0, 0); g[0] = byte_of(w0, 1); b[0] = byte_of(w0, 2);
+    r[1] = byte_of(w0, 3); g[1] = byte_of(w1, 0); b[1] = byte_of(w1, 1);
+    r[2] = byte_of(w1, 2); g[2] = byte_of(w1, 3); b[2] = byte_of(w2, 0);
+    r[3] = byte_of(w2, 1); g[3] = byte_of(w2, 2); b[3] = byte_of(w2, 3);
+}
+
+__global__ __launch_bounds__(kBlock) void rgb2hsv_kernel(const uint8_t* __restrict__ rgb,
+                                                         uint8_t* __restrict__ hsv, size_t npx) {
+    __shared__ int sdiv[256], hdiv[256];
+    build_hsv_tables(sdiv, hdiv);
+    __syncthreads();
+    const size_t npx4 = npx / 4;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(rgb);
+    uint32_t* d = reinterpret_cast<uint32_t*>(hsv);
+    for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < npx4;
+         q += (size_t)gridDim.x * kBlock) {
+        int r[4], g[4], b[4], hh[4], ss[4], vv[4];
+        unpack4(s[3 * q], s[3 * q + 1], s[3 * q + 2], r, g, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rgb2hsv_px(r[i], g[i], b[i], sdiv, hdiv, hh[i], ss[i], vv[i]);
+        d[3 * q] = hh[0] | ss[0] << 8 | vv[0] << 16 | hh[1] << 24;
+        d[3 * q + 1] = ss[1] | vv[1] << 8 | hh[2] << 16 | ss[2] << 24;
+        d[3 * q + 2] = vv[2] | hh[3] << 8 | ss[3] << 16 | vv[3] << 24;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t p = npx4 * 4 + threadIdx.x; p < npx; p += kBlock) {
+            int h, sv, v;
+            rgb2hsv_px(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2], sdiv, hdiv, h, sv, v);
+            hsv[3 * p] = (uint8_t)h;
+            hsv[3 * p + 1] = (uint8_t)sv;
+            hsv[3 * p + 2] = (uint8_t)v;
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned gray_px(int r, int g, int b) {
+    return (unsigned)(r * 4899 + g * 9617 + b * 1868 + 8192) >> 14;
+}
+
+__global__ __launch_bounds__(kBlock) void rgb2gray_kernel(const uint8_t* __restrict__ rgb,
+                                                          uint8_t* __restrict__ gray, size_t npx) {
+    const size_t npx4 = npx / 4;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(rgb);
+    uint32_t* d = reinterpret_cast<uint32_t*>(gray);
+    for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < npx4;
+         q += (size_t)gridDim.x * kBlock) {
+        int r[4], g[4], b[4];
+        unpack4(s[3 * q], s[3 * q + 1], s[3 * q + 2], r, g, b);
+        d[q] = gray_px(r[0], g[0], b[0]) | gray_px(r[1], g[1], b[1]) << 8 |
+               gray_px(r[2], g[2], b[2]) << 16 | gray_px(r[3], g[3], b[3]) << 24;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t p = npx4 * 4 + threadIdx.x; p < npx; p += kBlock)
+            gray[p] = (uint8_t)gray_px(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// HSV colour-region statistics (hist.py)
+// ---------------------------------------------------------------------------
+// grid = (splits, n).  Per pixel: fused RGB->HSV, leaf predicate, 13 region predicates
+// (wave ballot + popcount), and H/S/V 256-bin histograms over the leaf pixels.
+__global__ __launch_bounds__(kBlock) void hsv_stats_kernel(const uint8_t* __restrict__ rgb,
+                                                           int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ hsv_hist,
+                                                           size_t npx) {
+    __shared__ int sdiv[256], hdiv[256];
+    __shared__ unsigned lh[768];
+    __shared__ unsigned lc[LF_HSV_NCOUNTS];
+    build_hsv_tables(sdiv, hdiv);
+    for (int i = threadIdx.x; i < 768; i += kBlock) lh[i] = 0;
+    if (threadIdx.x < LF_HSV_NCOUNTS) lc[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned n = blockIdx.y;
+    const uint8_t* src = rgb + (size_t)n * npx * 3;
+    unsigned cnt[LF_HSV_NCOUNTS];
+#pragma unroll
+    for (int i = 0; i < LF_HSV_NCOUNTS; ++i) cnt[i] = 0;
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx;
+         p += (size_t)gridDim.x * kBlock) {
+        int h, s, v;
+        rgb2hsv_px(src[3 * p], src[3 * p + 1], src[3 * p + 2], sdiv, hdiv, h, s, v);
+        const bool leaf = (s > 10) && (v > 15) && (v < 245);
+        if (leaf) {
+            atomicAdd(&lh[h], 1u);
+            atomicAdd(&lh[256 + s], 1u);
+            atomicAdd(&lh[512 + v], 1u);
+            cnt[0] += 1;
+            cnt[1] += (h >= 35) && (h <= 85) && (s >= 40) && (v >= 30);           // Vert Sain
+            cnt[2] += (h >= 20) && (h <= 40) && (s >= 25) && (v >= 30);           // Vert Jaunatre
+            cnt[3] += (h >= 15) && (h <= 35) && (s >= 50) && (v >= 50);           // Jaune
+            cnt[4] += ((h <= 25) || (h >= 160)) && (s >= 30) && (v >= 20);        // Brun/Orange
+            cnt[5] += (((h >= 160) && (h <= 180)) || (h <= 10)) && (s >= 40) && (v >= 30);  // Rouge
+            cnt[6] += (v <= 50) && (s >= 20);                                     // Zones Sombres
+            cnt[7] += (v >= 200) && (s <= 30);                                    // Zones Claires
+            cnt[8] += (h >= 120) && (h <= 160) && (s >= 20);                      // Violet/Pourpre
+            cnt[9] += (h >= 35) && (h <= 85);                                     // hue: Vert
+            cnt[10] += (h >= 15) && (h <= 35);                                    // hue: Jaune/Orange
+            cnt[11] += (h <= 15) || (h >= 160);                                   // hue: Rouge
+            cnt[12] += (h >= 120) && (h <= 160);                                  // hue: Violet
+            cnt[13] += ((h > 85) && (h < 120));  // hue: Autres ((h>35)&(h<15) is empty)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LF_HSV_NCOUNTS; ++i) {
+        unsigned v = cnt[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lc[i], v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 768; i += kBlock)
+        if (lh[i]) atomicAdd(&hsv_hist[(size_t)n * 768 + i], (int32_t)lh[i]);
+    if (threadIdx.x < LF_HSV_NCOUNTS && lc[threadIdx.x])
+        atomicAdd(&counts[(size_t)n * LF_HSV_NCOUNTS + threadIdx.x], (int32_t)lc[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
+// Gaussian blur, uint8, OpenCV fixed-point semantics, both passes fused via LDS
+// ---------------------------------------------------------------------------
+// Tile = kBT x kBT output pixels.  Stage (T+2r)x(T+2r) input with BORDER_REFLECT_101,
+// horizontal pass -> Q8.8 uint16 rows in LDS, vertical pass -> (acc + 2^15) >> 16.
+constexpr int kBT = 32;
+constexpr int kMaxR = 15;
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+template <int CH>
+__global__ __launch_bounds__(kBlock) void gauss_blur_kernel(const uint8_t* __restrict__ in,
+                                                            uint8_t* __restrict__ out, int h,
+                                                            int w, const uint16_t* __restrict__ kq,
+                                                            int ksize) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int r = ksize / 2;
+    const int pw = kBT + 2 * r;  // patch width/height in pixels
+    uint8_t* patch = smem;                                                     // [pw][pw*CH]
+    uint16_t* mid = reinterpret_cast<uint16_t*>(smem + ((pw * pw * CH + 15) & ~15));  // [pw][kBT*CH]
+    __shared__ unsigned kc[2 * kMaxR + 1];
+    if (threadIdx.x < ksize) kc[threadIdx.x] = kq[threadIdx.x];
+    const unsigned n = blockIdx.z;
+    const int x0 = blockIdx.x * kBT, y0 = blockIdx.y * kBT;
+    const uint8_t* src = in + (size_t)n * h * w * CH;
+    uint8_t* dst = out + (size_t)n * h * w * CH;
+    for (int i = threadIdx.x; i < pw * pw; i += kBlock) {
+        const int py = i / pw, px = i - py * pw;
+        const int sy = reflect101(y0 + py - r, h), sx = reflect101(x0 + px - r, w);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) patch[i * CH + c] = src[((size_t)sy * w + sx) * CH + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < pw * kBT * CH; i += kBlock) {
+        const int py = i / (kBT * CH), rem = i - py * (kBT * CH);
+        const uint8_t* p = patch + py * pw * CH + rem;  // window start (x - r) for this channel
+        unsigned acc = 0;
+        for (int k = 0; k < ksize; ++k) acc += kc[k] * p[k * CH];
+        mid[i] = (uint16_t)acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBT * kBT * CH; i += kBlock) {
+        const int ty = i / (kBT * CH), rem = i - ty * (kBT * CH);
+        const int tx = rem / CH;
+        if (y0 + ty >= h || x0 + tx >= w) continue;
+        const uint16_t* p = mid + ty * (kBT * CH) + rem;
+        unsigned acc = 0;
+        for (int k = 0; k < ksize; ++k) acc += kc[k] * p[k * kBT * CH];
+        dst[((size_t)(y0 + ty) * w + x0) * CH + rem] = (uint8_t)((acc + (1u << 15)) >> 16);
+    }
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int lf_pack_hwc_u8_to_nchw_f32(const uint8_t* in, float* out, int n, int h, int w,
+                               const float* mean3, const float* denom3, lf_stream_t stream) {
+    LF_REQUIRE(in && out, "lf_pack: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_pack: bad dims n=%d h=%d w=%d", n, h, w);
+    LF_REQUIRE((mean3 == nullptr) == (denom3 == nullptr), "lf_pack: mean/denom must both be set");
+    const size_t hw = (size_t)h * w;
+    float m[3] = {0, 0, 0}, d[3] = {1, 1, 1};
+    const bool norm = mean3 != nullptr;
+    if (norm) {
+        // mean/denom are HOST pointers (3 floats each): they are model constants.
+        for (int c = 0; c < 3; ++c) {
+            m[c] = mean3[c];
+            d[c] = denom3[c];
+        }
+    }
+    hipStream_t s = lf::as_stream(stream);
+    if (hw % 4 == 0) {
+        dim3 grid(lf::stream_grid(hw / 4, kBlock, 64), n);
+        if (norm)
+            pack_kernel<true><<<grid, kBlock, 0, s>>>(in, out, (unsigned)(hw / 4), m[0], m[1], m[2],
+                                                      d[0], d[1], d[2]);
+        else
+            pack_kernel<false><<<grid, kBlock, 0, s>>>(in, out, (unsigned)(hw / 4), m[0], m[1],
+                                                       m[2], d[0], d[1], d[2]);
+    } else {
+        dim3 grid(lf::stream_grid(hw, kBlock, 64), n);
+        if (norm)
+            pack_scalar_kernel<true><<<grid, kBlock, 0, s>>>(in, out, hw, m[0], m[1], m[2], d[0],
+                                                             d[1], d[2]);
+        else
+            pack_scalar_kernel<false><<<grid, kBlock, 0, s>>>(in, out, hw, m[0], m[1], m[2], d[0],
+                                                              d[1], d[2]);
+    }
+    return lf::check_launch("lf_pack");
+}
+
+int lf_hist_u8(const uint8_t* in, int32_t* hist, int n, int h, int w, lf_stream_t stream) {
+    LF_REQUIRE(in && hist, "lf_hist: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_hist: bad dims n=%d h=%d w=%d", n, h, w);
+    hipStream_t s = lf::as_stream(stream);
+    const size_t nbytes = (size_t)h * w * 3;
+    if (hipMemsetAsync(hist, 0, (size_t)n * 768 * sizeof(int32_t), s) != hipSuccess) {
+        lf::set_error("lf_hist: memset failed");
+        return LF_ERR_LAUNCH;
+    }
+    // enough workgroups per image that small batches still fill the chip
+    unsigned splits = n >= 2048 ? 1 : (unsigned)((2048 + n - 1) / n);
+    const unsigned maxs = lf::stream_grid(nbytes / 16 + 1, kBlock, 64);
+    if (splits > maxs) splits = maxs;
+    dim3 grid(splits, n);
+    hist_kernel<<<grid, kBlock, 0, s>>>(in, hist, nbytes);
+    return lf::check_launch("lf_hist");
+}
+
+int lf_autocontrast_lut(const int32_t* hist, const double* cutoff, uint8_t* lut, int n,
+                        lf_stream_t stream) {
+    LF_REQUIRE(hist && cutoff && lut, "lf_autocontrast_lut: null buffer");
+    LF_REQUIRE(n > 0, "lf_autocontrast_lut: bad n=%d", n);
+    const int total = n * 3;
+    autocontrast_lut_kernel<<<(total + 63) / 64, 64, 0, lf::as_stream(stream)>>>(hist, cutoff, lut,
+                                                                               total);
+    return lf::check_launch("lf_autocontrast_lut");
+}
+
+int lf_lut_apply_u8(const uint8_t* in, const uint8_t* lut, uint8_t* out, int n, int h, int w,
+                    lf_stream_t stream) {
+    LF_REQUIRE(in && lut && out, "lf_lut_apply: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_lut_apply: bad dims n=%d h=%d w=%d", n, h, w);
+    const size_t nbytes = (size_t)h * w * 3;
+    hipStream_t s = lf::as_stream(stream);
+    unsigned splits = n >= 2048 ? 1 : (unsigned)((2048 + n - 1) / n);
+    const bool aligned = nbytes % 16 == 0 && ((reinterpret_cast<size_t>(in) |
+                                               reinterpret_cast<size_t>(out)) & 15) == 0;
+    if (aligned) {
+        const unsigned maxs = lf::stream_grid(nbytes / 16, kBlock, 64);
+        if (splits > maxs) splits = maxs;
+        lut_apply_kernel<<<dim3(splits, n), kBlock, 0, s>>>(in, lut, out, nbytes);
+    } else {
+        const unsigned maxs = lf::stream_grid(nbytes, kBlock, 64);
+        if (splits > maxs) splits = maxs;
+        lut_apply_scalar_kernel<<<dim3(splits, n), kBlock, 0, s>>>(in, lut, out, nbytes);
+    }
+    return lf::check_launch("lf_lut_apply");
+}
+
+int lf_flip_u8(const uint8_t* in, uint8_t* out, const int32_t* mode, int n, int h, int w,
+               lf_stream_t stream) {
+    LF_REQUIRE(in && out && mode, "lf_flip: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_flip: bad dims n=%d h=%d w=%d", n, h, w);
+    LF_REQUIRE(in != out, "lf_flip: in-place flip is not supported");
+    hipStream_t s = lf::as_stream(stream);
+    const bool aligned = w % 4 == 0 && ((reinterpret_cast<size_t>(in) |
+                                         reinterpret_cast<size_t>(out)) & 3) == 0;
+    if (aligned) {
+        dim3 grid(lf::stream_grid((size_t)h * (w / 4), kBlock, 64), n);
+        flip_kernel<<<grid, kBlock, 0, s>>>(in, out, mode, h, w / 4);
+    } else {
+        dim3 grid(lf::stream_grid((size_t)h * w, kBlock, 64), n);
+        flip_scalar_kernel<<<grid, kBlock, 0, s>>>(in, out, mode, h, w);
+    }
+    return lf::check_launch("lf_flip");
+}
+
+int lf_noise_wrap_add_u8(const uint8_t* in, const double* noise, uint8_t* out, size_t nbytes,
+                         lf_stream_t stream) {
+    LF_REQUIRE(in && noise && out, "lf_noise_wrap_add: null buffer");
+    LF_REQUIRE(nbytes > 0, "lf_noise_wrap_add: empty input");
+    noise_add_kernel<<<lf::stream_grid(nbytes, kBlock), kBlock, 0, lf::as_stream(stream)>>>(
+        in, noise, out, nbytes);
+    return lf::check_launch("lf_noise_wrap_add");
+}
+
+int lf_noise_philox_add_u8(const uint8_t* in, uint8_t* out, size_t nbytes, uint64_t seed,
+                           float sigma, lf_stream_t stream) {
+    LF_REQUIRE(in && out, "lf_noise_philox_add: null buffer");
+    LF_REQUIRE(nbytes > 0, "lf_noise_philox_add: empty input");
+    LF_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out)) & 3) == 0,
+               "lf_noise_philox_add: buffers must be 4-byte aligned");
+    const size_t nwords = (nbytes + 3) / 4;
+    noise_philox_kernel<<<lf::stream_grid(nwords, kBlock), kBlock, 0, lf::as_stream(stream)>>>(
+        in, out, nwords, nbytes, seed, sigma);
+    return lf::check_launch("lf_noise_philox_add");
+}
+
+int lf_mask_composite_u8(const uint8_t* img, const uint8_t* mask, uint8_t* out, int n, int h,
+                         int w, int color, lf_stream_t stream) {
+    LF_REQUIRE(img && mask && out, "lf_mask_composite: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_mask_composite: bad dims n=%d h=%d w=%d", n, h, w);
+    LF_REQUIRE(color == 0 || color == 255, "lf_mask_composite: color must be 0 or 255");
+    const size_t npx = (size_t)n * h * w;
+    hipStream_t s = lf::as_stream(stream);
+    const bool aligned = ((reinterpret_cast<size_t>(img) | reinterpret_cast<size_t>(mask) |
+                           reinterpret_cast<size_t>(out)) & 3) == 0;
+    const size_t npx4 = aligned ? npx / 4 : 0;
+    if (npx4)
+        composite_kernel<<<lf::stream_grid(npx4, kBlock), kBlock, 0, s>>>(img, mask, out, npx4,
+                                                                       (unsigned)color);
+    if (npx4 * 4 < npx)
+        composite_scalar_kernel<<<lf::stream_grid(npx - npx4 * 4, kBlock), kBlock, 0, s>>>(
+            img, mask, out, npx4 * 4, npx, (unsigned)color);
+    return lf::check_launch("lf_mask_composite");
+}
+
+int lf_rgb2hsv_u8(const uint8_t* rgb, uint8_t* hsv, size_t npixels, lf_stream_t stream) {
+    LF_REQUIRE(rgb && hsv, "lf_rgb2hsv: null buffer");
+    LF_REQUIRE(npixels > 0, "lf_rgb2hsv: empty input");
+    LF_REQUIRE(((reinterpret_cast<size_t>(rgb) | reinterpret_cast<size_t>(hsv)) & 3) == 0,
+               "lf_rgb2hsv: buffers must be 4-byte aligned");
+    rgb2hsv_kernel<<<lf::stream_grid(npixels / 4 + 1, kBlock), kBlock, 0, lf::as_stream(stream)>>>(
+        rgb, hsv, npixels);
+    return lf::check_launch("lf_rgb2hsv");
+}
+
+int lf_rgb2gray_u8(const uint8_t* rgb, uint8_t* gray, size_t npixels, lf_stream_t stream) {
+    LF_REQUIRE(rgb && gray, "lf_rgb2gray: null buffer");
+    LF_REQUIRE(npixels > 0, "lf_rgb2gray: empty input");
+    LF_REQUIRE(((reinterpret_cast<size_t>(rgb) | reinterpret_cast<size_t>(gray)) & 3) == 0,
+               "lf_rgb2gray: buffers must be 4-byte aligned");
+    rgb2gray_kernel<<<lf::stream_grid(npixels / 4 + 1, kBlock), kBlock, 0,
+                      lf::as_stream(stream)>>>(rgb, gray, npixels);
+    return lf::check_launch("lf_rgb2gray");
+}
+
+int lf_hsv_region_stats(const uint8_t* rgb, int32_t* counts, int32_t* hsv_hist, int n, int h,
+                        int w, lf_stream_t stream) {
+    LF_REQUIRE(rgb && counts && hsv_hist, "lf_hsv_region_stats: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_hsv_region_stats: bad dims n=%d h=%d w=%d", n, h, w);
+    hipStream_t s = lf::as_stream(stream);
+    if (hipMemsetAsync(counts, 0, (size_t)n * LF_HSV_NCOUNTS * sizeof(int32_t), s) != hipSuccess ||
+        hipMemsetAsync(hsv_hist, 0, (size_t)n * 768 * sizeof(int32_t), s) != hipSuccess) {
+        lf::set_error("lf_hsv_region_stats: memset failed");
+        return LF_ERR_LAUNCH;
+    }
+    const size_t npx = (size_t)h * w;
+    unsigned splits = n >= 2048 ? 1 : (unsigned)((2048 + n - 1) / n);
+    const unsigned maxs = lf::stream_grid(npx, kBlock, 64);
+    if (splits > maxs) splits = maxs;
+    hsv_stats_kernel<<<dim3(splits, n), kBlock, 0, s>>>(rgb, counts, hsv_hist, npx);
+    return lf::check_launch("lf_hsv_region_stats");
+}
+
+int lf_gauss_blur_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int channels,
+                     const uint16_t* kq, int ksize, lf_stream_t stream) {
+    LF_REQUIRE(in && out && kq, "lf_gauss_blur: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_gauss_blur: bad dims n=%d h=%d w=%d", n, h, w);
+    LF_REQUIRE(channels == 1 || channels == 3, "lf_gauss_blur: channels must be 1 or 3");
+    LF_REQUIRE(ksize >= 1 && ksize <= 2 * kMaxR + 1 && (ksize & 1), "lf_gauss_blur: bad ksize %d",
+               ksize);
+    LF_REQUIRE(in != out, "lf_gauss_blur: in-place blur is not supported");
+    const int pw = kBT + (ksize / 2) * 2;
+    const size_t lds = ((size_t)(pw * pw * channels + 15) & ~(size_t)15) +
+                       (size_t)pw * kBT * channels * sizeof(uint16_t);
+    dim3 grid((w + kBT - 1) / kBT, (h + kBT - 1) / kBT, n);
+    hipStream_t s = lf::as_stream(stream);
+    if (channels == 3)
+        gauss_blur_kernel<3><<<grid, kBlock, lds, s>>>(in, out, h, w, kq, ksize);
+    else
+        gauss_blur_kernel<1><<<grid, kBlock, lds, s>>>(in, out, h, w, kq, ksize);
+    return lf::check_launch("lf_gauss_blur");
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+"""Host-side launchers for the augmentation kernels of libleafhip.so.
+
+torch supplies device memory and the current HIP stream; every function checks dtype,
+contiguity and device on the host before handing raw pointers to the C ABI, so a kernel
+is never launched with operand shapes other than the ones its grid assumes.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_U8, _I32, _F32, _F64 = torch.uint8, torch.int32, torch.float32, torch.float64
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str, ndim: Optional[int] = None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.LeafHipError(f"{name}: expected a CUDA(HIP) tensor — there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    return t
+
+
+def _hwc(t: torch.Tensor, name: str):
+    _chk(t, _U8, name, 4)
+    n, h, w, c = t.shape
+    if c != 3 or n == 0:
+        raise ValueError(f"{name}: expected [N,H,W,3] with N>0, got {tuple(t.shape)}")
+    return n, h, w
+
+
+def pack_hwc_u8_to_nchw_f32(x: torch.Tensor, mean: Optional[Sequence[float]] = None,
+                            denom: Optional[Sequence[float]] = None,
+                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[N,H,W,3] u8 -> [N,3,H,W] f32 = x/255 (then (v-mean)/denom per channel if given)."""
+    n, h, w = _hwc(x, "pack.x")
+    if out is None:
+        out = torch.empty((n, 3, h, w), dtype=_F32, device=x.device)
+    _chk(out, _F32, "pack.out", 4)
+    if tuple(out.shape) != (n, 3, h, w):
+        raise ValueError("pack.out: shape mismatch")
+    m = d = None
+    if mean is not None:
+        m = (_lib.c_float * 3)(*[float(v) for v in mean])
+        d = (_lib.c_float * 3)(*[float(v) for v in denom])
+    _lib.call("lf_pack_hwc_u8_to_nchw_f32", x.data_ptr(), out.data_ptr(), n, h, w, m, d, _stream())
+    return out
+
+
+def hist_u8(x: torch.Tensor) -> torch.Tensor:
+    """Per-image per-channel 256-bin histogram, int32 [N,3,256]."""
+    n, h, w = _hwc(x, "hist.x")
+    hist = torch.empty((n, 3, 256), dtype=_I32, device=x.device)
+    _lib.call("lf_hist_u8", x.data_ptr(), hist.data_ptr(), n, h, w, _stream())
+    return hist
+
+
+def autocontrast_lut(hist: torch.Tensor, cutoff: torch.Tensor) -> torch.Tensor:
+    _chk(hist, _I32, "autocontrast_lut.hist", 3)
+    _chk(cutoff, _F64, "autocontrast_lut.cutoff", 1)
+    n = hist.shape[0]
+    if tuple(hist.shape) != (n, 3, 256) or cutoff.shape[0] != n:
+        raise ValueError("autocontrast_lut: hist must be [N,3,256] and cutoff [N]")
+    lut = torch.empty((n, 3, 256), dtype=_U8, device=hist.device)
+    _lib.call("lf_autocontrast_lut", hist.data_ptr(), cutoff.data_ptr(), lut.data_ptr(), n,
+              _stream())
+    return lut
+
+
+def lut_apply_u8(x: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
+    n, h, w = _hwc(x, "lut_apply.x")
+    _chk(lut, _U8, "lut_apply.lut", 3)
+    if tuple(lut.shape) != (n, 3, 256):
+        raise ValueError("lut_apply.lut: expected [N,3,256]")
+    out = torch.empty_like(x)
+    _lib.call("lf_lut_apply_u8", x.data_ptr(), lut.data_ptr(), out.data_ptr(), n, h, w, _stream())
+    return out
+
+
+def autocontrast_u8(x: torch.Tensor, cutoff: torch.Tensor) -> torch.Tensor:
+    """PIL ImageOps.autocontrast(img, cutoff) for a batch: hist -> LUT -> point."""
+    return lut_apply_u8(x, autocontrast_lut(hist_u8(x), cutoff))
+
+
+def flip_u8(x: torch.Tensor, mode: torch.Tensor) -> torch.Tensor:
+    """mode[n] = 0: FLIP_LEFT_RIGHT, 1: FLIP_TOP_BOTTOM."""
+    n, h, w = _hwc(x, "flip.x")
+    _chk(mode, _I32, "flip.mode", 1)
+    if mode.shape[0] != n:
+        raise ValueError("flip.mode: expected [N]")
+    out = torch.empty_like(x)
+    _lib.call("lf_flip_u8", x.data_ptr(), out.data_ptr(), mode.data_ptr(), n, h, w, _stream())
+    return out
+
+
+def noise_wrap_add_u8(x: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    _chk(x, _U8, "noise.x")
+    _chk(noise, _F64, "noise.noise")
+    if noise.shape != x.shape or x.numel() == 0:
+        raise ValueError("noise: noise must have the image's shape")
+    out = torch.empty_like(x)
+    _lib.call("lf_noise_wrap_add_u8", x.data_ptr(), noise.data_ptr(), out.data_ptr(), x.numel(),
+              _stream())
+    return out
+
+
+def noise_philox_add_u8(x: torch.Tensor, seed: int, sigma: float = 5.0) -> torch.Tensor:
+    _chk(x, _U8, "noise_philox.x")
+    if x.numel() == 0:
+        raise ValueError("noise_philox: empty input")
+    out = torch.empty_like(x)
+    _lib.call("lf_noise_philox_add_u8", x.data_ptr(), out.data_ptr(), x.numel(),
+              int(seed) & (2**64 - 1), float(sigma), _stream())
+    return out
+
+
+def mask_composite_u8(img: torch.Tensor, mask: torch.Tensor, mask_color: str = "white"):
+    """apply_mask: out = mask > 127 ? img : (255 if white else 0)."""
+    if mask_color.upper() == "WHITE":
+        color = 255
+    elif mask_color.upper() == "BLACK":
+        color = 0
+    else:
+        raise ValueError(f'Mask Color {mask_color} is not "white" or "black"!')
+    n, h, w = _hwc(img, "mask_composite.img")
+    _chk(mask, _U8, "mask_composite.mask", 3)
+    if tuple(mask.shape) != (n, h, w):
+        raise ValueError("mask_composite.mask: expected [N,H,W]")
+    out = torch.empty_like(img)
+    _lib.call("lf_mask_composite_u8", img.data_ptr(), mask.data_ptr(), out.data_ptr(), n, h, w,
+              color, _stream())
+    return out
+
+
+def rgb2hsv_u8(x: torch.Tensor) -> torch.Tensor:
+    n, h, w = _hwc(x, "rgb2hsv.x")
+    out = torch.empty_like(x)
+    _lib.call("lf_rgb2hsv_u8", x.data_ptr(), out.data_ptr(), n * h * w, _stream())
+    return out
+
+
+def rgb2gray_u8(x: torch.Tensor) -> torch.Tensor:
+    n, h, w = _hwc(x, "rgb2gray.x")
+    out = torch.empty((n, h, w), dtype=_U8, device=x.device)
+    _lib.call("lf_rgb2gray_u8", x.data_ptr(), out.data_ptr(), n * h * w, _stream())
+    return out
+
+
+def hsv_region_stats(x: torch.Tensor):
+    """Returns (counts int32 [N,14], hsv_hist int32 [N,3,256]) — see include/leafhip.h."""
+    n, h, w = _hwc(x, "hsv_region_stats.x")
+    counts = torch.empty((n, 14), dtype=_I32, device=x.device)
+    hh = torch.empty((n, 3, 256), dtype=_I32, device=x.device)
+    _lib.call("lf_hsv_region_stats", x.data_ptr(), counts.data_ptr(), hh.data_ptr(), n, h, w,
+              _stream())
+    return counts, hh
+
+
+def gaussian_kernel_q8(ksize: int, sigma: float) -> np.ndarray:
+    """OpenCV getGaussianKernel + 8.8 fixed-point quantisation (sum == 256).
+
+    sigma <= 0 follows cv2: 0.3*((ksize-1)*0.5 - 1) + 0.8.  The fixed-point conversion
+    rounds each tap and carries the rounding error forward so that the taps sum to 256
+    (OpenCV's getGaussianKernelFixedPoint_ED).  Parity unpinned: cv2 is not installable here.
+    """
+    if sigma <= 0:
+        sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    xs = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    k = np.exp(-(xs * xs) / (2.0 * sigma * sigma))
+    k /= k.sum()
+    q = np.zeros(ksize, dtype=np.int64)
+    err = 0.0
+    half = ksize // 2
+    # symmetric error diffusion from the edges towards the centre
+    for i in range(half):
+        v = k[i] * 256.0 + err
+        q[i] = q[ksize - 1 - i] = int(np.floor(v + 0.5))
+        err = v - q[i]
+    q[half] = 256 - 2 * int(q[:half].sum())
+    return q.astype(np.uint16)
+
+
+def gauss_blur_u8(x: torch.Tensor, ksize: int, sigma: float) -> torch.Tensor:
+    """cv2.GaussianBlur(x, (ksize, ksize), sigma) for [N,H,W,3] or [N,H,W] uint8."""
+    _chk(x, _U8, "gauss_blur.x")
+    if x.dim() == 4 and x.shape[-1] == 3:
+        n, h, w, ch = x.shape
+    elif x.dim() == 3:
+        (n, h, w), ch = x.shape, 1
+    else:
+        raise ValueError("gauss_blur.x: expected [N,H,W,3] or [N,H,W]")
+    kq = torch.from_numpy(gaussian_kernel_q8(ksize, sigma).astype(np.int16)).to(x.device)
+    out = torch.empty_like(x)
+    _lib.call("lf_gauss_blur_u8", x.data_ptr(), out.data_ptr(), n, h, w, ch, kq.data_ptr(), ksize,
+              _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------
+# geometric ops (Pillow semantics)
+# ---------------------------------------------------------------------------
+from .preprocessing import geometry as _geo  # noqa: E402
+
+
+def warp_bicubic_u8(x: torch.Tensor, coeffs: torch.Tensor, perspective: bool) -> torch.Tensor:
+    """Image.transform(size, AFFINE|PERSPECTIVE, coeffs, BICUBIC); coeffs f64 [N,8]."""
+    n, h, w = _hwc(x, "warp_bicubic.x")
+    _chk(coeffs, _F64, "warp_bicubic.coeffs", 2)
+    if tuple(coeffs.shape) != (n, 8):
+        raise ValueError("warp_bicubic.coeffs: expected [N,8] float64")
+    out = torch.empty_like(x)
+    _lib.call("lf_warp_bicubic_u8", x.data_ptr(), out.data_ptr(), coeffs.data_ptr(),
+              1 if perspective else 0, n, h, w, _stream())
+    return out
+
+
+def rotate_expand_u8(x: torch.Tensor, angles: Sequence[float], fill: int = 255):
+    """Image.rotate(angle, expand=True, fillcolor=white) (NEAREST) for each image of a batch.
+
+    Returns a list of [oh_i, ow_i, 3] uint8 views into one packed device buffer.
+    """
+    n, h, w = _hwc(x, "rotate_expand.x")
+    if len(angles) != n:
+        raise ValueError("rotate_expand: one angle per image")
+    fix, ohw, offs, off = [], [], [], 0
+    for a in angles:
+        m, nw, nh = _geo.rotate_expand_matrix(w, h, float(a))
+        fix.append(_geo.affine_fixed_coeffs(m))
+        ohw.append((nh, nw))
+        offs.append(off)
+        off += ((nh * nw * 3 + 15) // 16) * 16
+    dev = x.device
+    fix_t = torch.tensor(fix, dtype=_I32, device=dev)
+    ohw_t = torch.tensor(ohw, dtype=_I32, device=dev)
+    off_t = torch.tensor(offs, dtype=torch.int64, device=dev)
+    out = torch.empty(off, dtype=_U8, device=dev)
+    _lib.call("lf_affine_nearest_fixed_u8", x.data_ptr(), out.data_ptr(), fix_t.data_ptr(),
+              ohw_t.data_ptr(), off_t.data_ptr(), n, h, w, max(a * b for a, b in ohw), int(fill),
+              _stream())
+    return [out[o:o + oh * ow * 3].view(oh, ow, 3) for o, (oh, ow) in zip(offs, ohw)]
+
+
+def resample_u8(x: torch.Tensor, oh: int, ow: int, xb: torch.Tensor, xk: torch.Tensor,
+                yb: torch.Tensor, yk: torch.Tensor, per_image: bool) -> torch.Tensor:
+    """Pillow two-pass fixed-point resample with host-computed tables (int32 tensors)."""
+    n, h, w = _hwc(x, "resample.x")
+    for t, nm in ((xb, "xb"), (xk, "xk"), (yb, "yb"), (yk, "yk")):
+        _chk(t, _I32, f"resample.{nm}")
+    lead = (n,) if per_image else ()
+    kx, ky = xk.shape[-1], yk.shape[-1]
+    if (tuple(xb.shape) != lead + (ow, 2) or tuple(xk.shape) != lead + (ow, kx)
+            or tuple(yb.shape) != lead + (oh, 2) or tuple(yk.shape) != lead + (oh, ky)):
+        raise ValueError("resample: table shapes do not match (n, oh, ow)")
+    tmp = torch.empty((n, h, ow, 3), dtype=_U8, device=x.device)
+    out = torch.empty((n, oh, ow, 3), dtype=_U8, device=x.device)
+    _lib.call("lf_resample_u8", x.data_ptr(), tmp.data_ptr(), out.data_ptr(), n, h, w, oh, ow,
+              xb.data_ptr(), xk.data_ptr(), kx, yb.data_ptr(), yk.data_ptr(), ky,
+              1 if per_image else 0, _stream())
+    return out
+
+
+def resize_lanczos_u8(x: torch.Tensor, size: int) -> torch.Tensor:
+    """ImageTransforms.resize_image(img, (size,size)) (LANCZOS) for a same-sized batch."""
+    n, h, w = _hwc(x, "resize_lanczos.x")
+    if (h, w) == (size, size):
+        return x.clone()  # Image.resize returns a copy when nothing changes
+    xb, xk, _ = _geo.lanczos_coeffs(w, 0.0, float(w), size)
+    yb, yk, _ = _geo.lanczos_coeffs(h, 0.0, float(h), size)
+    dev = x.device
+    if w == size:  # Pillow skips the horizontal pass: identity table keeps the kernel generic
+        xb = np.stack([np.arange(size), np.ones(size)], 1).astype(np.int32)
+        xk = np.full((size, 1), 1 << _geo.PRECISION_BITS, dtype=np.int32)
+    if h == size:
+        yb = np.stack([np.arange(size), np.ones(size)], 1).astype(np.int32)
+        yk = np.full((size, 1), 1 << _geo.PRECISION_BITS, dtype=np.int32)
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (xb, xk, yb, yk)]
+    return resample_u8(x, size, size, t[0], t[1], t[2], t[3], per_image=False)
+
+
+def crop_resize_lanczos_u8(x: torch.Tensor, boxes: Sequence[Sequence[int]]) -> torch.Tensor:
+    """ImageAugmenter.crop: per image (left, top, nw, nh) crop then LANCZOS back to (W,H)."""
+    n, h, w = _hwc(x, "crop_resize.x")
+    if len(boxes) != n:
+        raise ValueError("crop_resize: one box per image")
+    tabs = [_geo.crop_resize_tables(w, h, *[int(v) for v in b]) for b in boxes]
+    kx = max(t[2] for t in tabs)
+    ky = max(t[5] for t in tabs)
+    xb = np.stack([t[0] for t in tabs])
+    xk = np.stack([_geo.pad_k(t[1], kx) for t in tabs])
+    yb = np.stack([t[3] for t in tabs])
+    yk = np.stack([_geo.pad_k(t[4], ky) for t in tabs])
+    dev = x.device
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (xb, xk, yb, yk)]
+    return resample_u8(x, h, w, t[0], t[1], t[2], t[3], per_image=True)

@@ -1,0 +1,115 @@
+"""GPU image augmenter with the reference's `ImageAugmenter` interface.
+
+Mirror of srcs/preprocessing/image_augmenter.py:12-133: six file->file operations
+`(image_path, output_path) -> bool`, dispatched by name, that never raise (log + False).
+The random parameters are drawn from the process-global `random` / `np.random` streams
+in exactly the reference's call order, so a given seed yields the reference's pixels;
+the pixel work runs on the device through `leaffliction_amd.ops` (bit-exact with
+Pillow, see tests/test_augment_gpu.py).  `draw_params` / `apply_batch` expose the same
+ops for whole batches (used by DatasetBalancer's batched GPU path).
+"""
+from __future__ import annotations
+
+import random
+from typing import Any, Dict, List, Sequence
+
+import numpy as np
+
+from ..utils.common import get_logger
+from ..utils.image_utils import ImageLoader
+
+logger = get_logger(__name__)
+
+TRANSFORMATIONS = ["flip", "rotate", "skew", "shear", "crop", "distortion"]
+NOISE_LEVEL = 5
+
+
+def draw_params(op: str, width: int, height: int) -> Dict[str, Any]:
+    """Draw one op's random parameters with the reference's RNG calls, in its order."""
+    if op == "flip":  # image_augmenter.py:23
+        return {"mode": 0 if random.choice([True, False]) else 1}
+    if op == "rotate":  # :36
+        return {"angle": random.uniform(-30, 30)}
+    if op == "skew":  # :48-59
+        f = random.uniform(0.05, 0.15)
+        return {"coeffs": [1 + f, 0, -f * width, 0, 1 + f, -f * height, 0, 0]}
+    if op == "shear":  # :77-82
+        s = random.uniform(-0.2, 0.2)
+        if random.choice([True, False]):
+            return {"coeffs": [1, s, 0, 0, 1, 0, 0, 0]}
+        return {"coeffs": [1, 0, 0, s, 1, 0, 0, 0]}
+    if op == "crop":  # :101-107
+        r = random.uniform(0.8, 0.95)
+        nw, nh = int(width * r), int(height * r)
+        left = random.randint(0, width - nw)
+        top = random.randint(0, height - nh)
+        return {"box": (left, top, nw, nh)}
+    if op == "distortion":  # :121, :127 — np.random first, then random.uniform
+        noise = np.random.normal(0, NOISE_LEVEL, (height, width, 3))
+        return {"noise": noise, "cutoff": random.uniform(0, 2)}
+    raise AttributeError(op)
+
+
+def apply_batch(op: str, x, params: Sequence[Dict[str, Any]]) -> List:
+    """Run `op` on a same-sized device batch x [N,H,W,3] u8.  Returns a list of N device
+    tensors [h_i, w_i, 3] (rotate changes the size, the others keep it)."""
+    import torch
+
+    from .. import ops
+    dev = x.device
+    if op == "flip":
+        mode = torch.tensor([p["mode"] for p in params], dtype=torch.int32, device=dev)
+        return list(ops.flip_u8(x, mode))
+    if op == "rotate":
+        return ops.rotate_expand_u8(x, [p["angle"] for p in params], fill=255)
+    if op in ("skew", "shear"):
+        co = torch.tensor([p["coeffs"] for p in params], dtype=torch.float64, device=dev)
+        return list(ops.warp_bicubic_u8(x, co, perspective=(op == "skew")))
+    if op == "crop":
+        return list(ops.crop_resize_lanczos_u8(x, [p["box"] for p in params]))
+    if op == "distortion":
+        noise = torch.from_numpy(np.stack([p["noise"] for p in params])).to(dev)
+        cutoff = torch.tensor([p["cutoff"] for p in params], dtype=torch.float64, device=dev)
+        return list(ops.autocontrast_u8(ops.noise_wrap_add_u8(x, noise), cutoff))
+    raise AttributeError(op)
+
+
+class ImageAugmenter:
+    NOISE_LEVEL = NOISE_LEVEL
+
+    def __init__(self, seed=None):
+        if seed:  # seed 0 leaves the RNGs unseeded, as in the reference (:15-18)
+            random.seed(seed)
+            np.random.seed(seed)
+
+    def _run(self, op: str, image_path, output_path) -> bool:
+        try:
+            import torch
+            img = ImageLoader.load_as_array(image_path)
+            h, w, _ = img.shape
+            p = draw_params(op, w, h)
+            x = torch.from_numpy(np.ascontiguousarray(img)).cuda().unsqueeze(0)
+            out = apply_batch(op, x, [p])[0]
+            ImageLoader.save_array(out.cpu().numpy(), output_path)
+            return True
+        except Exception as e:
+            logger.error(f"Failed to process {image_path} - {e}")
+            return False
+
+    def flip(self, image_path, output_path):
+        return self._run("flip", image_path, output_path)
+
+    def rotate(self, image_path, output_path):
+        return self._run("rotate", image_path, output_path)
+
+    def skew(self, image_path, output_path):
+        return self._run("skew", image_path, output_path)
+
+    def shear(self, image_path, output_path):
+        return self._run("shear", image_path, output_path)
+
+    def crop(self, image_path, output_path):
+        return self._run("crop", image_path, output_path)
+
+    def distortion(self, image_path, output_path):
+        return self._run("distortion", image_path, output_path)

@@ -1,0 +1,233 @@
+"""HIP augmentation kernels (through the C ABI) vs the oracle and the golden vectors.
+
+Bit-exact for every uint8 / int32 result; the f32 pack is bit-exact vs numpy f32.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import leaf_like
+from oracle import cv_ops as CV
+from oracle import pil_ops as P
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, cuda):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def batch_inputs(n, h, w, seed):
+    rng = np.random.RandomState(seed)
+    imgs = [leaf_like(h, w, seed + i) if i % 2 else rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+            for i in range(n)]
+    return np.stack(imgs)
+
+
+SIZES = [(224, 224), (64, 48), (33, 17), (5, 7)]  # aligned fast path, ragged fallbacks, tiny
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_pack_bit_exact(cuda, h, w):
+    from leaffliction_amd import ops
+    x = batch_inputs(3, h, w, 1)
+    got = ops.pack_hwc_u8_to_nchw_f32(dev(x, cuda)).cpu().numpy()
+    assert np.array_equal(got, P.pack_nchw(x))
+    mean, den = [0.4, 0.5, 0.3], [0.2, 0.25, 0.22]
+    got = ops.pack_hwc_u8_to_nchw_f32(dev(x, cuda), mean, den).cpu().numpy()
+    assert np.array_equal(got, P.pack_nchw(x, mean, den))
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_hist_lut_autocontrast_bit_exact(cuda, h, w):
+    import torch
+    from leaffliction_amd import ops
+    x = batch_inputs(5, h, w, 2)
+    x[4] = 91  # flat image: hi <= lo -> identity LUT
+    xd = dev(x, cuda)
+    hist = ops.hist_u8(xd).cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(hist[i], P.histogram(x[i]))
+    cut = np.array([0.0, 0.37, 1.99, 1.0, 0.5])
+    lut = ops.autocontrast_lut(ops.hist_u8(xd), dev(cut, cuda)).cpu().numpy()
+    out = ops.autocontrast_u8(xd, dev(cut, cuda)).cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(lut[i], P.autocontrast_lut(P.histogram(x[i]), float(cut[i])))
+        assert np.array_equal(out[i], P.autocontrast(x[i], float(cut[i])))
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_flip_noise_mask_bit_exact(cuda, h, w):
+    from leaffliction_amd import ops
+    x = batch_inputs(4, h, w, 3)
+    xd = dev(x, cuda)
+    mode = np.array([0, 1, 1, 0], np.int32)
+    got = ops.flip_u8(xd, dev(mode, cuda)).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(got[i], P.flip(x[i], int(mode[i])))
+    noise = np.random.RandomState(9).normal(0, 5, x.shape)
+    noise[0, 0, 0] = [-256.2, 300.7, -3.7]
+    assert np.array_equal(ops.noise_wrap_add_u8(xd, dev(noise, cuda)).cpu().numpy(),
+                          P.noise_wrap_add(x, noise))
+    mask = np.random.RandomState(4).randint(0, 256, (4, h, w)).astype(np.uint8)
+    mask[0] = 127
+    mask[1] = 128
+    for color in ("white", "black"):
+        got = ops.mask_composite_u8(xd, dev(mask, cuda), color).cpu().numpy()
+        for i in range(4):
+            assert np.array_equal(got[i], CV.apply_mask(x[i], mask[i], color))
+    with pytest.raises(ValueError):
+        ops.mask_composite_u8(xd, dev(mask, cuda), "red")
+
+
+def test_apply_mask_docstring_example(cuda):
+    """srcs/utils/mask_utils.py:29-41."""
+    from leaffliction_amd import ops
+    img = np.random.randint(0, 255, (1, 100, 100, 3), dtype=np.uint8)
+    mask = np.random.randint(0, 2, (1, 100, 100), dtype=np.uint8) * 255
+    w = ops.mask_composite_u8(dev(img, cuda), dev(mask, cuda), "white").cpu().numpy()
+    b = ops.mask_composite_u8(dev(img, cuda), dev(mask, cuda), "black").cpu().numpy()
+    assert (w[0][mask[0] == 0] == 255).all() and (b[0][mask[0] == 0] == 0).all()
+    assert np.array_equal(w[0][mask[0] == 255], img[0][mask[0] == 255])
+
+
+def test_philox_noise_statistics(cuda):
+    """Device-drawn noise: integer noise must follow trunc(N(0,5)) statistically."""
+    from leaffliction_amd import ops
+    x = np.full((16, 224, 224, 3), 128, np.uint8)
+    got = ops.noise_philox_add_u8(dev(x, cuda), seed=42, sigma=5.0).cpu().numpy().astype(np.int64)
+    d = got - 128
+    assert abs(d.mean()) < 0.05
+    assert abs(d.std() - np.trunc(np.random.RandomState(0).normal(0, 5, 2_000_000)).std()) < 0.05
+    again = ops.noise_philox_add_u8(dev(x, cuda), seed=42, sigma=5.0).cpu().numpy()
+    assert np.array_equal(again, got.astype(np.uint8))  # counter-based: reproducible
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_colour_conversions_bit_exact(cuda, h, w):
+    from leaffliction_amd import ops
+    x = batch_inputs(3, h, w, 5)
+    xd = dev(x, cuda)
+    assert np.array_equal(ops.rgb2hsv_u8(xd).cpu().numpy(), CV.rgb2hsv(x))
+    assert np.array_equal(ops.rgb2gray_u8(xd).cpu().numpy(), CV.rgb2gray(x))
+    counts, hh = ops.hsv_region_stats(xd)
+    counts, hh = counts.cpu().numpy(), hh.cpu().numpy()
+    for i in range(3):
+        c, hist = CV.hsv_region_stats(x[i])
+        assert np.array_equal(counts[i], c)
+        assert np.array_equal(hh[i], hist)
+
+
+def test_hsv_all_colours(cuda):
+    """Every 8-bit RGB triple on a 32-step lattice plus the cube corners and greys."""
+    from leaffliction_amd import ops
+    v = np.arange(0, 256, 5, dtype=np.uint8)
+    grid = np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(1, -1, 1, 3)
+    grid = np.ascontiguousarray(np.concatenate([grid, grid[:, :4 - grid.shape[1] % 4]], 1))
+    assert np.array_equal(ops.rgb2hsv_u8(dev(grid, cuda)).cpu().numpy(), CV.rgb2hsv(grid))
+
+
+@pytest.mark.parametrize("h,w", [(224, 224), (64, 48), (33, 17)])
+@pytest.mark.parametrize("ksize,sigma", [(15, 0.0), (5, 1.5), (3, 0.0)])
+def test_gauss_blur_bit_exact(cuda, h, w, ksize, sigma):
+    from leaffliction_amd import ops
+    x = batch_inputs(2, h, w, 6)
+    got = ops.gauss_blur_u8(dev(x, cuda), ksize, sigma).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], CV.gaussian_blur(x[i], ksize, sigma))
+    g = np.ascontiguousarray(x[..., 1])
+    got = ops.gauss_blur_u8(dev(g, cuda), ksize, sigma).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], CV.gaussian_blur(g[i], ksize, sigma))
+
+
+def test_golden_augmenter_cases(cuda, golden):
+    """Every reference ImageAugmenter output (42 cases) reproduced bit-exactly on the GPU."""
+    import torch
+    from leaffliction_amd.preprocessing import image_augmenter as IA
+    arrays, meta = golden
+    for c in meta["cases"]:
+        img = arrays[c["input"]]
+        h, w, _ = img.shape
+        random.seed(c["seed"])
+        np.random.seed(c["seed"])
+        p = IA.draw_params(c["op"], w, h)
+        out = IA.apply_batch(c["op"], dev(img[None], cuda), [p])[0].cpu().numpy()
+        exp = arrays[c["output"]]
+        assert out.shape == exp.shape, c
+        assert np.array_equal(out, exp), c
+
+
+def test_golden_loader_resize(cuda, golden):
+    from leaffliction_amd import ops
+    arrays, _ = golden
+    for si in range(3):
+        img = arrays[f"in_{si}"]
+        for S in (32, 64, 224):
+            got = ops.resize_lanczos_u8(dev(img[None], cuda), S)[0].cpu().numpy()
+            assert np.array_equal(got, arrays[f"resize_{si}_{S}"]), (si, S)
+
+
+def test_geometric_batch_vs_oracle(cuda):
+    """Batched, per-image parameters; also size-independent properties at 224x224."""
+    import torch
+    from leaffliction_amd import ops
+    from leaffliction_amd.preprocessing import image_augmenter as IA
+    x = batch_inputs(6, 224, 224, 11)
+    xd = dev(x, cuda)
+    random.seed(5)
+    np.random.seed(5)
+    for op in ("rotate", "skew", "shear", "crop"):
+        ps = [IA.draw_params(op, 224, 224) for _ in range(6)]
+        outs = IA.apply_batch(op, xd, ps)
+        for i in range(6):
+            if op == "rotate":
+                exp = P.rotate_expand_white(x[i], ps[i]["angle"])
+            elif op == "crop":
+                exp = P.crop_resize_lanczos(x[i], *ps[i]["box"])
+            else:
+                exp = P.warp_bicubic(x[i], ps[i]["coeffs"], op == "skew")
+            assert np.array_equal(outs[i].cpu().numpy(), exp), (op, i)
+    # flip is an involution; identity warp reproduces the input
+    mode = torch.zeros(6, dtype=torch.int32, device=cuda)
+    assert torch.equal(ops.flip_u8(ops.flip_u8(xd, mode), mode), xd)
+    ident = torch.tensor([[1, 0, 0, 0, 1, 0, 0, 0]] * 6, dtype=torch.float64, device=cuda)
+    assert torch.equal(ops.warp_bicubic_u8(xd, ident, False), xd)
+    # histogram totals: every bin count sums to H*W per channel
+    assert (ops.hist_u8(xd).sum(-1) == 224 * 224).all()
+
+
+def test_image_augmenter_file_interface(cuda, tmp_path):
+    """ImageAugmenter(seed).<op>(src, dst) -> bool; failures return False, never raise."""
+    from PIL import Image
+    from leaffliction_amd.preprocessing.image_augmenter import ImageAugmenter, TRANSFORMATIONS
+    src = tmp_path / "leaf.jpg"
+    Image.fromarray(leaf_like(96, 96, 3)).save(src, quality=95)
+    for op in TRANSFORMATIONS:
+        assert getattr(ImageAugmenter(seed=42), op)(str(src), str(tmp_path / f"{op}.jpg")) is True
+        assert (tmp_path / f"{op}.jpg").exists()
+    assert ImageAugmenter(seed=1).flip(str(tmp_path / "missing.jpg"), str(tmp_path / "o.jpg")) is False
+    png = tmp_path / "x.png"
+    Image.fromarray(leaf_like(8, 8, 1)).save(png)
+    assert ImageAugmenter(seed=1).rotate(str(png), str(tmp_path / "o.jpg")) is False  # .jpg only
+
+
+def test_full_size_batch_properties(cuda):
+    """BASELINE-size batch (256 x 224x224): properties that need no oracle pass."""
+    import torch
+    from leaffliction_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(42)
+    x = torch.randint(0, 256, (256, 224, 224, 3), dtype=torch.uint8, generator=g).to(cuda)
+    hist = ops.hist_u8(x)
+    assert (hist.sum(-1) == 224 * 224).all()
+    ref = torch.stack([torch.bincount(x[7, ..., c].flatten().long(), minlength=256)
+                       for c in range(3)])
+    assert torch.equal(hist[7].long(), ref)
+    packed = ops.pack_hwc_u8_to_nchw_f32(x)
+    assert torch.equal((packed * 255).round().to(torch.uint8), x.permute(0, 3, 1, 2))
+    ident = torch.arange(256, dtype=torch.uint8, device=cuda).repeat(256, 3, 1)
+    assert torch.equal(ops.lut_apply_u8(x, ident), x)
+    m1 = torch.ones(256, dtype=torch.int32, device=cuda)
+    assert torch.equal(ops.flip_u8(ops.flip_u8(x, m1), m1), x)
