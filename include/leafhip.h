@@ -151,6 +151,39 @@ int lf_resample_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int n, int h, 
                    const int32_t* ybounds, const int32_t* yk, int ky, int per_image_coeffs,
                    lf_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* A2 — leaf_cnn conv stack (fp32, NCHW activations)                           */
+/* ------------------------------------------------------------------------- */
+/* Conv weights are kept in "IKO" layout [Cin][k*k][Cout] (tap = ky*k + kx); the keras
+ * HWIO kernel [k][k][Cin][Cout] maps to it by a transpose at the artifact boundary. */
+
+/* keras Conv2D(cout, ksize, padding="same", use_bias=False) forward
+ * (srcs/model/cnn.py:27-29,44): y[n][co] = sum_{ci,tap} w[ci][tap][co] * x[n][ci] (cross-
+ * correlation, zero padding).  Optional fused input prologue (both pointers non-null):
+ * x' = x*in_scale[ci] + in_shift[ci], then relu if in_relu — the producer's
+ * BatchNorm(+ReLU) applied while staging (cnn.py:30-31); padding stays exactly zero.
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32: result equals an fp32 fmaf chain over
+ * k = (ci, tap) in ascending order.  Tolerance vs fp32 torch conv2d: 1e-4 relative.
+ * dgrad is the same call on dy with lf_conv2d_dgrad_weights_f32's output. */
+int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
+                  int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                  lf_stream_t stream);
+
+/* w [Cin][k*k][Cout] -> wt [Cout][k*k (flipped)][Cin]: the weights with which
+ * lf_conv2d_f32(dy, wt, dx, n, cout, h, w, cin, k, ...) is the input gradient. */
+int lf_conv2d_dgrad_weights_f32(const float* w, float* wt, int cin, int ksize, int cout,
+                                lf_stream_t stream);
+
+/* Weight gradient dw[ci][tap][co] = sum_{n,y,x} x'[n][ci][y+ky-1][x+kx-1] * dy[n][co][y][x]
+ * (x' = optional prologue as above); dw = beta*dw + grad.  Needs a workspace of
+ * lf_conv2d_wgrad_workspace(...) bytes for the per-workgroup partial slabs, which are
+ * summed in a fixed order (deterministic). */
+size_t lf_conv2d_wgrad_workspace(int n, int cin, int h, int wd, int cout, int ksize);
+int lf_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int n, int cin, int h, int wd,
+                        int cout, int ksize, const float* in_scale, const float* in_shift,
+                        int in_relu, float beta, void* workspace, size_t ws_bytes,
+                        lf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

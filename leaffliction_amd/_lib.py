@@ -39,8 +39,13 @@ SIGNATURES = {
     "lf_affine_nearest_fixed_u8": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "lf_resample_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int,
                        c_int, P],
+    "lf_conv2d_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P],
+    "lf_conv2d_dgrad_weights_f32": [P, P, c_int, c_int, c_int, P],
+    "lf_conv2d_wgrad_workspace": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "lf_conv2d_wgrad_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int,
+                            c_float, P, c_size_t, P],
 }
-_RESTYPES = {"lf_last_error": C.c_char_p}
+_RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t}
 
 
 class LeafHipError(RuntimeError):

@@ -1,0 +1,95 @@
+"""conv2d forward / dgrad / wgrad (fp32 MFMA) vs torch CPU fp32 conv2d (the float oracle).
+
+Tolerance: the kernel is an fp32 fmaf chain over K = Cin*9 (<= 2304) terms; torch's CPU
+conv uses a different summation order, so compare at rtol 2e-4 of the output scale.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def iko_to_oihw(w_iko, k):
+    cin, taps, cout = w_iko.shape
+    return w_iko.permute(2, 0, 1).reshape(cout, cin, k, k).contiguous()
+
+
+def close(got, ref, tol=2e-4):
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+SHAPES = [  # n, cin, cout, h, w, k
+    (2, 3, 32, 64, 64, 3),     # stem-like (Cin=3)
+    (2, 32, 32, 64, 64, 3),
+    (2, 32, 64, 32, 32, 3),
+    (2, 64, 128, 56, 56, 3),   # 28x8 tiles
+    (1, 128, 256, 28, 28, 3),  # masked 28-wide tiles, two cout tiles
+    (2, 16, 16, 20, 12, 3),    # ragged: Cout < 32, partial tiles
+    (2, 5, 7, 9, 11, 3),       # everything ragged
+    (2, 32, 64, 32, 32, 1),    # 1x1 projection
+    (1, 128, 256, 28, 28, 1),
+    (3, 8, 40, 17, 5, 1),
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k", SHAPES)
+def test_conv_forward_dgrad_wgrad(cuda, n, cin, cout, h, w, k):
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(n * 1000 + cin * 10 + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, k * k, cout, generator=g) / (cin * k * k) ** 0.5
+    dy = torch.randn(n, cout, h, w, generator=g)
+    w_oihw = iko_to_oihw(wt, k)
+    xr = x.clone().requires_grad_(True)
+    wr = w_oihw.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, padding=k // 2)
+    y_ref.backward(dy)
+    xd, wd, dyd = x.to(cuda), wt.to(cuda), dy.to(cuda)
+    close(nn.conv2d(xd, wd, k).cpu(), y_ref.detach())
+    dx = nn.conv2d(dyd, nn.conv2d_dgrad_weights(wd, k), k).cpu()
+    close(dx, xr.grad)
+    dw = nn.conv2d_wgrad(xd, dyd, k).cpu()
+    dw_ref = wr.grad.reshape(cout, cin, k * k).permute(1, 2, 0)
+    close(dw, dw_ref, tol=5e-4)
+
+
+def test_conv_fused_prologue(cuda):
+    """Prologue = producer's BatchNorm+ReLU applied while staging; padding stays zero."""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 24, 40, generator=g)
+    wt = torch.randn(32, 9, 64, generator=g) / 17.0
+    sc = torch.rand(32, generator=g) + 0.5
+    sh = torch.randn(32, generator=g) * 0.3
+    dy = torch.randn(2, 64, 24, 40, generator=g)
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ar = a.clone().requires_grad_(True)
+    wr = iko_to_oihw(wt, 3).clone().requires_grad_(True)
+    y_ref = F.conv2d(ar, wr, padding=1)
+    y_ref.backward(dy)
+    xd, wd, scd, shd, dyd = (t.to(cuda) for t in (x, wt, sc, sh, dy))
+    close(nn.conv2d(xd, wd, 3, scd, shd, True).cpu(), y_ref.detach())
+    dw = nn.conv2d_wgrad(xd, dyd, 3, scd, shd, True).cpu()
+    close(dw, wr.grad.reshape(64, 32, 9).permute(1, 2, 0), tol=5e-4)
+
+
+def test_conv_known_answers(cuda):
+    """Delta kernel reproduces the input; ones kernel counts the valid neighbours (zero pad)."""
+    from leaffliction_amd import nn
+    x = torch.arange(2 * 4 * 6 * 6, dtype=torch.float32).reshape(2, 4, 6, 6).to(cuda)
+    w = torch.zeros(4, 9, 4, device=cuda)
+    for c in range(4):
+        w[c, 4, c] = 1.0  # centre tap, identity over channels
+    assert torch.equal(nn.conv2d(x, w, 3), x)
+    ones = torch.ones(1, 1, 5, 5, device=cuda)
+    cnt = nn.conv2d(ones, torch.ones(1, 9, 1, device=cuda), 3)[0, 0].cpu()
+    assert cnt[0, 0] == 4 and cnt[0, 2] == 6 and cnt[2, 2] == 9
+    # determinism: the slab reduce has a fixed order
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(4, 32, 32, 32, generator=g).to(cuda)
+    d = torch.randn(4, 32, 32, 32, generator=g).to(cuda)
+    assert torch.equal(nn.conv2d_wgrad(a, d, 3), nn.conv2d_wgrad(a, d, 3))
