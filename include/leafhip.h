@@ -164,10 +164,11 @@ int lf_resample_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int n, int h, 
  * BatchNorm(+ReLU) applied while staging (cnn.py:30-31); padding stays exactly zero.
  * Implicit GEMM on v_mfma_f32_32x32x2_f32: result equals an fp32 fmaf chain over
  * k = (ci, tap) in ascending order.  Tolerance vs fp32 torch conv2d: 1e-4 relative.
- * dgrad is the same call on dy with lf_conv2d_dgrad_weights_f32's output. */
+ * dgrad is the same call on dy with lf_conv2d_dgrad_weights_f32's output; accumulate != 0
+ * adds into y (residual gradient joins) instead of overwriting it. */
 int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
                   int ksize, const float* in_scale, const float* in_shift, int in_relu,
-                  lf_stream_t stream);
+                  int accumulate, lf_stream_t stream);
 
 /* w [Cin][k*k][Cout] -> wt [Cout][k*k (flipped)][Cin]: the weights with which
  * lf_conv2d_f32(dy, wt, dx, n, cout, h, w, cin, k, ...) is the input gradient. */
@@ -183,6 +184,91 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int n, int c
                         int cout, int ksize, const float* in_scale, const float* in_shift,
                         int in_relu, float beta, void* workspace, size_t ws_bytes,
                         lf_stream_t stream);
+
+/* ---- input stage ----------------------------------------------------------- */
+/* u8 HWC -> f32 NCHW with the model's train-time augmentation fused (cnn.py:74-86):
+ * keras RandomFlip("horizontal") -> RandomRotation (bilinear, fill_mode="reflect") ->
+ * RandomContrast on the [0,1] image, then Normalization (x-mean)/denom.  aug4[n] =
+ * {flip 0/1, cos, sin, contrast factor} (device, drawn by the host RNG); mean3/denom3 are
+ * HOST pointers (or both null); means_ws is a device scratch of n*3 floats.
+ * Stochastic layers: statistical parity with keras, exact parity with oracle/cnn_ref.py. */
+int lf_input_stage_f32(const uint8_t* in, float* out, int n, int h, int w, const float* aug4,
+                       const float* mean3, const float* denom3, float* means_ws,
+                       lf_stream_t stream);
+
+/* ---- BatchNorm (keras BatchNormalization: momentum 0.99, eps 1e-3; cnn.py:30,45) ---- */
+/* out = act(x*scale[c] + shift[c]) over [n][c][hw] (BN apply, optional ReLU). */
+int lf_scale_shift_act_f32(const float* x, float* out, int n, int c, int hw, const float* scale,
+                           const float* shift, int relu, lf_stream_t stream);
+size_t lf_bn_workspace(int c);
+/* Training statistics of y [n][c][hw]: batch mean / biased variance per channel; writes
+ * mean, invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale, and
+ * updates moving_mean/var <- moving*momentum + batch*(1-momentum). */
+int lf_bn_train_stats_f32(const float* y, int n, int c, int hw, const float* gamma,
+                          const float* beta, float* moving_mean, float* moving_var, float momentum,
+                          float eps, float* mean, float* invstd, float* scale, float* shift,
+                          void* workspace, size_t ws_bytes, lf_stream_t stream);
+/* Inference scale/shift from the moving statistics. */
+int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
+                                const float* moving_mean, const float* moving_var, float eps,
+                                float* scale, float* shift, lf_stream_t stream);
+/* BatchNorm backward with the upstream chain folded in: dz = (g*alpha_nc[n][c] + add_nc[n][c])
+ * where mask > 0 (alpha/add/mask optional), dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat));
+ * dgamma = sum dz*xhat, dbeta = sum dz. */
+int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* mask,
+                  const float* y, const float* mean, const float* invstd, const float* gamma,
+                  float* dy, float* dgamma, float* dbeta, int n, int c, int hw, void* workspace,
+                  size_t ws_bytes, lf_stream_t stream);
+
+/* ---- pooling / broadcast ---- */
+/* out[p] = mean over hw of x[p][:] (GlobalAveragePooling2D, cnn.py:13,98). */
+int lf_gap_f32(const float* x, float* out, int planes, int hw, lf_stream_t stream);
+/* out[p][:] = v[p]*scale (GAP backward). */
+int lf_bcast_planes_f32(const float* v, float* out, int planes, int hw, float scale,
+                        lf_stream_t stream);
+
+/* ---- Squeeze-Excite (cnn.py:9-17): s = sigmoid(relu(m w1 + b1) w2 + b2) ---- */
+/* m [n][c], w1 [c][cr], w2 [cr][c]; z1 = hidden activations (saved for backward). */
+int lf_se_fwd_f32(const float* m, const float* w1, const float* b1, const float* w2,
+                  const float* b2, float* z1, float* s, int n, int c, int cr, lf_stream_t stream);
+size_t lf_se_bwd_workspace(int n, int c, int cr);
+int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float* s,
+                  const float* w1, const float* w2, float* dm, float* dw1, float* db1, float* dw2,
+                  float* db2, int n, int c, int cr, void* workspace, size_t ws_bytes,
+                  lf_stream_t stream);
+
+/* ---- residual tail (cnn.py:47-48,94-96): Add -> ReLU -> SpatialDropout2D -> MaxPool2D(2) ---- */
+/* r = relu(sc' + a*s[n][c]), sc' = sc*sc_scale[c]+sc_shift[c] (projection BN) or sc;
+ * p = drop[n][c] * maxpool2x2(r) (drop = 0 or 1/(1-rate), null = 1). */
+int lf_block_tail_fwd_f32(const float* a, const float* s, const float* sc, const float* sc_scale,
+                          const float* sc_shift, const float* drop, float* r, float* p, int n,
+                          int c, int h, int w, lf_stream_t stream);
+/* dr = gradient wrt (sc' + a*s) : dp*drop routed to the first maximum of each window where
+ * r > 0; ds[n][c] = sum_hw dr*a (SE gate gradient; a/ds optional together). */
+int lf_block_tail_bwd_f32(const float* dp, const float* r, const float* a, const float* drop,
+                          float* dr, float* ds, int n, int c, int h, int w, lf_stream_t stream);
+
+/* ---- head (cnn.py:98-101; train/utils.py:30-35) ---- */
+/* probs = softmax(feat w + b), w [f][c]; loss[n] = -sum_j ytrue[n][j] log(clip(probs)). */
+int lf_head_fwd_f32(const float* feat, const float* w, const float* b, const float* ytrue,
+                    float* probs, float* loss, int n, int f, int c, lf_stream_t stream);
+int lf_head_bwd_f32(const float* feat, const float* w, const float* probs, const float* ytrue,
+                    float* dlogits, float* dfeat, float* dw, float* db, int n, int f, int c,
+                    float inv_n, lf_stream_t stream);
+int lf_mul_f32(const float* a, const float* b, float* out, size_t count, lf_stream_t stream);
+
+/* ---- optimizer (train/utils.py:17-27 AdamW + clipnorm; :44-57 EMA) ---- */
+/* Flat buffers; tensor t occupies [offsets[t], offsets[t+1]).  Per tensor: g' = g + 2*l2[t]*w
+ * (kernel_regularizer gradient), clip_by_norm(g', clipnorm) per tensor (0 = off), decoupled
+ * decay w -= lr*wd*w, Adam with bias correction at `step` (1-based), then
+ * ema = copy ? w : decay*ema + (1-decay)*w (ema may be null).  norms_ws: ntensors floats. */
+int lf_adamw_step_f32(float* param, const float* grad, float* m, float* v, float* ema,
+                      const long long* offsets, const float* l2, int ntensors, long long max_count,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      float clipnorm, long long step, float ema_decay, int ema_copy,
+                      float* norms_ws, lf_stream_t stream);
+int lf_ema_update_f32(float* ema, const float* w, size_t count, float decay, int copy,
+                      lf_stream_t stream);
 
 #ifdef __cplusplus
 }

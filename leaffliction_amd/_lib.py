@@ -39,13 +39,34 @@ SIGNATURES = {
     "lf_affine_nearest_fixed_u8": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "lf_resample_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int,
                        c_int, P],
-    "lf_conv2d_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P],
+    "lf_conv2d_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P],
     "lf_conv2d_dgrad_weights_f32": [P, P, c_int, c_int, c_int, P],
     "lf_conv2d_wgrad_workspace": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_wgrad_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int,
                             c_float, P, c_size_t, P],
+    "lf_input_stage_f32": [P, P, c_int, c_int, c_int, P, P, P, P, P],
+    "lf_scale_shift_act_f32": [P, P, c_int, c_int, c_int, P, P, c_int, P],
+    "lf_bn_workspace": [c_int],
+    "lf_bn_train_stats_f32": [P, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P,
+                              P, c_size_t, P],
+    "lf_bn_infer_scale_shift_f32": [c_int, P, P, P, P, c_float, P, P, P],
+    "lf_bn_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_size_t, P],
+    "lf_gap_f32": [P, P, c_int, c_int, P],
+    "lf_bcast_planes_f32": [P, P, c_int, c_int, c_float, P],
+    "lf_se_fwd_f32": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "lf_se_bwd_workspace": [c_int, c_int, c_int],
+    "lf_se_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_size_t, P],
+    "lf_block_tail_fwd_f32": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "lf_block_tail_bwd_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "lf_head_fwd_f32": [P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "lf_head_bwd_f32": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
+    "lf_mul_f32": [P, P, P, c_size_t, P],
+    "lf_adamw_step_f32": [P, P, P, P, P, P, P, c_int, C.c_longlong, c_float, c_float, c_float,
+                          c_float, c_float, c_float, C.c_longlong, c_float, c_int, P, P],
+    "lf_ema_update_f32": [P, P, c_size_t, c_float, c_int, P],
 }
-_RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t}
+_RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t,
+             "lf_bn_workspace": c_size_t, "lf_se_bwd_workspace": c_size_t}
 
 
 class LeafHipError(RuntimeError):

@@ -38,6 +38,7 @@ struct ConvArgs {
     int n, cin, cout, h, wd;
     int tiles_x, tiles_y;
     int in_relu;
+    int accumulate;  // y += conv(...) instead of y = conv(...)
 };
 
 // ---------------------------------------------------------------------------
@@ -182,7 +183,10 @@ __global__ __launch_bounds__(kThreads, (MB * NB * 16 <= 32 ? 4 : (MB * NB * 16 <
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cb + (r & 3) + 8 * (r >> 2);
-                if (co < p.cout) yout[(size_t)co * hw + pix] = acc[m][nb][r];
+                if (co < p.cout) {
+                    float* dst = yout + (size_t)co * hw + pix;
+                    *dst = p.accumulate ? *dst + acc[m][nb][r] : acc[m][nb][r];
+                }
             }
         }
     }
@@ -432,7 +436,7 @@ extern "C" {
 
 int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
                   int ksize, const float* in_scale, const float* in_shift, int in_relu,
-                  lf_stream_t stream) {
+                  int accumulate, lf_stream_t stream) {
     LF_REQUIRE(x && w && y, "lf_conv2d: null buffer");
     LF_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && wd > 0,
                "lf_conv2d: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, wd);
@@ -456,6 +460,7 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
     a.tiles_x = (wd + v.tw - 1) / v.tw;
     a.tiles_y = (h + v.th - 1) / v.th;
     a.in_relu = in_relu;
+    a.accumulate = accumulate;
     dim3 grid(a.tiles_x * a.tiles_y, (cout + v.ct - 1) / v.ct, n);
     hipStream_t s = lf::as_stream(stream);
     const int rc = ksize == 3 ? launch_fwd<9>(best, a, grid, s) : launch_fwd<1>(best, a, grid, s);

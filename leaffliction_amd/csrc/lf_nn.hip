@@ -1,1 +1,878 @@
+// libleafhip — leaf_cnn non-conv kernels (fp32, NCHW): input stage (pack + in-model
+// augmentation + Normalization), BatchNorm (train statistics / backward), Squeeze-Excite,
+// residual tail (add + ReLU + SpatialDropout + MaxPool) forward/backward, GAP + Dense +
+// softmax cross-entropy head, AdamW with per-tensor clipnorm + EMA.
+//
+// All of these are HBM-bound streaming / reduction kernels: float4 accesses, one
+// (n, c) plane per workgroup row so per-channel / per-sample parameters are uniform, and
+// every cross-workgroup reduction goes through partial sums that are combined in a fixed
+// order (deterministic; no float atomics).  Reference semantics: srcs/model/cnn.py:9-104,
+// srcs/train/utils.py:17-57 (Keras 3 layer / optimizer definitions).
 #include "lf_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kBnSplit = 64;  // partial sums per channel in the BN reductions
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide sum of up to 3 values; result valid in thread 0
+template <int K>
+__device__ __forceinline__ void block_sum(float (&v)[K], float* red /* [K][4] */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = wave_sum(v[k]);
+        if (lane == 0) red[k * 4 + wid] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = red[k * 4] + red[k * 4 + 1] + red[k * 4 + 2] + red[k * 4 + 3];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// input stage: u8 HWC -> [flip, rotate(bilinear, reflect), contrast] -> normalise -> f32 NCHW
+// ---------------------------------------------------------------------------
+// aug[n] = {flip, cos, sin, contrast}.  Sampling follows keras RandomFlip("horizontal") ->
+// RandomRotation (affine about the image centre, bilinear, fill_mode="reflect") ->
+// RandomContrast ((x - mean_hw) * f + mean_hw, clipped to [0, 255]) on the [0,1] image.
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    // fill_mode="reflect": (d c b a | a b c d | d c b a)
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+__device__ __forceinline__ void sample_aug(const uint8_t* __restrict__ src, int h, int w, int oy,
+                                           int ox, float flip, float cs, float sn, float* rgb) {
+    // output -> input coordinates (keras RandomRotation's projective matrix)
+    const float wm = (float)(w - 1), hm = (float)(h - 1);
+    const float xoff = (wm - (cs * wm - sn * hm)) * 0.5f;
+    const float yoff = (hm - (sn * wm + cs * hm)) * 0.5f;
+    const float fx = cs * ox - sn * oy + xoff;
+    const float fy = sn * ox + cs * oy + yoff;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float ax = fx - x0f, ay = fy - y0f;
+    int xs[2] = {reflect_idx((int)x0f, w), reflect_idx((int)x0f + 1, w)};
+    const int ys[2] = {reflect_idx((int)y0f, h), reflect_idx((int)y0f + 1, h)};
+    if (flip != 0.f) {  // the flip precedes the rotation: sample the mirrored source
+        xs[0] = w - 1 - xs[0];
+        xs[1] = w - 1 - xs[1];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v00 = src[((size_t)ys[0] * w + xs[0]) * 3 + c];
+        const float v01 = src[((size_t)ys[0] * w + xs[1]) * 3 + c];
+        const float v10 = src[((size_t)ys[1] * w + xs[0]) * 3 + c];
+        const float v11 = src[((size_t)ys[1] * w + xs[1]) * 3 + c];
+        const float top = v00 + (v01 - v00) * ax, bot = v10 + (v11 - v10) * ax;
+        rgb[c] = (top + (bot - top) * ay) * (1.0f / 255.0f);
+    }
+}
+
+// per-image channel means of the flipped+rotated image (RandomContrast's mean); grid = n
+__global__ __launch_bounds__(kBlock) void aug_means_kernel(const uint8_t* __restrict__ in,
+                                                           const float* __restrict__ aug,
+                                                           float* __restrict__ means, int h, int w) {
+    __shared__ float red[12];
+    const int n = blockIdx.x;
+    const uint8_t* src = in + (size_t)n * h * w * 3;
+    const float flip = aug[4 * n], cs = aug[4 * n + 1], sn = aug[4 * n + 2];
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int p = threadIdx.x; p < h * w; p += kBlock) {
+        float rgb[3];
+        sample_aug(src, h, w, p / w, p % w, flip, cs, sn, rgb);
+        acc[0] += rgb[0];
+        acc[1] += rgb[1];
+        acc[2] += rgb[2];
+    }
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        const float inv = 1.0f / (float)(h * w);
+        means[3 * n] = acc[0] * inv;
+        means[3 * n + 1] = acc[1] * inv;
+        means[3 * n + 2] = acc[2] * inv;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void input_aug_kernel(const uint8_t* __restrict__ in,
+                                                           float* __restrict__ out,
+                                                           const float* __restrict__ aug,
+                                                           const float* __restrict__ means, int h,
+                                                           int w, float m0, float m1, float m2,
+                                                           float d0, float d1, float d2) {
+    const int n = blockIdx.y;
+    const size_t hw = (size_t)h * w;
+    const uint8_t* src = in + (size_t)n * hw * 3;
+    float* dst = out + (size_t)n * hw * 3;
+    const float flip = aug[4 * n], cs = aug[4 * n + 1], sn = aug[4 * n + 2], ct = aug[4 * n + 3];
+    const float mu[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+    const float nm[3] = {m0, m1, m2}, nd[3] = {d0, d1, d2};
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < (int)hw; p += gridDim.x * kBlock) {
+        float rgb[3];
+        sample_aug(src, h, w, p / w, p % w, flip, cs, sn, rgb);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = (rgb[c] - mu[c]) * ct + mu[c];
+            v = fminf(fmaxf(v, 0.f), 255.f);
+            dst[(size_t)c * hw + p] = (v - nm[c]) / nd[c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plane-wise elementwise: out = act(x * scale[c] + shift[c])
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void scale_shift_act_kernel(const float* __restrict__ x,
+                                                                 float* __restrict__ out, int c,
+                                                                 int hwv,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 int relu) {
+    const int plane = blockIdx.x;
+    const float sc = scale[plane % c], sh = shift[plane % c];
+    const size_t base = (size_t)plane * hwv * VEC;
+    for (int i = blockIdx.y * kBlock + threadIdx.x; i < hwv; i += gridDim.y * kBlock) {
+        if (VEC == 4) {
+            float4 v = reinterpret_cast<const float4*>(x + base)[i];
+            v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            reinterpret_cast<float4*>(out + base)[i] = v;
+        } else {
+            float v = fmaf(x[base + i], sc, sh);
+            out[base + i] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm statistics (training): per-channel sum / sum of squares over N*H*W
+// ---------------------------------------------------------------------------
+// grid = (kBnSplit, C): workgroup (s, c) reduces the planes n = s, s+kBnSplit, ... of channel c
+// around a per-channel pivot (the first element) to keep sum-of-squares well conditioned.
+__global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restrict__ y, int n, int c,
+                                                          int hw, float* __restrict__ part) {
+    __shared__ float red[8];
+    const int ch = blockIdx.y, s = blockIdx.x;
+    const float pivot = y[(size_t)ch * hw];
+    float acc[2] = {0.f, 0.f};
+    for (int img = s; img < n; img += kBnSplit) {
+        const float* p = y + ((size_t)img * c + ch) * hw;
+        if ((hw & 3) == 0) {
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            for (int i = threadIdx.x; i < hw / 4; i += kBlock) {
+                const float4 v = p4[i];
+                const float a = v.x - pivot, b = v.y - pivot, cc = v.z - pivot, d = v.w - pivot;
+                acc[0] += (a + b) + (cc + d);
+                acc[1] += (a * a + b * b) + (cc * cc + d * d);
+            }
+        } else {
+            for (int i = threadIdx.x; i < hw; i += kBlock) {
+                const float a = p[i] - pivot;
+                acc[0] += a;
+                acc[1] += a * a;
+            }
+        }
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        part[((size_t)ch * kBnSplit + s) * 2] = acc[0];
+        part[((size_t)ch * kBnSplit + s) * 2 + 1] = acc[1];
+    }
+}
+
+// One thread per channel: combine partials in double, produce mean / invstd / scale / shift and
+// update the moving statistics (keras BatchNormalization: biased variance, momentum 0.99).
+__global__ void bn_finalize_kernel(const float* __restrict__ y, const float* __restrict__ part,
+                                   int c, int hw, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ mmean,
+                                   float* __restrict__ mvar, float momentum, float eps,
+                                   float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                   float* __restrict__ scale_o, float* __restrict__ shift_o) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < kBnSplit; ++k) {
+        s += part[((size_t)ch * kBnSplit + k) * 2];
+        q += part[((size_t)ch * kBnSplit + k) * 2 + 1];
+    }
+    const double pivot = y[(size_t)ch * hw];
+    const double dm = s / count;
+    double var = q / count - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)(pivot + dm);
+    const float fvar = (float)var;
+    const float invstd = 1.0f / sqrtf(fvar + eps);
+    mean_o[ch] = mean;
+    invstd_o[ch] = invstd;
+    const float sc = gamma[ch] * invstd;
+    scale_o[ch] = sc;
+    shift_o[ch] = beta[ch] - mean * sc;
+    mmean[ch] = mmean[ch] * momentum + mean * (1.0f - momentum);
+    mvar[ch] = mvar[ch] * momentum + fvar * (1.0f - momentum);
+}
+
+__global__ void bn_infer_kernel(int c, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ mmean,
+                                const float* __restrict__ mvar, float eps,
+                                float* __restrict__ scale_o, float* __restrict__ shift_o) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const float sc = gamma[ch] / sqrtf(mvar[ch] + eps);
+    scale_o[ch] = sc;
+    shift_o[ch] = beta[ch] - mmean[ch] * sc;
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm backward.  dz = (g * alpha[n,c] + beta[n,c]) masked by (mask > 0);
+// xhat = (y - mean) * invstd.  Reduce: sum dz, sum dz*xhat per channel; apply:
+// dy = gamma*invstd * (dz - sum_dz/M - xhat * sum_dzx/M).
+// ---------------------------------------------------------------------------
+struct BnBwdArgs {
+    const float* g;      // upstream gradient [N][C][HW]
+    const float* alpha;  // [N][C] or null (1)
+    const float* addnc;  // [N][C] or null (0)
+    const float* mask;   // [N][C][HW] or null: gradient passes where mask > 0
+    const float* y;      // pre-BN activations
+    const float* mean;
+    const float* invstd;
+    int n, c, hw;
+};
+
+__device__ __forceinline__ float bn_dz(const BnBwdArgs& a, size_t idx, float al, float ad) {
+    float dz = fmaf(a.g[idx], al, ad);
+    if (a.mask != nullptr && !(a.mask[idx] > 0.f)) dz = 0.f;
+    return dz;
+}
+
+__global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(BnBwdArgs a, float* __restrict__ part) {
+    __shared__ float red[8];
+    const int ch = blockIdx.y, s = blockIdx.x;
+    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    float acc[2] = {0.f, 0.f};
+    for (int img = s; img < a.n; img += kBnSplit) {
+        const size_t base = ((size_t)img * a.c + ch) * a.hw;
+        const float al = a.alpha ? a.alpha[img * a.c + ch] : 1.f;
+        const float ad = a.addnc ? a.addnc[img * a.c + ch] : 0.f;
+        for (int i = threadIdx.x; i < a.hw; i += kBlock) {
+            const float dz = bn_dz(a, base + i, al, ad);
+            acc[0] += dz;
+            acc[1] += dz * ((a.y[base + i] - mean) * invstd);
+        }
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        part[((size_t)ch * kBnSplit + s) * 2] = acc[0];
+        part[((size_t)ch * kBnSplit + s) * 2 + 1] = acc[1];
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int c,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < kBnSplit; ++k) {
+        s += part[((size_t)ch * kBnSplit + k) * 2];
+        q += part[((size_t)ch * kBnSplit + k) * 2 + 1];
+    }
+    dbeta[ch] = (float)s;
+    dgamma[ch] = (float)q;
+}
+
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(BnBwdArgs a,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ dgamma,
+                                                              const float* __restrict__ dbeta,
+                                                              float inv_count,
+                                                              float* __restrict__ dy) {
+    const int plane = blockIdx.x, ch = plane % a.c;
+    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    const float k = gamma[ch] * invstd;
+    const float mdz = dbeta[ch] * inv_count, mdzx = dgamma[ch] * inv_count;
+    const float al = a.alpha ? a.alpha[plane] : 1.f;
+    const float ad = a.addnc ? a.addnc[plane] : 0.f;
+    const size_t base = (size_t)plane * a.hw;
+    for (int i = blockIdx.y * kBlock + threadIdx.x; i < a.hw; i += gridDim.y * kBlock) {
+        const float dz = bn_dz(a, base + i, al, ad);
+        const float xh = (a.y[base + i] - mean) * invstd;
+        dy[base + i] = k * (dz - mdz - xh * mdzx);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// global average pool per plane, and its broadcast backward
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gap_kernel(const float* __restrict__ x,
+                                                     float* __restrict__ out, int hw) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * hw;
+    float acc[1] = {0.f};
+    for (int i = threadIdx.x; i < hw; i += kBlock) acc[0] += x[base + i];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc[0] / (float)hw;
+}
+
+__global__ __launch_bounds__(kBlock) void bcast_planes_kernel(const float* __restrict__ v,
+                                                              float* __restrict__ out, int hw,
+                                                              float scale) {
+    const float val = v[blockIdx.x] * scale;
+    const size_t base = (size_t)blockIdx.x * hw;
+    for (int i = blockIdx.y * kBlock + threadIdx.x; i < hw; i += gridDim.y * kBlock) out[base + i] = val;
+}
+
+// ---------------------------------------------------------------------------
+// Squeeze-Excite FC pair (1x1 convs with bias on [N,C,1,1]): one workgroup per sample
+// ---------------------------------------------------------------------------
+// w1 [C][Cr], b1 [Cr], w2 [Cr][C], b2 [C]  (keras kernel [1,1,in,out] flattened)
+__global__ __launch_bounds__(kBlock) void se_fwd_kernel(const float* __restrict__ m,
+                                                        const float* __restrict__ w1,
+                                                        const float* __restrict__ b1,
+                                                        const float* __restrict__ w2,
+                                                        const float* __restrict__ b2,
+                                                        float* __restrict__ z1,
+                                                        float* __restrict__ s, int c, int cr) {
+    extern __shared__ float sm[];  // [c] m, [cr] z
+    float* lm = sm;
+    float* lz = sm + c;
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < c; i += kBlock) lm[i] = m[(size_t)n * c + i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < cr; j += kBlock) {
+        float acc = b1[j];
+        for (int i = 0; i < c; ++i) acc = fmaf(lm[i], w1[(size_t)i * cr + j], acc);
+        acc = fmaxf(acc, 0.f);
+        lz[j] = acc;
+        z1[(size_t)n * cr + j] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += kBlock) {
+        float acc = b2[i];
+        for (int j = 0; j < cr; ++j) acc = fmaf(lz[j], w2[(size_t)j * c + i], acc);
+        s[(size_t)n * c + i] = 1.0f / (1.0f + __expf(-acc));
+    }
+}
+
+// per sample: dpre2 = ds*s*(1-s); dpre1 = (dpre2 . w2^T) * (z1>0); dm = dpre1 . w1^T
+__global__ __launch_bounds__(kBlock) void se_bwd_sample_kernel(
+    const float* __restrict__ ds, const float* __restrict__ s, const float* __restrict__ z1,
+    const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ dpre2,
+    float* __restrict__ dpre1, float* __restrict__ dm, int c, int cr) {
+    extern __shared__ float sm[];  // [c] dpre2, [cr] dpre1
+    float* l2 = sm;
+    float* l1 = sm + c;
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < c; i += kBlock) {
+        const float sv = s[(size_t)n * c + i];
+        const float v = ds[(size_t)n * c + i] * sv * (1.f - sv);
+        l2[i] = v;
+        dpre2[(size_t)n * c + i] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < cr; j += kBlock) {
+        float acc = 0.f;
+        for (int i = 0; i < c; ++i) acc = fmaf(l2[i], w2[(size_t)j * c + i], acc);
+        if (!(z1[(size_t)n * cr + j] > 0.f)) acc = 0.f;
+        l1[j] = acc;
+        dpre1[(size_t)n * cr + j] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += kBlock) {
+        float acc = 0.f;
+        for (int j = 0; j < cr; ++j) acc = fmaf(l1[j], w1[(size_t)i * cr + j], acc);
+        dm[(size_t)n * c + i] = acc;
+    }
+}
+
+// out[i][j] = sum_n a[n][i] * b[n][j]  (i < ra, j < rb); i == ra row holds sum_n b[n][j] (bias)
+__global__ __launch_bounds__(kBlock) void outer_sum_kernel(const float* __restrict__ a,
+                                                           const float* __restrict__ b,
+                                                           float* __restrict__ out,
+                                                           float* __restrict__ bias_out, int n,
+                                                           int ra, int rb) {
+    const int total = (ra + 1) * rb;
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
+        const int i = t / rb, j = t - i * rb;
+        float acc = 0.f;
+        if (i < ra) {
+            for (int k = 0; k < n; ++k) acc = fmaf(a[(size_t)k * ra + i], b[(size_t)k * rb + j], acc);
+            out[(size_t)i * rb + j] = acc;
+        } else {
+            for (int k = 0; k < n; ++k) acc += b[(size_t)k * rb + j];
+            bias_out[j] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// residual tail: r = relu(sc' + a*s[n,c]); p = drop[n,c] * maxpool2x2(r)
+// ---------------------------------------------------------------------------
+// sc' = sc*sc_scale[c] + sc_shift[c] when the shortcut is a projection (BN of the 1x1 conv).
+__global__ __launch_bounds__(kBlock) void tail_fwd_kernel(
+    const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ sc,
+    const float* __restrict__ sc_scale, const float* __restrict__ sc_shift,
+    const float* __restrict__ drop, float* __restrict__ r, float* __restrict__ p, int c, int h,
+    int w) {
+    const int plane = blockIdx.x, ch = plane % c;
+    const float sv = s ? s[plane] : 1.f;
+    const float ks = sc_scale ? sc_scale[ch] : 1.f, kb = sc_shift ? sc_shift[ch] : 0.f;
+    const float dv = drop ? drop[plane] : 1.f;
+    const int ph = h / 2, pw = w / 2;
+    const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
+    // one thread per pooled output (2x2 window); odd trailing row/col handled below
+    for (int t = blockIdx.y * kBlock + threadIdx.x; t < ph * pw; t += gridDim.y * kBlock) {
+        const int py = t / pw, px = t - py * pw;
+        float mx = 0.f;  // r >= 0
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const size_t o = base + (size_t)(2 * py + dy) * w + 2 * px;
+            const float2 av = *reinterpret_cast<const float2*>(a + o);
+            const float2 sv2 = *reinterpret_cast<const float2*>(sc + o);
+            float2 rv;
+            rv.x = fmaxf(fmaf(sv2.x, ks, kb) + av.x * sv, 0.f);
+            rv.y = fmaxf(fmaf(sv2.y, ks, kb) + av.y * sv, 0.f);
+            *reinterpret_cast<float2*>(r + o) = rv;
+            mx = fmaxf(mx, fmaxf(rv.x, rv.y));
+        }
+        p[pbase + t] = mx * dv;
+    }
+    // leftover row / column when h or w is odd (not pooled, but r must be complete)
+    if ((h & 1) || (w & 1)) {
+        for (int t = blockIdx.y * kBlock + threadIdx.x; t < h * w; t += gridDim.y * kBlock) {
+            const int y = t / w, x = t - y * w;
+            if (y >= 2 * ph || x >= 2 * pw)
+                r[base + t] = fmaxf(fmaf(sc[base + t], ks, kb) + a[base + t] * sv, 0.f);
+        }
+    }
+}
+
+// dr = dp*drop routed to the first max of each 2x2 window where r > 0; ds[n,c] = sum dr*a
+__global__ __launch_bounds__(kBlock) void tail_bwd_kernel(const float* __restrict__ dp,
+                                                          const float* __restrict__ r,
+                                                          const float* __restrict__ a,
+                                                          const float* __restrict__ drop,
+                                                          float* __restrict__ dr,
+                                                          float* __restrict__ ds, int h, int w) {
+    __shared__ float red[4];
+    const int plane = blockIdx.x;
+    const float dv = drop ? drop[plane] : 1.f;
+    const int ph = h / 2, pw = w / 2;
+    const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
+    float acc[1] = {0.f};
+    for (int t = threadIdx.x; t < ph * pw; t += kBlock) {
+        const int py = t / pw, px = t - py * pw;
+        const size_t o0 = base + (size_t)(2 * py) * w + 2 * px, o1 = o0 + w;
+        const float2 r0 = *reinterpret_cast<const float2*>(r + o0);
+        const float2 r1 = *reinterpret_cast<const float2*>(r + o1);
+        const float g = dp[pbase + t] * dv;
+        // argmax in window scan order (first maximum wins); relu'(r) = r > 0
+        float best = r0.x;
+        int bi = 0;
+        if (r0.y > best) { best = r0.y; bi = 1; }
+        if (r1.x > best) { best = r1.x; bi = 2; }
+        if (r1.y > best) { best = r1.y; bi = 3; }
+        const float gg = best > 0.f ? g : 0.f;
+        float2 d0 = make_float2(bi == 0 ? gg : 0.f, bi == 1 ? gg : 0.f);
+        float2 d1 = make_float2(bi == 2 ? gg : 0.f, bi == 3 ? gg : 0.f);
+        *reinterpret_cast<float2*>(dr + o0) = d0;
+        *reinterpret_cast<float2*>(dr + o1) = d1;
+        if (a != nullptr) {
+            const float av = bi == 0 ? a[o0] : (bi == 1 ? a[o0 + 1] : (bi == 2 ? a[o1] : a[o1 + 1]));
+            acc[0] += gg * av;
+        }
+    }
+    if ((h & 1) || (w & 1)) {
+        for (int t = threadIdx.x; t < h * w; t += kBlock) {
+            const int y = t / w, x = t - y * w;
+            if (y >= 2 * ph || x >= 2 * pw) dr[base + t] = 0.f;
+        }
+    }
+    if (ds != nullptr) {
+        block_sum<1>(acc, red);
+        if (threadIdx.x == 0) ds[plane] = acc[0];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// head: logits = (g*drop) W + b; softmax; label-smoothed cross-entropy (keras semantics)
+// ---------------------------------------------------------------------------
+// one workgroup (64 threads) per sample; `feat` is the (dropped-out) GAP feature vector
+__global__ void head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                const float* __restrict__ b, const float* __restrict__ ytrue,
+                                float* __restrict__ probs, float* __restrict__ loss, int f, int c) {
+    extern __shared__ float sm[];  // [c] logits
+    const int n = blockIdx.x;
+    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+        float acc = b[j];
+        for (int i = 0; i < f; ++i) acc = fmaf(feat[(size_t)n * f + i], w[(size_t)i * c + j], acc);
+        sm[j] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mx = sm[0];
+        for (int j = 1; j < c; ++j) mx = fmaxf(mx, sm[j]);
+        float den = 0.f;
+        for (int j = 0; j < c; ++j) den += expf(sm[j] - mx);
+        float l = 0.f;
+        for (int j = 0; j < c; ++j) {
+            const float pr = expf(sm[j] - mx) / den;
+            probs[(size_t)n * c + j] = pr;
+            if (ytrue != nullptr) {
+                // keras categorical_crossentropy: clip to [1e-7, 1-1e-7] then -sum y log p
+                const float pc = fminf(fmaxf(pr, 1e-7f), 1.f - 1e-7f);
+                l -= ytrue[(size_t)n * c + j] * logf(pc);
+            }
+        }
+        if (loss != nullptr) loss[n] = l;
+    }
+}
+
+// dlogits = (probs - ytrue) * inv_n; dfeat = dlogits W^T; (dW, db) by outer_sum_kernel
+__global__ void head_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ ytrue,
+                                const float* __restrict__ w, float* __restrict__ dlogits,
+                                float* __restrict__ dfeat, int f, int c, float inv_n) {
+    extern __shared__ float sm[];  // [c]
+    const int n = blockIdx.x;
+    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+        const float d = (probs[(size_t)n * c + j] - ytrue[(size_t)n * c + j]) * inv_n;
+        sm[j] = d;
+        dlogits[(size_t)n * c + j] = d;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < f; i += blockDim.x) {
+        float acc = 0.f;
+        for (int j = 0; j < c; ++j) acc = fmaf(sm[j], w[(size_t)i * c + j], acc);
+        dfeat[(size_t)n * f + i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void mul_kernel(const float* __restrict__ a,
+                                                     const float* __restrict__ b,
+                                                     float* __restrict__ out, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * kBlock)
+        out[i] = a[i] * b[i];
+}
+
+// ---------------------------------------------------------------------------
+// AdamW (keras 3): per-tensor clipnorm, L2-regulariser gradient, decoupled weight decay,
+// bias-corrected Adam, EMA of the updated weights.  Flat buffers + a segment table.
+// ---------------------------------------------------------------------------
+// norms: one workgroup per tensor: sum over (g + 2*l2*w)^2
+__global__ __launch_bounds__(1024) void adam_norm_kernel(const float* __restrict__ p,
+                                                         const float* __restrict__ g,
+                                                         const long long* __restrict__ offs,
+                                                         const float* __restrict__ l2,
+                                                         float* __restrict__ norms) {
+    __shared__ double red[16];
+    const int t = blockIdx.x;
+    const long long b = offs[t], e = offs[t + 1];
+    const float l2c = 2.f * l2[t];
+    double acc = 0.0;
+    for (long long i = b + threadIdx.x; i < e; i += 1024) {
+        const float gv = fmaf(l2c, p[i], g[i]);
+        acc += (double)gv * gv;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < 16; ++k) s += red[k];
+        norms[t] = (float)sqrt(s);
+    }
+}
+
+struct AdamArgs {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    float* ema;  // may be null
+    const long long* offs;
+    const float* l2;
+    const float* norms;
+    float lr, beta1, beta2, eps, wd, clipnorm, alpha, ema_decay;
+    int ema_copy;
+};
+
+__global__ __launch_bounds__(kBlock) void adam_step_kernel(AdamArgs a) {
+    const int t = blockIdx.y;
+    const long long b = a.offs[t], e = a.offs[t + 1];
+    const float l2c = 2.f * a.l2[t];
+    // keras clip_by_norm: g * clip / max(norm, clip)
+    const float cf = a.clipnorm > 0.f ? a.clipnorm / fmaxf(a.norms[t], a.clipnorm) : 1.f;
+    for (long long i = b + (long long)blockIdx.x * kBlock + threadIdx.x; i < e;
+         i += (long long)gridDim.x * kBlock) {
+        float w = a.p[i];
+        const float gv = fmaf(l2c, w, a.g[i]) * cf;
+        w -= w * a.wd * a.lr;  // decoupled decay first (keras _apply_weight_decay)
+        float m = a.m[i], v = a.v[i];
+        m += (gv - m) * (1.f - a.beta1);
+        v += (gv * gv - v) * (1.f - a.beta2);
+        w -= m * a.alpha / (sqrtf(v) + a.eps);
+        a.p[i] = w;
+        a.m[i] = m;
+        a.v[i] = v;
+        if (a.ema != nullptr) a.ema[i] = a.ema_copy ? w : a.ema_decay * a.ema[i] + (1.f - a.ema_decay) * w;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ema_kernel(float* __restrict__ ema,
+                                                     const float* __restrict__ w, size_t count,
+                                                     float decay, int copy) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * kBlock)
+        ema[i] = copy ? w[i] : decay * ema[i] + (1.f - decay) * w[i];
+}
+
+inline unsigned plane_grid(int hw_items) { return lf::stream_grid((size_t)hw_items, kBlock, 64); }
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int lf_input_stage_f32(const uint8_t* in, float* out, int n, int h, int w, const float* aug4,
+                       const float* mean3, const float* denom3, float* means_ws,
+                       lf_stream_t stream) {
+    LF_REQUIRE(in && out && aug4 && means_ws, "lf_input_stage: null buffer");
+    LF_REQUIRE(n > 0 && h > 1 && w > 1, "lf_input_stage: bad dims n=%d h=%d w=%d", n, h, w);
+    LF_REQUIRE((mean3 == nullptr) == (denom3 == nullptr), "lf_input_stage: mean/denom must both be set");
+    LF_REQUIRE(n <= 65535, "lf_input_stage: batch too large");
+    float m[3] = {0, 0, 0}, d[3] = {1, 1, 1};
+    if (mean3)
+        for (int c = 0; c < 3; ++c) {
+            m[c] = mean3[c];
+            d[c] = denom3[c];
+        }
+    hipStream_t s = lf::as_stream(stream);
+    aug_means_kernel<<<n, kBlock, 0, s>>>(in, aug4, means_ws, h, w);
+    input_aug_kernel<<<dim3(plane_grid(h * w), n), kBlock, 0, s>>>(in, out, aug4, means_ws, h, w,
+                                                                   m[0], m[1], m[2], d[0], d[1], d[2]);
+    return lf::check_launch("lf_input_stage");
+}
+
+int lf_scale_shift_act_f32(const float* x, float* out, int n, int c, int hw, const float* scale,
+                           const float* shift, int relu, lf_stream_t stream) {
+    LF_REQUIRE(x && out && scale && shift, "lf_scale_shift_act: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && hw > 0 && (long long)n * c < (1LL << 31),
+               "lf_scale_shift_act: bad dims n=%d c=%d hw=%d", n, c, hw);
+    hipStream_t s = lf::as_stream(stream);
+    const int planes = n * c;
+    if ((hw & 3) == 0)
+        scale_shift_act_kernel<4><<<dim3(planes, plane_grid(hw / 4)), kBlock, 0, s>>>(x, out, c, hw / 4,
+                                                                                 scale, shift, relu);
+    else
+        scale_shift_act_kernel<1><<<dim3(planes, plane_grid(hw)), kBlock, 0, s>>>(x, out, c, hw, scale,
+                                                                             shift, relu);
+    return lf::check_launch("lf_scale_shift_act");
+}
+
+size_t lf_bn_workspace(int c) { return c > 0 ? (size_t)c * kBnSplit * 2 * sizeof(float) : 0; }
+
+int lf_bn_train_stats_f32(const float* y, int n, int c, int hw, const float* gamma,
+                          const float* beta, float* moving_mean, float* moving_var, float momentum,
+                          float eps, float* mean, float* invstd, float* scale, float* shift,
+                          void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(y && gamma && beta && moving_mean && moving_var && mean && invstd && scale && shift &&
+                   workspace,
+               "lf_bn_train_stats: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && hw > 0 && c <= 65535, "lf_bn_train_stats: bad dims n=%d c=%d hw=%d", n, c, hw);
+    if (ws_bytes < lf_bn_workspace(c)) {
+        lf::set_error("lf_bn_train_stats: workspace %zu < %zu", ws_bytes, lf_bn_workspace(c));
+        return LF_ERR_WORKSPACE;
+    }
+    hipStream_t s = lf::as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    bn_stats_kernel<<<dim3(kBnSplit, c), kBlock, 0, s>>>(y, n, c, hw, part);
+    bn_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(y, part, c, hw, (double)n * hw, gamma, beta,
+                                                   moving_mean, moving_var, momentum, eps, mean,
+                                                   invstd, scale, shift);
+    return lf::check_launch("lf_bn_train_stats");
+}
+
+int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
+                                const float* moving_mean, const float* moving_var, float eps,
+                                float* scale, float* shift, lf_stream_t stream) {
+    LF_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift, "lf_bn_infer: null buffer");
+    LF_REQUIRE(c > 0, "lf_bn_infer: bad c=%d", c);
+    bn_infer_kernel<<<(c + 63) / 64, 64, 0, lf::as_stream(stream)>>>(c, gamma, beta, moving_mean,
+                                                                   moving_var, eps, scale, shift);
+    return lf::check_launch("lf_bn_infer");
+}
+
+int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* mask,
+                  const float* y, const float* mean, const float* invstd, const float* gamma,
+                  float* dy, float* dgamma, float* dbeta, int n, int c, int hw, void* workspace,
+                  size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(g && y && mean && invstd && gamma && dy && dgamma && dbeta && workspace,
+               "lf_bn_bwd: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && hw > 0 && c <= 65535 && (long long)n * c < (1LL << 31),
+               "lf_bn_bwd: bad dims n=%d c=%d hw=%d", n, c, hw);
+    if (ws_bytes < lf_bn_workspace(c)) {
+        lf::set_error("lf_bn_bwd: workspace %zu < %zu", ws_bytes, lf_bn_workspace(c));
+        return LF_ERR_WORKSPACE;
+    }
+    BnBwdArgs a{g, alpha_nc, add_nc, mask, y, mean, invstd, n, c, hw};
+    hipStream_t s = lf::as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    bn_bwd_reduce_kernel<<<dim3(kBnSplit, c), kBlock, 0, s>>>(a, part);
+    bn_bwd_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(part, c, dgamma, dbeta);
+    bn_bwd_apply_kernel<<<dim3(n * c, plane_grid(hw)), kBlock, 0, s>>>(
+        a, gamma, dgamma, dbeta, 1.0f / ((float)n * (float)hw), dy);
+    return lf::check_launch("lf_bn_bwd");
+}
+
+int lf_gap_f32(const float* x, float* out, int planes, int hw, lf_stream_t stream) {
+    LF_REQUIRE(x && out, "lf_gap: null buffer");
+    LF_REQUIRE(planes > 0 && hw > 0, "lf_gap: bad dims planes=%d hw=%d", planes, hw);
+    gap_kernel<<<planes, kBlock, 0, lf::as_stream(stream)>>>(x, out, hw);
+    return lf::check_launch("lf_gap");
+}
+
+int lf_bcast_planes_f32(const float* v, float* out, int planes, int hw, float scale,
+                        lf_stream_t stream) {
+    LF_REQUIRE(v && out, "lf_bcast_planes: null buffer");
+    LF_REQUIRE(planes > 0 && hw > 0, "lf_bcast_planes: bad dims planes=%d hw=%d", planes, hw);
+    bcast_planes_kernel<<<dim3(planes, plane_grid(hw)), kBlock, 0, lf::as_stream(stream)>>>(v, out, hw,
+                                                                                           scale);
+    return lf::check_launch("lf_bcast_planes");
+}
+
+int lf_se_fwd_f32(const float* m, const float* w1, const float* b1, const float* w2,
+                  const float* b2, float* z1, float* s, int n, int c, int cr, lf_stream_t stream) {
+    LF_REQUIRE(m && w1 && b1 && w2 && b2 && z1 && s, "lf_se_fwd: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && cr > 0 && c + cr <= 8192, "lf_se_fwd: bad dims n=%d c=%d cr=%d", n, c, cr);
+    se_fwd_kernel<<<n, kBlock, (size_t)(c + cr) * sizeof(float), lf::as_stream(stream)>>>(
+        m, w1, b1, w2, b2, z1, s, c, cr);
+    return lf::check_launch("lf_se_fwd");
+}
+
+size_t lf_se_bwd_workspace(int n, int c, int cr) {
+    return (n > 0 && c > 0 && cr > 0) ? (size_t)n * (c + cr) * sizeof(float) : 0;
+}
+
+int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float* s,
+                  const float* w1, const float* w2, float* dm, float* dw1, float* db1, float* dw2,
+                  float* db2, int n, int c, int cr, void* workspace, size_t ws_bytes,
+                  lf_stream_t stream) {
+    LF_REQUIRE(ds && m && z1 && s && w1 && w2 && dm && dw1 && db1 && dw2 && db2 && workspace,
+               "lf_se_bwd: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && cr > 0 && c + cr <= 8192, "lf_se_bwd: bad dims n=%d c=%d cr=%d", n, c, cr);
+    if (ws_bytes < lf_se_bwd_workspace(n, c, cr)) {
+        lf::set_error("lf_se_bwd: workspace too small");
+        return LF_ERR_WORKSPACE;
+    }
+    hipStream_t st = lf::as_stream(stream);
+    float* dpre2 = static_cast<float*>(workspace);
+    float* dpre1 = dpre2 + (size_t)n * c;
+    se_bwd_sample_kernel<<<n, kBlock, (size_t)(c + cr) * sizeof(float), st>>>(ds, s, z1, w1, w2, dpre2,
+                                                                              dpre1, dm, c, cr);
+    // dw1[c][cr] = sum_n m[n][c] dpre1[n][cr]; dw2[cr][c] = sum_n z1[n][cr] dpre2[n][c]
+    outer_sum_kernel<<<lf::stream_grid((size_t)(c + 1) * cr, kBlock), kBlock, 0, st>>>(m, dpre1, dw1, db1,
+                                                                                    n, c, cr);
+    outer_sum_kernel<<<lf::stream_grid((size_t)(cr + 1) * c, kBlock), kBlock, 0, st>>>(z1, dpre2, dw2,
+                                                                                    db2, n, cr, c);
+    return lf::check_launch("lf_se_bwd");
+}
+
+int lf_block_tail_fwd_f32(const float* a, const float* s, const float* sc, const float* sc_scale,
+                          const float* sc_shift, const float* drop, float* r, float* p, int n,
+                          int c, int h, int w, lf_stream_t stream) {
+    LF_REQUIRE(a && sc && r && p, "lf_block_tail_fwd: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && h > 1 && w > 1 && (long long)n * c < (1LL << 31),
+               "lf_block_tail_fwd: bad dims n=%d c=%d h=%d w=%d", n, c, h, w);
+    LF_REQUIRE((w & 1) == 0, "lf_block_tail_fwd: width must be even (float2 rows)");
+    LF_REQUIRE((sc_scale == nullptr) == (sc_shift == nullptr), "lf_block_tail_fwd: sc_scale/sc_shift");
+    tail_fwd_kernel<<<dim3(n * c, plane_grid((h / 2) * (w / 2))), kBlock, 0, lf::as_stream(stream)>>>(
+        a, s, sc, sc_scale, sc_shift, drop, r, p, c, h, w);
+    return lf::check_launch("lf_block_tail_fwd");
+}
+
+int lf_block_tail_bwd_f32(const float* dp, const float* r, const float* a, const float* drop,
+                          float* dr, float* ds, int n, int c, int h, int w, lf_stream_t stream) {
+    LF_REQUIRE(dp && r && dr, "lf_block_tail_bwd: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && h > 1 && w > 1, "lf_block_tail_bwd: bad dims n=%d c=%d h=%d w=%d", n, c, h, w);
+    LF_REQUIRE((w & 1) == 0, "lf_block_tail_bwd: width must be even (float2 rows)");
+    LF_REQUIRE((a == nullptr) == (ds == nullptr), "lf_block_tail_bwd: a and ds go together");
+    tail_bwd_kernel<<<n * c, kBlock, 0, lf::as_stream(stream)>>>(dp, r, a, drop, dr, ds, h, w);
+    return lf::check_launch("lf_block_tail_bwd");
+}
+
+int lf_head_fwd_f32(const float* feat, const float* w, const float* b, const float* ytrue,
+                    float* probs, float* loss, int n, int f, int c, lf_stream_t stream) {
+    LF_REQUIRE(feat && w && b && probs, "lf_head_fwd: null buffer");
+    LF_REQUIRE(n > 0 && f > 0 && c > 0 && c <= 4096, "lf_head_fwd: bad dims n=%d f=%d c=%d", n, f, c);
+    LF_REQUIRE((ytrue == nullptr) == (loss == nullptr), "lf_head_fwd: ytrue and loss go together");
+    head_fwd_kernel<<<n, 64, (size_t)c * sizeof(float), lf::as_stream(stream)>>>(feat, w, b, ytrue, probs,
+                                                                               loss, f, c);
+    return lf::check_launch("lf_head_fwd");
+}
+
+int lf_head_bwd_f32(const float* feat, const float* w, const float* probs, const float* ytrue,
+                    float* dlogits, float* dfeat, float* dw, float* db, int n, int f, int c,
+                    float inv_n, lf_stream_t stream) {
+    LF_REQUIRE(feat && w && probs && ytrue && dlogits && dfeat && dw && db, "lf_head_bwd: null buffer");
+    LF_REQUIRE(n > 0 && f > 0 && c > 0 && c <= 4096, "lf_head_bwd: bad dims n=%d f=%d c=%d", n, f, c);
+    hipStream_t st = lf::as_stream(stream);
+    head_bwd_kernel<<<n, 64, (size_t)c * sizeof(float), st>>>(probs, ytrue, w, dlogits, dfeat, f, c, inv_n);
+    // dW[f][c] = sum_n feat[n][f] dlogits[n][c]; db[c] = sum_n dlogits[n][c]
+    outer_sum_kernel<<<lf::stream_grid((size_t)(f + 1) * c, kBlock), kBlock, 0, st>>>(feat, dlogits, dw, db,
+                                                                                   n, f, c);
+    return lf::check_launch("lf_head_bwd");
+}
+
+int lf_mul_f32(const float* a, const float* b, float* out, size_t count, lf_stream_t stream) {
+    LF_REQUIRE(a && b && out, "lf_mul: null buffer");
+    LF_REQUIRE(count > 0, "lf_mul: empty");
+    mul_kernel<<<lf::stream_grid(count, kBlock), kBlock, 0, lf::as_stream(stream)>>>(a, b, out, count);
+    return lf::check_launch("lf_mul");
+}
+
+int lf_adamw_step_f32(float* param, const float* grad, float* m, float* v, float* ema,
+                      const long long* offsets, const float* l2, int ntensors, long long max_count,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      float clipnorm, long long step, float ema_decay, int ema_copy,
+                      float* norms_ws, lf_stream_t stream) {
+    LF_REQUIRE(param && grad && m && v && offsets && l2 && norms_ws, "lf_adamw_step: null buffer");
+    LF_REQUIRE(ntensors > 0 && ntensors <= 65535 && max_count > 0 && step >= 1,
+               "lf_adamw_step: bad ntensors=%d max_count=%lld step=%lld", ntensors, max_count, step);
+    hipStream_t st = lf::as_stream(stream);
+    adam_norm_kernel<<<ntensors, 1024, 0, st>>>(param, grad, offsets, l2, norms_ws);
+    AdamArgs a;
+    a.p = param; a.g = grad; a.m = m; a.v = v; a.ema = ema; a.offs = offsets; a.l2 = l2;
+    a.norms = norms_ws;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.clipnorm = clipnorm;
+    const double b1p = pow((double)beta1, (double)step), b2p = pow((double)beta2, (double)step);
+    a.alpha = (float)((double)lr * sqrt(1.0 - b2p) / (1.0 - b1p));
+    a.ema_decay = ema_decay;
+    a.ema_copy = ema_copy;
+    const unsigned gx = lf::stream_grid((size_t)max_count, kBlock, 64);
+    adam_step_kernel<<<dim3(gx, ntensors), kBlock, 0, st>>>(a);
+    return lf::check_launch("lf_adamw_step");
+}
+
+int lf_ema_update_f32(float* ema, const float* w, size_t count, float decay, int copy,
+                      lf_stream_t stream) {
+    LF_REQUIRE(ema && w, "lf_ema_update: null buffer");
+    LF_REQUIRE(count > 0, "lf_ema_update: empty");
+    ema_kernel<<<lf::stream_grid(count, kBlock), kBlock, 0, lf::as_stream(stream)>>>(ema, w, count, decay,
+                                                                                 copy);
+    return lf::check_launch("lf_ema_update");
+}
+
+}  // extern "C"

@@ -1,0 +1,588 @@
+"""leaf_cnn on MI355X: the reference's residual-SE CNN (srcs/model/cnn.py:9-131) with a
+hand-written forward/backward over libleafhip's kernels.
+
+`build_leafcnn(...)` keeps the reference's signature and returns `(model, norm_layer)`;
+the model object offers what the reference's callers use of a Keras model
+(SURVEY §8b "Model object contract"): `fit`, `evaluate`, `predict`, `get_weights`,
+`set_weights`, `save`, `stop_training` — plus `train_step` for the benchmark.
+
+Data layout in HBM: activations NCHW f32; every trainable tensor lives in ONE flat f32
+buffer (`flat_p`, with matching `flat_g`, Adam `flat_m`/`flat_v` and `flat_ema`), so the
+optimizer is two launches and data-parallel training all-reduces one bucket.  Conv kernels
+are stored "IKO" [Cin, k*k, Cout]; `get_weights()` converts to keras HWIO.
+"""
+from __future__ import annotations
+
+import json
+import math
+import zipfile
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import nn, ops
+
+BN_MOMENTUM = 0.99
+BN_EPS = 1e-3
+NORM_EPS = 1e-7
+
+
+def _specs(num_classes: int, widths: List[int], use_se: bool):
+    """Trainable tensors in creation order: (name, shape, kind).  kind 'w3' = 3x3 kernel
+    (carries the L2 kernel_regularizer, cnn.py:21-29), 'w1' = 1x1 kernel, 'vec', 'dense'."""
+    out = [("stem.w", (3, 9, widths[0]), "w3"), ("stem.bn.gamma", (widths[0],), "vec"),
+           ("stem.bn.beta", (widths[0],), "vec")]
+    cin = widths[0]
+    for i, f in enumerate(widths):
+        p = f"s{i}."
+        out += [(p + "c1.w", (cin, 9, f), "w3"), (p + "bn1.gamma", (f,), "vec"),
+                (p + "bn1.beta", (f,), "vec"), (p + "c2.w", (f, 9, f), "w3"),
+                (p + "bn2.gamma", (f,), "vec"), (p + "bn2.beta", (f,), "vec")]
+        if use_se:
+            out += [(p + "se.w1", (f, f // 8), "w1"), (p + "se.b1", (f // 8,), "vec"),
+                    (p + "se.w2", (f // 8, f), "w1"), (p + "se.b2", (f,), "vec")]
+        if cin != f:
+            out += [(p + "proj.w", (cin, 1, f), "w1"), (p + "bnp.gamma", (f,), "vec"),
+                    (p + "bnp.beta", (f,), "vec")]
+        cin = f
+    out += [("dense.w", (widths[-1], num_classes), "dense"), ("dense.b", (num_classes,), "vec")]
+    return out
+
+
+def _bn_layers(widths: List[int]):
+    out = [("stem.bn", widths[0])]
+    cin = widths[0]
+    for i, f in enumerate(widths):
+        out += [(f"s{i}.bn1", f), (f"s{i}.bn2", f)]
+        if cin != f:
+            out.append((f"s{i}.bnp", f))
+        cin = f
+    return out
+
+
+class Normalization:
+    """keras.layers.Normalization(axis=-1) stand-in: per-channel mean/variance, adapt()."""
+
+    def __init__(self) -> None:
+        self.mean = np.zeros(3, np.float32)
+        self.variance = np.ones(3, np.float32)
+        self.adapted = False
+
+    def adapt(self, data: np.ndarray) -> None:
+        """data: [N,H,W,3] float32 in [0,1] (the loader's output)."""
+        d = np.asarray(data, dtype=np.float64).reshape(-1, data.shape[-1])
+        self.mean = d.mean(axis=0).astype(np.float32)
+        self.variance = d.var(axis=0).astype(np.float32)
+        self.adapted = True
+
+    @property
+    def denom(self) -> np.ndarray:
+        return np.maximum(np.sqrt(self.variance), NORM_EPS).astype(np.float32)
+
+
+class LeafCNN:
+    name = "leaf_cnn"
+
+    def __init__(self, *, num_classes: int, img_size: int = 224, use_norm: bool = True,
+                 widths: Optional[List[int]] = None, drop_block: float = 0.15,
+                 drop_top: float = 0.40, l2_reg: float = 0.0, separable: bool = False,
+                 augment: bool = True, use_se: bool = True, seed: int = 0,
+                 device: Optional[torch.device] = None) -> None:
+        if separable:
+            raise NotImplementedError("SeparableConv2D (--separable) is outside the hot-path scope")
+        if not torch.cuda.is_available():
+            raise RuntimeError("LeafCNN needs a HIP device: there is no CPU fallback")
+        self.num_classes = int(num_classes)
+        self.img_size = int(img_size)
+        self.widths = list(widths or [32, 64, 128])
+        self.drop_block = float(drop_block or 0.0)
+        self.drop_top = float(drop_top or 0.0)
+        self.l2_reg = float(l2_reg or 0.0)
+        self.augment = bool(augment)
+        self.use_se = bool(use_se)
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.norm = Normalization() if use_norm else None
+        self.stop_training = False
+        self.gen = torch.Generator(device="cpu").manual_seed(int(seed))
+        self.np_rng = np.random.RandomState(int(seed) & 0x7FFFFFFF)
+
+        # ---- flat parameter / state storage
+        self.specs = _specs(self.num_classes, self.widths, self.use_se)
+        offs, off = [0], 0
+        for _n, shape, _k in self.specs:
+            off += int(np.prod(shape))
+            offs.append(off)
+        self.n_params = off
+        dev = self.device
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.flat_ema = torch.zeros_like(self.flat_p)
+        self.offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self.l2_vec = torch.tensor([self.l2_reg if k == "w3" else 0.0 for _n, _s, k in self.specs],
+                                   dtype=torch.float32, device=dev)
+        self.max_count = max(int(np.prod(s)) for _n, s, _k in self.specs)
+        self.norms_ws = torch.empty(len(self.specs), dtype=torch.float32, device=dev)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        for (name, shape, _k), b, e in zip(self.specs, offs[:-1], offs[1:]):
+            self.p[name] = self.flat_p[b:e].view(shape)
+            self.g[name] = self.flat_g[b:e].view(shape)
+        self.bn_layers = _bn_layers(self.widths)
+        soff = 0
+        for _n, c in self.bn_layers:
+            soff += 2 * c
+        self.flat_s = torch.zeros(soff, dtype=torch.float32, device=dev)
+        self.flat_s_ema = torch.zeros_like(self.flat_s)
+        self.s: Dict[str, torch.Tensor] = {}
+        self.stats: Dict[str, torch.Tensor] = {}
+        soff = 0
+        for n_, c in self.bn_layers:
+            self.s[n_ + ".mean"] = self.flat_s[soff:soff + c]
+            self.s[n_ + ".var"] = self.flat_s[soff + c:soff + 2 * c]
+            soff += 2 * c
+            self.stats[n_] = torch.zeros((4, c), dtype=torch.float32, device=dev)
+        self._init_weights()
+        self.opt_step = 0
+        self.ema_started = False
+        self._bufs: Dict[Any, Dict[str, torch.Tensor]] = {}
+        self._wt: Dict[str, torch.Tensor] = {}
+        self._saved: Dict[str, Any] = {}
+
+    # ------------------------------------------------------------------ init
+    def _init_weights(self) -> None:
+        """glorot_uniform kernels, zero biases, BN gamma=1/beta=0, moving mean 0 / var 1."""
+        for name, shape, kind in self.specs:
+            if kind == "vec":
+                self.p[name].fill_(1.0 if name.endswith("gamma") else 0.0)
+                continue
+            if len(shape) == 3:
+                fan_in, fan_out = shape[0] * shape[1], shape[2] * shape[1]
+            else:
+                fan_in, fan_out = shape
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            w = (torch.rand(shape, generator=self.gen) * 2 - 1) * lim
+            self.p[name].copy_(w)
+        for n_, _c in self.bn_layers:
+            self.s[n_ + ".mean"].zero_()
+            self.s[n_ + ".var"].fill_(1.0)
+
+    # ------------------------------------------------------------- buffers
+    def _buf(self, n: int, key: str, shape) -> torch.Tensor:
+        d = self._bufs.setdefault(n, {})
+        t = d.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            d[key] = t
+        return t
+
+    def _norm_consts(self):
+        if self.norm is None:
+            return None, None
+        return [float(v) for v in self.norm.mean], [float(v) for v in self.norm.denom]
+
+    # --------------------------------------------------------------- input
+    def draw_augmentation(self, n: int) -> torch.Tensor:
+        """Per-image {flip, cos, sin, contrast}: RandomFlip("horizontal"), RandomRotation(0.05)
+        (angle ~ U(-0.05, 0.05) * 2 pi), RandomContrast(0.1) (factor ~ U(0.9, 1.1)); cnn.py:76-80."""
+        flip = (self.np_rng.uniform(size=n) <= 0.5).astype(np.float32)
+        ang = self.np_rng.uniform(-0.05, 0.05, size=n) * 2.0 * math.pi
+        ct = self.np_rng.uniform(0.9, 1.1, size=n).astype(np.float32)
+        a = np.stack([flip, np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32), ct], 1)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def _input(self, x, training: bool, aug4: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Accepts uint8 [N,H,W,3] (host or device) or float32 [N,H,W,3] in [0,1] (the
+        reference loader's format); returns normalised f32 NCHW on the device."""
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        x = x.to(self.device, non_blocking=True)
+        n = x.shape[0]
+        mean, denom = self._norm_consts()
+        out = self._buf(n, "x0", (n, 3, x.shape[1], x.shape[2]))
+        if x.dtype == torch.uint8:
+            x = x.contiguous()
+            if training and self.augment:
+                if aug4 is None:
+                    aug4 = self.draw_augmentation(n)
+                return nn.input_stage(x, aug4, mean, denom, out=out)
+            return ops.pack_hwc_u8_to_nchw_f32(x, mean, denom, out=out)
+        if x.dtype != torch.float32:
+            raise TypeError("model input must be uint8 or float32 [N,H,W,3]")
+        if training and self.augment:
+            u8 = (x * 255.0).round().clamp_(0, 255).to(torch.uint8).contiguous()
+            if aug4 is None:
+                aug4 = self.draw_augmentation(n)
+            return nn.input_stage(u8, aug4, mean, denom, out=out)
+        xc = x.permute(0, 3, 1, 2).contiguous()
+        if mean is None:
+            return xc
+        sc = torch.tensor([1.0 / d for d in denom], dtype=torch.float32, device=self.device)
+        sh = torch.tensor([-m / d for m, d in zip(mean, denom)], dtype=torch.float32,
+                          device=self.device)
+        return nn.scale_shift_act(xc, sc, sh, False, out=out)
+
+    # ------------------------------------------------------------- forward
+    def _bn(self, name: str, y: torch.Tensor, training: bool) -> torch.Tensor:
+        st = self.stats[name]
+        if training:
+            nn.bn_train_stats(y, self.p[name + ".gamma"], self.p[name + ".beta"],
+                              self.s[name + ".mean"], self.s[name + ".var"], st, BN_MOMENTUM, BN_EPS)
+        else:
+            nn.bn_infer_scale_shift(self.p[name + ".gamma"], self.p[name + ".beta"],
+                                    self.s[name + ".mean"], self.s[name + ".var"], st, BN_EPS)
+        return st
+
+    def forward(self, x0: torch.Tensor, training: bool, y_true: Optional[torch.Tensor] = None,
+                drops: Optional[List[torch.Tensor]] = None,
+                top_drop: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """x0: normalised f32 NCHW.  Returns (probs [N,C], per-sample loss or None).
+        In training mode every tensor the backward pass needs is kept in self._saved."""
+        n, _c, h, w = x0.shape
+        P, B = self.p, lambda k, shape: self._buf(n, k, shape)
+        sv: Dict[str, Any] = {"x0": x0, "n": n}
+        y = nn.conv2d(x0, P["stem.w"], 3, out=B("stem.y", (n, self.widths[0], h, w)))
+        st = self._bn("stem.bn", y, training)
+        a = nn.scale_shift_act(y, st[2], st[3], True, out=B("stem.a", y.shape))
+        sv["stem.y"], sv["stem.a"] = y, a
+        cin = self.widths[0]
+        for i, f in enumerate(self.widths):
+            p = f"s{i}."
+            xin = a
+            y1 = nn.conv2d(xin, P[p + "c1.w"], 3, out=B(p + "y1", (n, f, h, w)))
+            st1 = self._bn(p + "bn1", y1, training)
+            a1 = nn.scale_shift_act(y1, st1[2], st1[3], True, out=B(p + "a1", y1.shape))
+            y2 = nn.conv2d(a1, P[p + "c2.w"], 3, out=B(p + "y2", y1.shape))
+            st2 = self._bn(p + "bn2", y2, training)
+            a2 = nn.scale_shift_act(y2, st2[2], st2[3], True, out=B(p + "a2", y1.shape))
+            s = None
+            if self.use_se:
+                m = nn.gap(a2, out=B(p + "m", (n, f)))
+                z1 = B(p + "z1", (n, f // 8))
+                s = nn.se_fwd(m, P[p + "se.w1"], P[p + "se.b1"], P[p + "se.w2"], P[p + "se.b2"], z1,
+                              B(p + "s", (n, f)))
+                sv[p + "m"], sv[p + "z1"] = m, z1
+            if cin != f:
+                yp = nn.conv2d(xin, P[p + "proj.w"], 1, out=B(p + "yp", y1.shape))
+                stp = self._bn(p + "bnp", yp, training)
+                sc, scs, scb = yp, stp[2], stp[3]
+                sv[p + "yp"] = yp
+            else:
+                sc, scs, scb = xin, None, None
+            drop = drops[i] if (training and drops is not None) else None
+            r = B(p + "r", y1.shape)
+            pooled = B(p + "p", (n, f, h // 2, w // 2))
+            nn.block_tail_fwd(a2, s, sc, scs, scb, drop, r, pooled)
+            sv.update({p + "xin": xin, p + "y1": y1, p + "a1": a1, p + "y2": y2, p + "a2": a2,
+                       p + "s": s, p + "r": r, p + "drop": drop, p + "hw": (h, w)})
+            a, cin, h, w = pooled, f, h // 2, w // 2
+        g = nn.gap(a, out=B("g", (n, self.widths[-1])))
+        feat = g
+        if training and top_drop is not None:
+            feat = nn.mul(g, top_drop, B("feat", g.shape))
+        probs = B("probs", (n, self.num_classes))
+        loss = B("loss", (n,)) if y_true is not None else None
+        nn.head_fwd(feat, P["dense.w"], P["dense.b"], y_true, probs, loss)
+        sv.update({"feat": feat, "top_drop": top_drop, "probs": probs, "y_true": y_true,
+                   "last_hw": (h, w)})
+        if training:
+            self._saved = sv
+        return probs, loss
+
+    # ------------------------------------------------------------ backward
+    def backward(self) -> None:
+        """Fills flat_g with d(mean data loss)/d(param) for the last training forward."""
+        sv, P, G = self._saved, self.p, self.g
+        n = sv["n"]
+        B = lambda k, shape: self._buf(n, k, shape)  # noqa: E731
+        f_last = self.widths[-1]
+        dlogits = B("dlogits", (n, self.num_classes))
+        dfeat = B("dfeat", (n, f_last))
+        nn.head_bwd(sv["feat"], P["dense.w"], sv["probs"], sv["y_true"], dlogits, dfeat,
+                    G["dense.w"], G["dense.b"], 1.0 / n)
+        dg = dfeat
+        if sv["top_drop"] is not None:
+            dg = nn.mul(dfeat, sv["top_drop"], B("dg", dfeat.shape))
+        h, w = sv["last_hw"]
+        dp = nn.bcast_planes(dg, h, w, 1.0 / (h * w), out=B("dp_last", (n, f_last, h, w)))
+        for i in reversed(range(len(self.widths))):
+            f = self.widths[i]
+            cin = self.widths[i - 1] if i > 0 else self.widths[0]
+            p = f"s{i}."
+            h, w = sv[p + "hw"]
+            xin, y1, a1, y2, a2 = (sv[p + k] for k in ("xin", "y1", "a1", "y2", "a2"))
+            s, r, drop = sv[p + "s"], sv[p + "r"], sv[p + "drop"]
+            gA = B(p + "gA", y1.shape)
+            gB = B(p + "gB", y1.shape)
+            gC = B(p + "gC", y1.shape)
+            ds = B(p + "ds", (n, f)) if self.use_se else None
+            nn.block_tail_bwd(dp, r, a2 if self.use_se else None, drop, gA, ds)
+            add_nc = None
+            if self.use_se:
+                dm = B(p + "dm", (n, f))
+                nn.se_bwd(ds, sv[p + "m"], sv[p + "z1"], s, P[p + "se.w1"], P[p + "se.w2"], dm,
+                          G[p + "se.w1"], G[p + "se.b1"], G[p + "se.w2"], G[p + "se.b2"])
+                add_nc = dm.mul_(1.0 / (h * w))
+            # conv2 branch: dz2 = (dr*s + dm/HW) * (a2>0) -> BN2 backward -> dy2 (gB)
+            nn.bn_bwd(gA, y2, self.stats[p + "bn2"], P[p + "bn2.gamma"], G[p + "bn2.gamma"],
+                      G[p + "bn2.beta"], alpha_nc=s, add_nc=add_nc, mask=a2, out=gB)
+            nn.conv2d_wgrad(a1, gB, 3, out=G[p + "c2.w"])
+            nn.conv2d(gB, self._dgrad_w(p + "c2.w", 3), 3, out=gC)          # da1
+            nn.bn_bwd(gC, y1, self.stats[p + "bn1"], P[p + "bn1.gamma"], G[p + "bn1.gamma"],
+                      G[p + "bn1.beta"], mask=a1, out=gB)                     # dy1
+            nn.conv2d_wgrad(xin, gB, 3, out=G[p + "c1.w"])
+            need_dx = True
+            if cin != f:
+                nn.bn_bwd(gA, sv[p + "yp"], self.stats[p + "bnp"], P[p + "bnp.gamma"],
+                          G[p + "bnp.gamma"], G[p + "bnp.beta"], out=gC)       # dyp
+                nn.conv2d_wgrad(xin, gC, 1, out=G[p + "proj.w"])
+                dx = B(p + "dx", xin.shape)
+                nn.conv2d(gC, self._dgrad_w(p + "proj.w", 1), 1, out=dx)
+            else:
+                dx = gA  # identity shortcut: dx starts as dr
+            if need_dx:
+                nn.conv2d(gB, self._dgrad_w(p + "c1.w", 3), 3, out=dx, accumulate=True)
+            dp = dx
+        # stem: dp is the gradient wrt stem.a
+        gS = self._buf(n, "stem.g", sv["stem.y"].shape)
+        nn.bn_bwd(dp, sv["stem.y"], self.stats["stem.bn"], P["stem.bn.gamma"], G["stem.bn.gamma"],
+                  G["stem.bn.beta"], mask=sv["stem.a"], out=gS)
+        nn.conv2d_wgrad(sv["x0"], gS, 3, out=G["stem.w"])
+
+    def _dgrad_w(self, name: str, k: int) -> torch.Tensor:
+        return nn.conv2d_dgrad_weights(self.p[name], k)
+
+    # ------------------------------------------------------------ training
+    def draw_dropout(self, n: int):
+        """SpatialDropout2D keep-scales [N,C_i] per stage and Dropout keep-scales [N,F]."""
+        drops = None
+        if self.drop_block > 0:
+            drops = []
+            for f in self.widths:
+                keep = (torch.rand((n, f), generator=self.gen) >= self.drop_block).float()
+                drops.append((keep / (1.0 - self.drop_block)).to(self.device))
+        top = None
+        if self.drop_top > 0:
+            keep = (torch.rand((n, self.widths[-1]), generator=self.gen) >= self.drop_top).float()
+            top = (keep / (1.0 - self.drop_top)).to(self.device)
+        return drops, top
+
+    def train_step(self, x, y_true: torch.Tensor, lr: float, *, weight_decay: float = 1e-4,
+                   clipnorm: float = 0.5, ema_decay: float = 0.999, adamw: bool = True,
+                   grad_sync=None):
+        """One optimisation step on a batch.  y_true: f32 [N,C] (already label-smoothed).
+        grad_sync(flat_g) is called between backward and the optimizer (data-parallel
+        all-reduce).  Returns (probs, per-sample loss) device tensors (no host sync)."""
+        n = x.shape[0]
+        drops, top = self.draw_dropout(n)
+        x0 = self._input(x, True)
+        probs, loss = self.forward(x0, True, y_true, drops, top)
+        self.backward()
+        if grad_sync is not None:
+            grad_sync(self.flat_g)
+        self.opt_step += 1
+        nn.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v,
+                      self.flat_ema if ema_decay > 0 else None, self.offsets, self.l2_vec,
+                      self.max_count, lr, self.opt_step,
+                      weight_decay=weight_decay if adamw else 0.0, clipnorm=clipnorm,
+                      ema_decay=ema_decay, ema_copy=not self.ema_started, norms=self.norms_ws)
+        if ema_decay > 0:
+            nn.ema_update(self.flat_s_ema, self.flat_s, ema_decay, not self.ema_started)
+            self.ema_started = True
+        return probs, loss
+
+    def l2_penalty(self) -> torch.Tensor:
+        tot = torch.zeros((), dtype=torch.float32, device=self.device)
+        if self.l2_reg > 0:
+            for name, _s, kind in self.specs:
+                if kind == "w3":
+                    tot = tot + self.l2_reg * (self.p[name] ** 2).sum()
+        return tot
+
+    # ----------------------------------------------------------- inference
+    @torch.no_grad()
+    def predict(self, x, batch_size: int = 256, verbose: Any = 0) -> np.ndarray:
+        """probabilities [N,C] as a host array (keras Model.predict contract)."""
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        outs = []
+        for b in range(0, x.shape[0], batch_size):
+            xb = x[b:b + batch_size]
+            probs, _ = self.forward(self._input(xb, False), False)
+            outs.append(probs.clone())
+        return torch.cat(outs).cpu().numpy()
+
+    def predict_device(self, x) -> torch.Tensor:
+        probs, _ = self.forward(self._input(x, False), False)
+        return probs
+
+    def evaluate(self, data, verbose: Any = 0) -> List[float]:
+        """[loss, accuracy] over an iterable of (X, y) batches (one-hot or sparse labels)."""
+        tot_loss, correct, count = 0.0, 0, 0
+        for i in range(len(data)):
+            bx, by = data[i]
+            by = torch.as_tensor(np.asarray(by)).to(self.device)
+            if by.dim() == 1:
+                yt = torch.nn.functional.one_hot(by.long(), self.num_classes).float()
+                idx = by.long()
+            else:
+                yt = by.float()
+                idx = by.argmax(-1)
+            probs, loss = self.forward(self._input(bx, False), False, yt.contiguous())
+            tot_loss += float(loss.sum())
+            correct += int((probs.argmax(-1) == idx).sum())
+            count += int(idx.numel())
+        reg = float(self.l2_penalty())
+        return [tot_loss / max(count, 1) + reg, correct / max(count, 1)]
+
+    # ------------------------------------------------------------- weights
+    def weight_names(self) -> List[str]:
+        names = []
+        if self.norm is not None:
+            names += ["input_norm.mean", "input_norm.variance"]
+        bn_done = set()
+        for name, _s, _k in self.specs:
+            names.append(name)
+            if name.endswith(".beta"):
+                base = name[:-5]
+                if base not in bn_done:
+                    bn_done.add(base)
+                    names += [base + ".moving_mean", base + ".moving_variance"]
+        return names
+
+    def get_weights(self) -> List[np.ndarray]:
+        """All weights (trainable + BN moving statistics + normalization) as host arrays in
+        keras layouts: conv kernels HWIO [k,k,Cin,Cout], 1x1 SE convs [1,1,in,out]."""
+        out = []
+        for name in self.weight_names():
+            out.append(self._get_one(name))
+        return out
+
+    def _get_one(self, name: str) -> np.ndarray:
+        if name == "input_norm.mean":
+            return self.norm.mean.copy()
+        if name == "input_norm.variance":
+            return self.norm.variance.copy()
+        if name.endswith(".moving_mean"):
+            return self.s[name[:-12] + ".mean"].cpu().numpy()
+        if name.endswith(".moving_variance"):
+            return self.s[name[:-16] + ".var"].cpu().numpy()
+        t = self.p[name].detach().cpu()
+        kind = next(k for n_, _s, k in self.specs if n_ == name)
+        if kind == "w3" or (kind == "w1" and t.dim() == 3):
+            cin, taps, cout = t.shape
+            k = int(round(math.sqrt(taps)))
+            return t.view(cin, k, k, cout).permute(1, 2, 0, 3).contiguous().numpy()
+        if kind == "w1":
+            return t.view(1, 1, *t.shape).numpy().copy()
+        return t.numpy().copy()
+
+    def set_weights(self, weights: List[np.ndarray]) -> None:
+        names = self.weight_names()
+        if len(weights) != len(names):
+            raise ValueError(f"set_weights: expected {len(names)} arrays, got {len(weights)}")
+        for name, arr in zip(names, weights):
+            arr = np.asarray(arr, dtype=np.float32)
+            if name == "input_norm.mean":
+                self.norm.mean = arr.reshape(3).copy()
+            elif name == "input_norm.variance":
+                self.norm.variance = arr.reshape(3).copy()
+            elif name.endswith(".moving_mean"):
+                self.s[name[:-12] + ".mean"].copy_(torch.from_numpy(arr))
+            elif name.endswith(".moving_variance"):
+                self.s[name[:-16] + ".var"].copy_(torch.from_numpy(arr))
+            else:
+                t = torch.from_numpy(arr)
+                dst = self.p[name]
+                if t.dim() == 4 and dst.dim() == 3:      # HWIO -> IKO
+                    k = t.shape[0]
+                    t = t.permute(2, 0, 1, 3).reshape(t.shape[2], k * k, t.shape[3])
+                elif t.dim() == 4 and dst.dim() == 2:    # [1,1,in,out] -> [in,out]
+                    t = t.reshape(t.shape[2], t.shape[3])
+                dst.copy_(t.reshape(dst.shape))
+
+    def ema_weights(self) -> List[np.ndarray]:
+        """The EMA shadow in get_weights() order (train/utils.py:44-57 averages every weight)."""
+        live_p, live_s = self.flat_p.clone(), self.flat_s.clone()
+        self.flat_p.copy_(self.flat_ema)
+        self.flat_s.copy_(self.flat_s_ema)
+        w = self.get_weights()
+        self.flat_p.copy_(live_p)
+        self.flat_s.copy_(live_s)
+        return w
+
+    def config(self) -> Dict[str, Any]:
+        return {"name": self.name, "num_classes": self.num_classes, "img_size": self.img_size,
+                "use_norm": self.norm is not None, "widths": self.widths,
+                "drop_block": self.drop_block, "drop_top": self.drop_top, "l2_reg": self.l2_reg,
+                "separable": False, "augment": self.augment, "use_se": self.use_se}
+
+    def save(self, path) -> None:
+        """`leaf_cnn.keras`: a zip with config.json / metadata.json (keras-v3 member names) and
+        model.weights.npz (authoritative here; HDF5 needs h5py, which this image lacks)."""
+        path = Path(path)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        names = self.weight_names()
+        arrays = {f"{i:03d}:{n}": a for i, (n, a) in enumerate(zip(names, self.get_weights()))}
+        import io
+        buf = io.BytesIO()
+        np.savez(buf, **arrays)
+        with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+            z.writestr("config.json", json.dumps({"module": "leaffliction_amd.model.cnn",
+                                                   "class_name": "LeafCNN",
+                                                   "config": self.config()}, indent=1))
+            z.writestr("metadata.json", json.dumps({"leaffliction_amd_version": "0.1.0",
+                                                     "weights_format": "npz",
+                                                     "weight_names": names}, indent=1))
+            z.writestr("model.weights.npz", buf.getvalue())
+
+
+def load_model(path) -> LeafCNN:
+    """Counterpart of keras.models.load_model for files written by LeafCNN.save."""
+    import io
+    with zipfile.ZipFile(path) as z:
+        cfg = json.loads(z.read("config.json"))["config"]
+        data = np.load(io.BytesIO(z.read("model.weights.npz")))
+        meta = json.loads(z.read("metadata.json"))
+    model = LeafCNN(num_classes=cfg["num_classes"], img_size=cfg["img_size"],
+                    use_norm=cfg["use_norm"], widths=cfg["widths"], drop_block=cfg["drop_block"],
+                    drop_top=cfg["drop_top"], l2_reg=cfg["l2_reg"], augment=cfg["augment"],
+                    use_se=cfg["use_se"])
+    keys = sorted(data.files)
+    assert [k.split(":", 1)[1] for k in keys] == meta["weight_names"]
+    model.set_weights([data[k] for k in keys])
+    return model
+
+
+def build_leafcnn(*, num_classes: int, img_size: int = 224, use_norm: bool = True,
+                  widths: Optional[List[int]] = None, drop_block: float = 0.15,
+                  drop_top: float = 0.40, l2_reg: float = 0.0, separable: bool = False,
+                  augment: bool = True, use_se: bool = True, seed: int = 0):
+    """Same keyword signature as the reference (cnn.py:52-64); returns (model, norm_layer)."""
+    model = LeafCNN(num_classes=num_classes, img_size=img_size, use_norm=use_norm, widths=widths,
+                    drop_block=drop_block, drop_top=drop_top, l2_reg=l2_reg, separable=separable,
+                    augment=augment, use_se=use_se, seed=seed)
+    return model, model.norm
+
+
+def adapt_normalization(norm_layer, train_seq) -> None:
+    """cnn.py:107-131: adapt on the first batches (<= 64 batches, >= 2048 samples)."""
+    if norm_layer is None or not hasattr(norm_layer, "adapt"):
+        return
+    samples, collected = [], 0
+    for i in range(min(len(train_seq), 64)):
+        batch = train_seq[i]
+        X = batch[0] if isinstance(batch, (list, tuple)) else batch
+        if isinstance(X, torch.Tensor):
+            X = X.cpu().numpy()
+        if X.dtype == np.uint8:
+            X = X.astype(np.float32) / 255.0
+        samples.append(X)
+        collected += len(X)
+        if collected >= 2048:
+            break
+    if samples:
+        norm_layer.adapt(np.concatenate(samples, axis=0))

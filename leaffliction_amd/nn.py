@@ -27,7 +27,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def conv2d(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, in_scale=None, in_shift=None,
-           in_relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           in_relu: bool = False, out: Optional[torch.Tensor] = None,
+           accumulate: bool = False) -> torch.Tensor:
     """y = conv2d_same(x', w); x' = relu?(x*in_scale[c]+in_shift[c]) if a prologue is given.
 
     x [N,Cin,H,W] f32, w_iko [Cin, k*k, Cout] f32 -> y [N,Cout,H,W].
@@ -44,13 +45,16 @@ def conv2d(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, in_scale=None, in_s
             if t.shape[0] != cin:
                 raise ValueError(f"conv2d.{nm}: expected [{cin}]")
     if out is None:
+        if accumulate:
+            raise ValueError("conv2d: accumulate needs an output tensor")
         out = torch.empty((n, cout, h, w), dtype=_F32, device=x.device)
     else:
         _chk(out, _F32, "conv2d.out", 4)
         if tuple(out.shape) != (n, cout, h, w):
             raise ValueError("conv2d.out: shape mismatch")
     _lib.call("lf_conv2d_f32", x.data_ptr(), w_iko.data_ptr(), out.data_ptr(), n, cin, h, w, cout,
-              ksize, _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, _stream())
+              ksize, _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, 1 if accumulate else 0,
+              _stream())
     return out
 
 
@@ -89,3 +93,188 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, in_scale=None, i
               cout, ksize, _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, float(beta),
               ws.data_ptr(), ws.numel(), _stream())
     return out
+
+
+# ---------------------------------------------------------------------------
+# non-conv layers
+# ---------------------------------------------------------------------------
+def input_stage(x_u8: torch.Tensor, aug4: torch.Tensor, mean=None, denom=None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """u8 [N,H,W,3] -> f32 [N,3,H,W] with flip/rotate/contrast (aug4 [N,4]) + Normalization."""
+    _chk(x_u8, torch.uint8, "input_stage.x", 4)
+    _chk(aug4, _F32, "input_stage.aug", 2)
+    n, h, w, c = x_u8.shape
+    if c != 3 or tuple(aug4.shape) != (n, 4):
+        raise ValueError("input_stage: x must be [N,H,W,3] and aug [N,4]")
+    if out is None:
+        out = torch.empty((n, 3, h, w), dtype=_F32, device=x_u8.device)
+    ws = torch.empty((n, 3), dtype=_F32, device=x_u8.device)
+    m = d = None
+    if mean is not None:
+        m = (_lib.c_float * 3)(*[float(v) for v in mean])
+        d = (_lib.c_float * 3)(*[float(v) for v in denom])
+    _lib.call("lf_input_stage_f32", x_u8.data_ptr(), out.data_ptr(), n, h, w, aug4.data_ptr(), m, d,
+              ws.data_ptr(), _stream())
+    return out
+
+
+def scale_shift_act(x, scale, shift, relu: bool, out=None):
+    _chk(x, _F32, "scale_shift_act.x", 4)
+    n, c, h, w = x.shape
+    for t in (scale, shift):
+        _chk(t, _F32, "scale_shift_act.scale/shift", 1)
+        if t.shape[0] != c:
+            raise ValueError("scale_shift_act: per-channel vectors must be [C]")
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("lf_scale_shift_act_f32", x.data_ptr(), out.data_ptr(), n, c, h * w, scale.data_ptr(),
+              shift.data_ptr(), 1 if relu else 0, _stream())
+    return out
+
+
+def bn_train_stats(y, gamma, beta, mmean, mvar, stats, momentum=0.99, eps=1e-3):
+    """stats: f32 [4,C] rows = mean, invstd, scale, shift (written)."""
+    _chk(y, _F32, "bn_train_stats.y", 4)
+    n, c, h, w = y.shape
+    for t in (gamma, beta, mmean, mvar):
+        _chk(t, _F32, "bn_train_stats.param", 1)
+        if t.shape[0] != c:
+            raise ValueError("bn_train_stats: per-channel vectors must be [C]")
+    _chk(stats, _F32, "bn_train_stats.stats", 2)
+    if tuple(stats.shape) != (4, c):
+        raise ValueError("bn_train_stats.stats: expected [4,C]")
+    nbytes = _lib.load().lf_bn_workspace(c)
+    ws = _workspace(nbytes, y.device)
+    _lib.call("lf_bn_train_stats_f32", y.data_ptr(), n, c, h * w, gamma.data_ptr(), beta.data_ptr(),
+              mmean.data_ptr(), mvar.data_ptr(), float(momentum), float(eps), stats[0].data_ptr(),
+              stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), ws.data_ptr(),
+              ws.numel(), _stream())
+    return stats
+
+
+def bn_infer_scale_shift(gamma, beta, mmean, mvar, stats, eps=1e-3):
+    c = gamma.shape[0]
+    _lib.call("lf_bn_infer_scale_shift_f32", c, gamma.data_ptr(), beta.data_ptr(), mmean.data_ptr(),
+              mvar.data_ptr(), float(eps), stats[2].data_ptr(), stats[3].data_ptr(), _stream())
+    return stats
+
+
+def bn_bwd(g, y, stats, gamma, dgamma, dbeta, alpha_nc=None, add_nc=None, mask=None, out=None):
+    _chk(g, _F32, "bn_bwd.g", 4)
+    _chk(y, _F32, "bn_bwd.y", 4)
+    if g.shape != y.shape or (mask is not None and mask.shape != y.shape):
+        raise ValueError("bn_bwd: g, y (and mask) must share a shape")
+    n, c, h, w = y.shape
+    for t in (alpha_nc, add_nc):
+        if t is not None:
+            _chk(t, _F32, "bn_bwd.alpha/add", 2)
+            if tuple(t.shape) != (n, c):
+                raise ValueError("bn_bwd: alpha/add must be [N,C]")
+    if out is None:
+        out = torch.empty_like(y)
+    ws = _workspace(_lib.load().lf_bn_workspace(c), y.device)
+    _lib.call("lf_bn_bwd_f32", g.data_ptr(), _ptr(alpha_nc), _ptr(add_nc), _ptr(mask), y.data_ptr(),
+              stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(), out.data_ptr(),
+              dgamma.data_ptr(), dbeta.data_ptr(), n, c, h * w, ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def gap(x, out=None):
+    _chk(x, _F32, "gap.x", 4)
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=_F32, device=x.device)
+    _lib.call("lf_gap_f32", x.data_ptr(), out.data_ptr(), n * c, h * w, _stream())
+    return out
+
+
+def bcast_planes(v, h, w, scale, out=None):
+    _chk(v, _F32, "bcast_planes.v", 2)
+    n, c = v.shape
+    if out is None:
+        out = torch.empty((n, c, h, w), dtype=_F32, device=v.device)
+    _lib.call("lf_bcast_planes_f32", v.data_ptr(), out.data_ptr(), n * c, h * w, float(scale),
+              _stream())
+    return out
+
+
+def se_fwd(m, w1, b1, w2, b2, z1, s):
+    n, c = m.shape
+    cr = w1.shape[1]
+    if tuple(w1.shape) != (c, cr) or tuple(w2.shape) != (cr, c) or tuple(z1.shape) != (n, cr) \
+            or tuple(s.shape) != (n, c):
+        raise ValueError("se_fwd: shape mismatch")
+    _lib.call("lf_se_fwd_f32", m.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+              b2.data_ptr(), z1.data_ptr(), s.data_ptr(), n, c, cr, _stream())
+    return s
+
+
+def se_bwd(ds, m, z1, s, w1, w2, dm, dw1, db1, dw2, db2):
+    n, c = m.shape
+    cr = w1.shape[1]
+    ws = _workspace(_lib.load().lf_se_bwd_workspace(n, c, cr), m.device)
+    _lib.call("lf_se_bwd_f32", ds.data_ptr(), m.data_ptr(), z1.data_ptr(), s.data_ptr(),
+              w1.data_ptr(), w2.data_ptr(), dm.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
+              dw2.data_ptr(), db2.data_ptr(), n, c, cr, ws.data_ptr(), ws.numel(), _stream())
+    return dm
+
+
+def block_tail_fwd(a, s, sc, sc_scale, sc_shift, drop, r, p):
+    _chk(a, _F32, "block_tail_fwd.a", 4)
+    n, c, h, w = a.shape
+    if sc.shape != a.shape or r.shape != a.shape or tuple(p.shape) != (n, c, h // 2, w // 2):
+        raise ValueError("block_tail_fwd: shape mismatch")
+    _lib.call("lf_block_tail_fwd_f32", a.data_ptr(), _ptr(s), sc.data_ptr(), _ptr(sc_scale),
+              _ptr(sc_shift), _ptr(drop), r.data_ptr(), p.data_ptr(), n, c, h, w, _stream())
+    return r, p
+
+
+def block_tail_bwd(dp, r, a, drop, dr, ds):
+    _chk(r, _F32, "block_tail_bwd.r", 4)
+    n, c, h, w = r.shape
+    if tuple(dp.shape) != (n, c, h // 2, w // 2) or dr.shape != r.shape:
+        raise ValueError("block_tail_bwd: shape mismatch")
+    _lib.call("lf_block_tail_bwd_f32", dp.data_ptr(), r.data_ptr(), _ptr(a), _ptr(drop),
+              dr.data_ptr(), _ptr(ds), n, c, h, w, _stream())
+    return dr, ds
+
+
+def head_fwd(feat, w, b, ytrue, probs, loss):
+    n, f = feat.shape
+    c = w.shape[1]
+    _lib.call("lf_head_fwd_f32", feat.data_ptr(), w.data_ptr(), b.data_ptr(), _ptr(ytrue),
+              probs.data_ptr(), _ptr(loss), n, f, c, _stream())
+    return probs
+
+
+def head_bwd(feat, w, probs, ytrue, dlogits, dfeat, dw, db, inv_n):
+    n, f = feat.shape
+    c = w.shape[1]
+    _lib.call("lf_head_bwd_f32", feat.data_ptr(), w.data_ptr(), probs.data_ptr(), ytrue.data_ptr(),
+              dlogits.data_ptr(), dfeat.data_ptr(), dw.data_ptr(), db.data_ptr(), n, f, c,
+              float(inv_n), _stream())
+
+
+def mul(a, b, out):
+    if a.shape != b.shape or out.shape != a.shape:
+        raise ValueError("mul: shape mismatch")
+    _lib.call("lf_mul_f32", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+    return out
+
+
+def adamw_step(param, grad, m, v, ema, offsets, l2, max_count, lr, step, beta1=0.9, beta2=0.999,
+               eps=1e-7, weight_decay=1e-4, clipnorm=0.5, ema_decay=0.999, ema_copy=False,
+               norms=None):
+    nt = offsets.numel() - 1
+    if norms is None:
+        norms = torch.empty(nt, dtype=_F32, device=param.device)
+    _lib.call("lf_adamw_step_f32", param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+              _ptr(ema), offsets.data_ptr(), l2.data_ptr(), nt, int(max_count), float(lr),
+              float(beta1), float(beta2), float(eps), float(weight_decay), float(clipnorm),
+              int(step), float(ema_decay), 1 if ema_copy else 0, norms.data_ptr(), _stream())
+    return norms
+
+
+def ema_update(ema, w, decay, copy):
+    _lib.call("lf_ema_update_f32", ema.data_ptr(), w.data_ptr(), w.numel(), float(decay),
+              1 if copy else 0, _stream())

@@ -1,0 +1,151 @@
+"""leaf_cnn forward / backward / optimizer on the GPU vs the torch-CPU fp32 oracle.
+
+Tolerances (fp32 everywhere, different summation orders): input stage 2e-4 absolute,
+probabilities 2e-5 absolute,
+loss 1e-5 relative, gradients 2e-3 of each tensor's max-abs (BatchNorm backward subtracts
+large means), parameters after AdamW steps 1e-5 absolute, label indices (argmax) exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cnn_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def make_model(cuda, widths, classes, img, seed=3, **kw):
+    from leaffliction_amd.model.cnn import LeafCNN
+    m = LeafCNN(num_classes=classes, img_size=img, widths=widths, l2_reg=1e-4, seed=seed, **kw)
+    ref_p = {name: m.p[name].detach().cpu().clone() for name, _s, _k in m.specs}
+    ref_s = R.init_state(widths)
+    return m, ref_p, ref_s
+
+
+def rel_err(got, ref):
+    return (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+
+
+@pytest.mark.parametrize("widths,img,n,classes", [([32, 64, 128, 256], 32, 6, 8),
+                                                  ([16, 32, 64], 24, 5, 2),
+                                                  ([32, 64, 128], 64, 3, 5)])
+def test_train_step_matches_oracle(cuda, widths, img, n, classes):
+    from leaffliction_amd import nn
+    m, ref_p, ref_s = make_model(cuda, widths, classes, img, use_norm=True)
+    g = torch.Generator().manual_seed(11)
+    x_u8 = torch.randint(0, 256, (n, img, img, 3), dtype=torch.uint8, generator=g)
+    labels = torch.randint(0, classes, (n,), generator=g)
+    y = R.smooth_labels(torch.nn.functional.one_hot(labels, classes).float(), 0.02)
+    m.norm.mean = np.array([0.45, 0.5, 0.4], np.float32)
+    m.norm.variance = np.array([0.05, 0.06, 0.04], np.float32)
+    mean, denom = m._norm_consts()
+    aug = m.draw_augmentation(n)
+    drops, top = m.draw_dropout(n)
+
+    # ---- GPU
+    x0 = nn.input_stage(x_u8.to(cuda), aug, mean, denom)
+    probs, loss = m.forward(x0, True, y.to(cuda), drops, top)
+    m.backward()
+    # ---- oracle
+    # input stage (bilinear rotate + contrast + normalisation): 2e-4 absolute on values in
+    # about [-2.5, 2.5]; the device fuses multiply-adds in the coordinate arithmetic
+    x0_ref = R.input_stage(x_u8, aug.cpu(), mean, denom)
+    assert (x0.cpu() - x0_ref).abs().max().item() < 2e-4
+    # the CNN comparison starts from the same x0 so that it measures the CNN alone
+    _tot, data_loss, probs_ref, grads = R.train_step(
+        ref_p, ref_s, x0.cpu(), torch.nn.functional.one_hot(labels, classes).float(), widths,
+        [d.cpu() for d in drops], top.cpu(), l2=1e-4, smoothing=0.02, grads_include_l2=False)
+    assert (probs.cpu() - probs_ref).abs().max().item() < 2e-5
+    assert torch.equal(probs.cpu().argmax(-1), probs_ref.argmax(-1))
+    assert abs(loss.mean().item() - data_loss) < 1e-5 * max(1.0, abs(data_loss))
+    for name, _s, _k in m.specs:
+        assert rel_err(m.g[name].cpu(), grads[name]) < 2e-3, name
+    for bn, _c in m.bn_layers:  # moving statistics updated identically
+        assert (m.s[bn + ".mean"].cpu() - ref_s[bn + ".mean"]).abs().max().item() < 1e-5
+        assert (m.s[bn + ".var"].cpu() - ref_s[bn + ".var"]).abs().max().item() < 1e-5
+
+
+def test_inference_and_label_indices(cuda):
+    widths, classes, img, n = [32, 64, 128, 256], 8, 32, 16
+    m, ref_p, ref_s = make_model(cuda, widths, classes, img, use_norm=False)
+    for bn, _c in m.bn_layers:  # non-trivial moving statistics
+        m.s[bn + ".mean"].normal_(0, 0.1)
+        m.s[bn + ".var"].uniform_(0.5, 1.5)
+        ref_s[bn + ".mean"] = m.s[bn + ".mean"].cpu().clone()
+        ref_s[bn + ".var"] = m.s[bn + ".var"].cpu().clone()
+    g = torch.Generator().manual_seed(2)
+    x_u8 = torch.randint(0, 256, (n, img, img, 3), dtype=torch.uint8, generator=g)
+    probs = m.predict(x_u8.numpy())
+    ref = R.forward(ref_p, ref_s, R.input_stage(x_u8, None), widths, False).numpy()
+    assert np.abs(probs - ref).max() < 2e-5
+    assert np.array_equal(probs.argmax(-1), ref.argmax(-1))
+    # the reference loader's float32 NHWC [0,1] format gives the same result as uint8
+    probs_f = m.predict(x_u8.numpy().astype(np.float32) / 255.0)
+    assert np.abs(probs_f - probs).max() < 1e-6
+
+
+def test_adamw_clipnorm_ema_matches_oracle(cuda):
+    """Three optimizer steps on synthetic gradients: per-tensor clip, decoupled decay, L2, EMA."""
+    from leaffliction_amd import nn
+    widths, classes = [16, 32], 3
+    m, ref_p, _ = make_model(cuda, widths, classes, 16)
+    mm = {k: torch.zeros_like(v) for k, v in ref_p.items()}
+    vv = {k: torch.zeros_like(v) for k, v in ref_p.items()}
+    ema = None
+    g = torch.Generator().manual_seed(4)
+    total = 10
+    for step in range(1, 4):
+        grads = {k: torch.randn(v.shape, generator=g) * (3.0 if "c1" in k else 0.01)
+                 for k, v in ref_p.items()}
+        for k in grads:
+            m.g[k].copy_(grads[k])
+        lr = R.cosine_lr(2e-3, step - 1, total)
+        m.opt_step = step
+        nn.adamw_step(m.flat_p, m.flat_g, m.flat_m, m.flat_v, m.flat_ema, m.offsets, m.l2_vec,
+                      m.max_count, lr, step, weight_decay=1e-4, clipnorm=0.5, ema_decay=0.999,
+                      ema_copy=(step == 1))
+        full = {k: grads[k] + (2e-4 * ref_p[k] if kind == "w3" else 0)
+                for (k, _s, kind) in m.specs}
+        ref_p, mm, vv = R.adamw_step(ref_p, full, mm, vv, step, lr)
+        ema = {k: v.clone() for k, v in ref_p.items()} if ema is None else \
+            {k: 0.999 * ema[k] + 0.001 * ref_p[k] for k in ref_p}
+    for name, _s, _k in m.specs:
+        assert (m.p[name].cpu() - ref_p[name]).abs().max().item() < 1e-5, name
+    b, e = 0, m.p["stem.w"].numel()
+    assert (m.flat_ema[b:e].cpu().view(m.p["stem.w"].shape) - ema["stem.w"]).abs().max() < 1e-6
+
+
+def test_cosine_schedule_known_answers():
+    assert R.cosine_lr(2e-3, 0, 100) == pytest.approx(2e-3)
+    assert R.cosine_lr(2e-3, 50, 100) == pytest.approx(1e-3)
+    assert R.cosine_lr(2e-3, 100, 100) == pytest.approx(0.0, abs=1e-12)
+    assert R.cosine_lr(2e-3, 500, 100) == pytest.approx(0.0, abs=1e-12)
+
+
+def test_training_reduces_loss_and_weights_roundtrip(cuda, tmp_path):
+    """A few real steps: loss goes down on a memorisable batch; save/load/get/set weights."""
+    from leaffliction_amd.model.cnn import load_model
+    widths, classes, img, n = [16, 32, 64], 4, 32, 32
+    m, _, _ = make_model(cuda, widths, classes, img, use_norm=True, augment=False)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(0, 256, (n, img, img, 3), dtype=torch.uint8, generator=g)
+    labels = torch.arange(n) % classes
+    for i in range(n):  # make classes separable: brighten one channel block per class
+        x[i, :, :, int(labels[i]) % 3] //= 4
+    y = R.smooth_labels(torch.nn.functional.one_hot(labels, classes).float(), 0.02).to(cuda)
+    m.drop_block = m.drop_top = 0.0
+    losses = []
+    for step in range(30):
+        _p, loss = m.train_step(x, y, lr=3e-3)
+        losses.append(loss.mean().item())
+    assert losses[-1] < 0.5 * losses[0], losses[::5]
+    probs = m.predict(x.numpy())
+    m.save(tmp_path / "leaf_cnn.keras")
+    m2 = load_model(tmp_path / "leaf_cnn.keras")
+    assert np.array_equal(m2.predict(x.numpy()), probs)
+    w = m.get_weights()
+    assert w[2].shape == (3, 3, 3, 16)  # keras HWIO stem kernel after the two norm arrays
+    m2.set_weights(m.ema_weights())
+    assert np.abs(m2.predict(x.numpy()) - probs).max() < 0.5
