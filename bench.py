@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leaf_cnn training images/sec on MI355X (BASELINE.json config C2).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full training step of the reference's `srcs/cli/train.py` path on one
+per-GPU batch of synthetic input that is already resident in HBM: fused input stage
+(uint8 HWC -> augment -> Normalization -> f32 NCHW), leaf_cnn `base` forward, label-smoothed
+cross-entropy, backward, (N>1: one RCCL all-reduce of the flat gradient bucket), AdamW with
+per-tensor clipnorm + cosine LR, EMA.  fp32 throughout (BASELINE.json configs[1]); weak
+scaling: every rank keeps batch 256.
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel,
+algorithmic FLOP / measured launch duration from HIP events recorded inside the timed
+region) and `cpu_baseline` (the torch-CPU oracle's training step on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from collections import defaultdict
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WIDTHS = [32, 64, 128, 256]
+NUM_CLASSES = 8
+IMG = 224
+BATCH = 256
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+TRAIN_GFLOP_PER_IMG = 18.757  # 3 x 3.126 GMAC x 2
+
+FWD_NAMES = {0: "conv_mfma_kernel<T,32,8,1,1,4,2>", 1: "conv_mfma_kernel<T,32,8,1,2,4,2>",
+             2: "conv_mfma_kernel<T,16,16,1,1,4,2>", 3: "conv_mfma_kernel<T,16,16,1,2,4,2>",
+             4: "conv_mfma_kernel<T,28,8,4,1,1,7>", 5: "conv_mfma_kernel<T,32,8,2,2,2,4>"}
+WG_NAMES = {0: "wgrad_mfma_kernel<T,32,4,1,1,4>", 1: "wgrad_mfma_kernel<T,16,8,1,2,2>",
+            2: "wgrad_mfma_kernel<T,16,4,2,2,1>", 3: "wgrad_mfma_kernel<T,28,2,2,2,1>",
+            4: "wgrad_mfma_kernel<T,32,4,1,2,2>"}
+
+
+class KernelTimer:
+    """HIP events around the conv launches, on the stream they are launched on."""
+
+    def __init__(self, lib_mod):
+        self.lib_mod = lib_mod
+        self.records = []
+        self.enabled = False
+        self._orig = lib_mod.call
+
+    def install(self):
+        timer = self
+
+        def call(name, *args):
+            if not timer.enabled or name not in ("lf_conv2d_f32", "lf_conv2d_wgrad_f32"):
+                return timer._orig(name, *args)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = timer._orig(name, *args)
+            e1.record()
+            lib = timer.lib_mod.load()
+            if name == "lf_conv2d_f32":
+                n, cin, h, w, cout, k = args[3:9]
+                kname = FWD_NAMES[lib.lf_conv2d_variant(h, w, cout)].replace("T", str(k * k))
+            else:
+                n, cin, h, w, cout, k = args[2:8]
+                kname = WG_NAMES[lib.lf_conv2d_wgrad_variant(n, cin, h, w, cout)].replace("T", str(k * k))
+            flop = 2.0 * n * h * w * cin * cout * k * k
+            timer.records.append((kname, flop, e0, e1))
+            return rc
+
+        self.lib_mod.call = call
+        # nn.py / ops.py bound `_lib` as a module, so patching the attribute is enough
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = defaultdict(lambda: [0.0, 0.0, 0])
+        for kname, flop, e0, e1 in self.records:
+            a = agg[kname]
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flop
+            a[2] += 1
+        return {k: {"seconds": v[0], "flop": v[1], "launches": v[2]} for k, v in agg.items()}
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """The oracle (torch CPU fp32 restatement of the reference's Keras train step) timed on
+    this box's host cores: base preset, img 224, batch 32 (the reference default, train.py:67)."""
+    from oracle import cnn_ref as R
+    threads = torch.get_num_threads()
+    bs = 32
+    params = R.init_params(NUM_CLASSES, WIDTHS, seed=0)
+    state = R.init_state(WIDTHS)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((bs, 3, IMG, IMG), generator=g)
+    y = torch.nn.functional.one_hot(torch.randint(0, NUM_CLASSES, (bs,), generator=g), NUM_CLASSES).float()
+    drops = [torch.ones(bs, f) for f in WIDTHS]
+    top = torch.ones(bs, WIDTHS[-1])
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(v_) for k, v_ in params.items()}
+    steps, t_used = 0, 0.0
+    R.train_step(params, state, x, y, WIDTHS, drops, top)  # warm-up (allocations, threads)
+    while steps < 1 or (t_used < seconds_budget and steps < 8):
+        t0 = time.perf_counter()
+        _l, _d, _p, grads = R.train_step(params, state, x, y, WIDTHS, drops, top)
+        params, m, v = R.adamw_step(params, grads, m, v, steps + 1, 2e-3)
+        t_used += time.perf_counter() - t0
+        steps += 1
+    return {"value": round(bs * steps / t_used, 2), "unit": "images/sec", "cores": threads,
+            "kind": "port",
+            "sample": f"{steps} training steps of leaf_cnn base at 224x224, batch {bs}, fp32 "
+                      f"(oracle/cnn_ref.py on torch CPU, {threads} threads)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
+                     "(--nproc-per-node N --master-addr 127.0.0.1)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from leaffliction_amd import _lib
+    from leaffliction_amd.model.cnn import LeafCNN
+    _lib.load()
+    timer = KernelTimer(_lib)
+    timer.install()
+
+    model = LeafCNN(num_classes=NUM_CLASSES, img_size=IMG, widths=WIDTHS, drop_block=0.15,
+                    drop_top=0.40, l2_reg=1e-4, augment=True, use_se=True, seed=42, device=dev)
+    model.norm.mean[:] = 0.5       # statistics of the synthetic uniform data
+    model.norm.variance[:] = 1.0 / 12.0
+    if world > 1:  # identical replicas
+        dist.broadcast(model.flat_p, 0)
+    gen = torch.Generator().manual_seed(42 + rank)
+    n = args.batch
+    x = torch.randint(0, 256, (n, IMG, IMG, 3), dtype=torch.uint8, generator=gen).to(dev)
+    labels = torch.randint(0, NUM_CLASSES, (n,), generator=gen)
+    y = (torch.nn.functional.one_hot(labels, NUM_CLASSES).float() * (1 - 0.02) + 0.02 / NUM_CLASSES).to(dev)
+
+    total = args.warmup + args.steps
+    grad_sync = None
+    if world > 1:
+        def grad_sync(flat_g):  # one flat bucket, averaged over ranks (RCCL over xGMI)
+            dist.all_reduce(flat_g, op=dist.ReduceOp.AVG)
+
+    def lr_at(step):
+        return 2e-3 * 0.5 * (1.0 + math.cos(math.pi * min(step, total) / total))
+
+    step = 0
+    for _ in range(args.warmup):
+        model.train_step(x, y, lr_at(step), grad_sync=grad_sync)
+        step += 1
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _probs, loss = model.train_step(x, y, lr_at(step), grad_sync=grad_sync)
+        step += 1
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.mean())
+    if not math.isfinite(final_loss):
+        sys.exit(f"bench.py: non-finite loss {final_loss}")
+
+    if rank == 0:
+        kern = timer.summary()
+        dom_name, dom = max(kern.items(), key=lambda kv: kv[1]["seconds"])
+        achieved = dom["flop"] / dom["seconds"] / 1e12
+        conv_s = sum(v["seconds"] for v in kern.values())
+        conv_f = sum(v["flop"] for v in kern.values())
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_latest.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get(dom_name)
+            except Exception:
+                traffic = None
+        images = world * n * args.steps
+        out = {
+            "metric": "224x224 images/sec train",
+            "value": round(images / elapsed, 2),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "leaf_cnn base train step (configs[1]: img 224, batch 256/GPU, "
+                                   "fp32, 8 classes, AdamW+clipnorm+EMA, in-model augmentation)",
+                       "per_gpu_batch": n, "global_batch": world * n, "img_size": IMG,
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": dom_name,
+                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": traffic,
+                         "launches_per_step": dom["launches"] / args.steps,
+                         "avg_launch_ms": round(dom["seconds"] / dom["launches"] * 1e3, 4),
+                         "algorithmic_gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3)},
+            "conv_all": {"tflops": round(conv_f / conv_s / 1e12, 2),
+                         "frac_of_mfma_peak": round(conv_f / conv_s / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                         "share_of_step_time": round(conv_s / elapsed, 4)},
+            "step_tflops": round(TRAIN_GFLOP_PER_IMG * n * args.steps / elapsed / 1e3, 2),
+            "final_loss": round(final_loss, 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,10 +40,13 @@ SIGNATURES = {
     "lf_resample_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int,
                        c_int, P],
     "lf_conv2d_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P],
+    "lf_conv2d_variant": [c_int, c_int, c_int],
+    "lf_conv2d_wgrad_variant": [c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_dgrad_weights_f32": [P, P, c_int, c_int, c_int, P],
     "lf_conv2d_wgrad_workspace": [c_int, c_int, c_int, c_int, c_int, c_int],
-    "lf_conv2d_wgrad_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int,
-                            c_float, P, c_size_t, P],
+    "lf_conv2d_wgrad_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,
+                            c_size_t, P],
+    "lf_conv2d_wgrad_reduce_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P],
     "lf_input_stage_f32": [P, P, c_int, c_int, c_int, P, P, P, P, P],
     "lf_scale_shift_act_f32": [P, P, c_int, c_int, c_int, P, P, c_int, P],
     "lf_bn_workspace": [c_int],

@@ -434,6 +434,8 @@ WgPlan plan_wgrad(int n, int cin, int cout, int h, int w) {
 
 extern "C" {
 
+int lf_conv2d_variant(int h, int wd, int cout);
+
 int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
                   int ksize, const float* in_scale, const float* in_shift, int in_relu,
                   int accumulate, lf_stream_t stream) {
@@ -444,15 +446,7 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
     LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr),
                "lf_conv2d: in_scale/in_shift must both be set");
     LF_REQUIRE(n <= 65535, "lf_conv2d: batch too large for grid.z");
-    int best = 0;
-    long long bw = -1;
-    for (int v = 0; v < kNumFwd; ++v) {
-        const long long c = padded_work(kFwdVariants[v], h, wd, cout);
-        if (bw < 0 || c < bw) {
-            bw = c;
-            best = v;
-        }
-    }
+    const int best = lf_conv2d_variant(h, wd, cout);
     const FwdVariant& v = kFwdVariants[best];
     ConvArgs a;
     a.x = x; a.w = w; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
@@ -466,6 +460,24 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
     const int rc = ksize == 3 ? launch_fwd<9>(best, a, grid, s) : launch_fwd<1>(best, a, grid, s);
     if (rc != LF_OK) return rc;
     return lf::check_launch("lf_conv2d");
+}
+
+int lf_conv2d_variant(int h, int wd, int cout) {
+    int best = 0;
+    long long bw = -1;
+    for (int v = 0; v < kNumFwd; ++v) {
+        const long long c = padded_work(kFwdVariants[v], h, wd, cout);
+        if (bw < 0 || c < bw) {
+            bw = c;
+            best = v;
+        }
+    }
+    return best;
+}
+
+int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout) {
+    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || wd <= 0) return -1;
+    return plan_wgrad(n, cin, cout, h, wd).variant;
 }
 
 int lf_conv2d_dgrad_weights_f32(const float* w, float* wt, int cin, int ksize, int cout,
@@ -484,11 +496,10 @@ size_t lf_conv2d_wgrad_workspace(int n, int cin, int h, int wd, int cout, int ks
     return (size_t)pl.slabs * cin * ksize * ksize * cout * sizeof(float);
 }
 
-int lf_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int n, int cin, int h, int wd,
-                        int cout, int ksize, const float* in_scale, const float* in_shift,
-                        int in_relu, float beta, void* workspace, size_t ws_bytes,
-                        lf_stream_t stream) {
-    LF_REQUIRE(x && dy && dw && workspace, "lf_conv2d_wgrad: null buffer");
+int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, int wd, int cout,
+                        int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                        void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(x && dy && workspace, "lf_conv2d_wgrad: null buffer");
     LF_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && wd > 0,
                "lf_conv2d_wgrad: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, wd);
     LF_REQUIRE(ksize == 3 || ksize == 1, "lf_conv2d_wgrad: ksize must be 1 or 3 (got %d)", ksize);
@@ -513,11 +524,19 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int n, int c
     const int rc = ksize == 3 ? launch_wgrad<9>(pl.variant, a, grid, s)
                               : launch_wgrad<1>(pl.variant, a, grid, s);
     if (rc != LF_OK) return rc;
-    int e = lf::check_launch("lf_conv2d_wgrad");
-    if (e != LF_OK) return e;
-    slab_reduce_kernel<<<lf::stream_grid(count, kThreads), kThreads, 0, s>>>(a.part, dw, count,
-                                                                          pl.slabs, beta);
-    return lf::check_launch("lf_conv2d_wgrad(reduce)");
+    return lf::check_launch("lf_conv2d_wgrad");
+}
+
+int lf_conv2d_wgrad_reduce_f32(const void* workspace, float* dw, int n, int cin, int h, int wd,
+                               int cout, int ksize, float beta, lf_stream_t stream) {
+    LF_REQUIRE(workspace && dw, "lf_conv2d_wgrad_reduce: null buffer");
+    LF_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && wd > 0 && (ksize == 1 || ksize == 3),
+               "lf_conv2d_wgrad_reduce: bad dims");
+    const WgPlan pl = plan_wgrad(n, cin, cout, h, wd);
+    const size_t count = (size_t)cin * ksize * ksize * cout;
+    slab_reduce_kernel<<<lf::stream_grid(count, kThreads), kThreads, 0, lf::as_stream(stream)>>>(
+        static_cast<const float*>(workspace), dw, count, pl.slabs, beta);
+    return lf::check_launch("lf_conv2d_wgrad_reduce");
 }
 
 }  // extern "C"

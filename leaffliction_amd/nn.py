@@ -89,9 +89,11 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, in_scale=None, i
             raise ValueError("wgrad.out: shape mismatch")
     nbytes = _lib.load().lf_conv2d_wgrad_workspace(n, cin, h, w, cout, ksize)
     ws = _workspace(nbytes, x.device)
-    _lib.call("lf_conv2d_wgrad_f32", x.data_ptr(), dy.data_ptr(), out.data_ptr(), n, cin, h, w,
-              cout, ksize, _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, float(beta),
-              ws.data_ptr(), ws.numel(), _stream())
+    _lib.call("lf_conv2d_wgrad_f32", x.data_ptr(), dy.data_ptr(), n, cin, h, w, cout, ksize,
+              _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, ws.data_ptr(), ws.numel(),
+              _stream())
+    _lib.call("lf_conv2d_wgrad_reduce_f32", ws.data_ptr(), out.data_ptr(), n, cin, h, w, cout,
+              ksize, float(beta), _stream())
     return out
 
 
