@@ -81,6 +81,11 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 and libleafhip.so
+    # depends on the same SONAME, so whichever is loaded first serves both.  Import torch
+    # first, otherwise the system runtime gets loaded here and torch's device pointers and
+    # streams (owned by the other runtime instance) are invalid inside the library.
+    import torch  # noqa: F401
     path = Path(os.environ.get("LEAFHIP_LIB", LIB_PATH))
     if not path.exists():
         raise LeafHipError(
