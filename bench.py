@@ -43,7 +43,7 @@ FWD_NAMES = {0: "conv_mfma_kernel<T,32,8,1,1,4,2>", 1: "conv_mfma_kernel<T,32,8,
              4: "conv_mfma_kernel<T,28,8,4,1,1,7>", 5: "conv_mfma_kernel<T,32,8,2,2,2,4>"}
 WG_NAMES = {0: "wgrad_mfma_kernel<T,32,4,1,1,4>", 1: "wgrad_mfma_kernel<T,16,8,1,2,2>",
             2: "wgrad_mfma_kernel<T,16,4,2,2,1>", 3: "wgrad_mfma_kernel<T,28,2,2,2,1>",
-            4: "wgrad_mfma_kernel<T,32,4,1,2,2>"}
+            4: "wgrad_mfma_kernel<T,32,4,1,2,2>", 5: "wgrad_smallcin_kernel<32,8>"}
 
 
 class KernelTimer:
@@ -72,7 +72,7 @@ class KernelTimer:
                 kname = FWD_NAMES[lib.lf_conv2d_variant(h, w, cout)].replace("T", str(k * k))
             else:
                 n, cin, h, w, cout, k = args[2:8]
-                kname = WG_NAMES[lib.lf_conv2d_wgrad_variant(n, cin, h, w, cout)].replace("T", str(k * k))
+                kname = WG_NAMES[lib.lf_conv2d_wgrad_variant(n, cin, h, w, cout, k)].replace("T", str(k * k))
             flop = 2.0 * n * h * w * cin * cout * k * k
             timer.records.append((kname, flop, e0, e1))
             return rc

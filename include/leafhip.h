@@ -173,7 +173,7 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
 /* Which tile variant (template instantiation) the dispatcher picks for a shape — used by
  * bench.py to attribute measured launch durations to kernel names. */
 int lf_conv2d_variant(int h, int wd, int cout);
-int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout);
+int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout, int ksize);
 
 /* w [Cin][k*k][Cout] -> wt [Cout][k*k (flipped)][Cin]: the weights with which
  * lf_conv2d_f32(dy, wt, dx, n, cout, h, w, cin, k, ...) is the input gradient. */
@@ -181,15 +181,15 @@ int lf_conv2d_dgrad_weights_f32(const float* w, float* wt, int cin, int ksize, i
                                 lf_stream_t stream);
 
 /* Weight gradient dw[ci][tap][co] = sum_{n,y,x} x'[n][ci][y+ky-1][x+kx-1] * dy[n][co][y][x]
- * (x' = optional prologue as above) in two launches: lf_conv2d_wgrad_f32 writes per-wave
- * partial slabs into a workspace of lf_conv2d_wgrad_workspace(...) bytes;
- * lf_conv2d_wgrad_reduce_f32 sums them in a fixed order: dw = beta*dw + sum (deterministic,
- * no float atomics). */
+ * (x' = optional prologue as above) in two steps: lf_conv2d_wgrad_f32 writes one partial
+ * slab per workgroup into a workspace of lf_conv2d_wgrad_workspace(...) bytes;
+ * lf_conv2d_wgrad_reduce_f32 sums them in a fixed order (two-stage when there are many):
+ * dw = beta*dw + sum (deterministic, no float atomics; the workspace tail is scratch). */
 size_t lf_conv2d_wgrad_workspace(int n, int cin, int h, int wd, int cout, int ksize);
 int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, int wd, int cout,
                         int ksize, const float* in_scale, const float* in_shift, int in_relu,
                         void* workspace, size_t ws_bytes, lf_stream_t stream);
-int lf_conv2d_wgrad_reduce_f32(const void* workspace, float* dw, int n, int cin, int h, int wd,
+int lf_conv2d_wgrad_reduce_f32(void* workspace, float* dw, int n, int cin, int h, int wd,
                                int cout, int ksize, float beta, lf_stream_t stream);
 
 /* ---- input stage ----------------------------------------------------------- */

@@ -41,7 +41,7 @@ SIGNATURES = {
                        c_int, P],
     "lf_conv2d_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P],
     "lf_conv2d_variant": [c_int, c_int, c_int],
-    "lf_conv2d_wgrad_variant": [c_int, c_int, c_int, c_int, c_int],
+    "lf_conv2d_wgrad_variant": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_dgrad_weights_f32": [P, P, c_int, c_int, c_int, P],
     "lf_conv2d_wgrad_workspace": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_wgrad_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,

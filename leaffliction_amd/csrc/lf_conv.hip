@@ -11,15 +11,21 @@
 //   NCHW store is 128-byte contiguous per half-wave.
 //   A workgroup (4 waves) owns a TWxTH pixel tile (flat-indexed 32-pixel blocks, so tile
 //   shapes like 28x8 work) x CT output channels; the input patch (+halo) and the weight
-//   slice for KC input channels are staged in LDS per K-chunk; several workgroups are
-//   resident per CU (2-4 waves per SIMD) so one workgroup's staging overlaps another's MFMAs.
+//   slice for KC input channels are staged in LDS per K-chunk.  Staging uses 16-byte
+//   loads (row interiors and weight rows) with every load of a chunk in flight at once, and
+//   the NEXT chunk's loads are issued into registers before the current chunk's MFMAs
+//   (a bounded register prefetch: <= 13 float4 per thread); 2-4 workgroups are resident per
+//   CU so one workgroup's LDS write phase overlaps another's MFMAs.
 //   An optional prologue applies y = relu(x*scale[c]+shift[c]) to the input while staging
 //   (BatchNorm+ReLU of the producer fused into the consumer; zero padding stays zero).
 //
 // wgrad kernel (wgrad_mfma_kernel): dW[ci][tap][co] = sum_pixels X[ci][p+tap] dY[co][p],
-//   K = pixels, split across workgroups (and across the waves of a workgroup); every wave
-//   writes a partial slab to a workspace and a reduce kernel sums the slabs in a fixed order
-//   (deterministic, no float atomics).
+//   K = pixels, split across workgroups and across the waves of a workgroup (reduced through
+//   LDS); every workgroup writes one partial slab and a two-stage reduce sums the slabs in a
+//   fixed order (deterministic, no float atomics).  wgrad_smallcin_kernel packs (ci, tap)
+//   into the MFMA's M dimension for the stem (Cin*9 <= 32): one MFMA per pixel pair.
+#include <type_traits>
+
 #include "lf_common.h"
 
 namespace {
@@ -29,9 +35,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kThreads = 256;
 constexpr int kKC = 8;  // input channels per K-chunk
 
+__device__ __forceinline__ float pro_apply(float v, float sc, float sh, int relu) {
+    v = fmaf(v, sc, sh);
+    return relu ? fmaxf(v, 0.f) : v;
+}
+
 struct ConvArgs {
     const float* x;
-    const float* w;      // [Cin][TAPS][Cout]
+    const float* w;  // [Cin][TAPS][Cout]
     float* y;
     const float* in_scale;  // optional prologue (nullptr = none)
     const float* in_shift;
@@ -39,6 +50,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;
     int in_relu;
     int accumulate;  // y += conv(...) instead of y = conv(...)
+    int vec_ok;      // W % 4 == 0, Cout % 4 == 0, 16-byte aligned bases
 };
 
 // ---------------------------------------------------------------------------
@@ -46,20 +58,25 @@ struct ConvArgs {
 // ---------------------------------------------------------------------------
 // TAPS: 9 (3x3) or 1 (1x1).  Tile TW x TH pixels = NPB blocks of 32 (flat index).
 // Waves: WCO x WPX = 4; each wave computes MB cout-blocks x NB pixel-blocks.
-// min waves/SIMD asked of the register allocator: accumulators (AGPRs) + VGPRs share one
-// 512-entry file per SIMD lane, so <=64 accumulators leave room for 3 waves, more for 2.
+// min waves/SIMD asked of the register allocator: accumulators + VGPRs share one 512-entry
+// file per SIMD lane; with the prefetch registers <=32 accumulators fit 3 waves, more fit 2.
 template <int TAPS, int TW, int TH, int WCO, int MB, int WPX, int NB>
-__global__ __launch_bounds__(kThreads, (MB * NB * 16 <= 32 ? 4 : (MB * NB * 16 <= 64 ? 3 : 2))) void conv_mfma_kernel(ConvArgs p) {
+__global__ __launch_bounds__(kThreads, (MB * NB * 16 <= 32 ? 3 : 2))
+void conv_mfma_kernel(ConvArgs p) {
     constexpr int NPB = TW * TH / 32;
-    static_assert(TW * TH % 32 == 0, "tile must be whole 32-pixel blocks");
+    static_assert(TW * TH % 32 == 0 && TW % 4 == 0, "tile must be whole 32-pixel blocks, TW % 4 == 0");
     static_assert(WCO * WPX == 4 && WPX * NB == NPB, "wave decomposition");
     constexpr int CT = 32 * WCO * MB;
     constexpr int HALO = TAPS == 9 ? 1 : 0;
     constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO, PP = PW * PH;
     constexpr int PATCH = kKC * PP;
     constexpr int WSZ = kKC * TAPS * CT;
+    // vector staging: per patch row TW/4 float4 interior items + 2 halo scalars
+    constexpr int TW4 = TW / 4, VROW = TW4 + 2 * HALO;
+    constexpr int NPI = kKC * PH * VROW, IPT = (NPI + kThreads - 1) / kThreads;
+    constexpr int CT4 = CT / 4, NWI = kKC * TAPS * CT4, WPT = (NWI + kThreads - 1) / kThreads;
 
-    __shared__ float lds[PATCH + WSZ];
+    __shared__ __attribute__((aligned(16))) float lds[PATCH + WSZ];
     float* lp = lds;
     float* lw = lds + PATCH;
 
@@ -70,6 +87,7 @@ __global__ __launch_bounds__(kThreads, (MB * NB * 16 <= 32 ? 4 : (MB * NB * 16 <
     const int co0 = blockIdx.y * CT;
     const int n = blockIdx.z;
     const size_t hw = (size_t)p.h * p.wd;
+    const unsigned uhw = (unsigned)hw;
     const float* xin = p.x + (size_t)n * p.cin * hw;
 
     // per-lane LDS read bases
@@ -91,64 +109,8 @@ __global__ __launch_bounds__(kThreads, (MB * NB * 16 <= 32 ? 4 : (MB * NB * 16 <
             for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
 
     const bool pro = p.in_scale != nullptr;
-    const unsigned uhw = (unsigned)hw;
 
-    // Staging map: a thread owns one patch position (two when the patch has more than 256)
-    // and walks the chunk's channels, so the position -> (row, col, bounds, global offset)
-    // arithmetic is done once per kernel and every load is base + c*H*W.
-    constexpr int SLOTS = PP <= 64 ? 64 : (PP <= 128 ? 128 : 256);
-    constexpr int G = kThreads / SLOTS;
-    constexpr int ROUNDS = (PP + SLOTS - 1) / SLOTS;
-    const int slot = tid % SLOTS, grp = tid / SLOTS;
-    unsigned goff[ROUNDS];
-    bool inb[ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int pos = slot + r * SLOTS;
-        const int py = pos / PW, px = pos - py * PW;
-        const int gy = ty0 + py - HALO, gx = tx0 + px - HALO;
-        inb[r] = pos < PP && gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd;
-        goff[r] = inb[r] ? (unsigned)gy * (unsigned)p.wd + (unsigned)gx : 0u;
-    }
-    constexpr int WROWS = kKC * TAPS, RPP = kThreads / CT;
-    const int wcol = tid % CT, wrow0 = tid / CT;
-    const bool wcol_ok = co0 + wcol < p.cout;
-
-    auto stage_chunk = [&](int c0) {
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int pos = slot + r * SLOTS;
-            if (pos < PP) {
-#pragma unroll 4
-                for (int kc = grp; kc < kKC; kc += G) {
-                    const int c = c0 + kc;
-                    float v = 0.f;
-                    if (inb[r] && c < p.cin) {
-                        v = xin[(unsigned)c * uhw + goff[r]];
-                        if (pro) {
-                            v = fmaf(v, p.in_scale[c], p.in_shift[c]);
-                            if (p.in_relu) v = fmaxf(v, 0.f);
-                        }
-                    }
-                    lp[kc * PP + pos] = v;
-                }
-            }
-        }
-        const int wvalid = (p.cin - c0) * TAPS;  // rows of this chunk that exist
-#pragma unroll 4
-        for (int row = wrow0; row < WROWS; row += RPP) {
-            float v = 0.f;
-            if (wcol_ok && row < wvalid)
-                v = p.w[((unsigned)c0 * TAPS + row) * (unsigned)p.cout + (unsigned)(co0 + wcol)];
-            lw[row * CT + wcol] = v;
-        }
-    };
-
-    const int nchunks = (p.cin + kKC - 1) / kKC;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();  // previous chunk's LDS reads are done
-        stage_chunk(ch * kKC);
-        __syncthreads();
+    auto compute_chunk = [&]() {
 #pragma unroll
         for (int cp = 0; cp < kKC / 2; ++cp) {
 #pragma unroll
@@ -166,6 +128,152 @@ __global__ __launch_bounds__(kThreads, (MB * NB * 16 <= 32 ? 4 : (MB * NB * 16 <
                         acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[nb], acc[m][nb], 0,
                                                                           0, 0);
             }
+        }
+    };
+
+    const int nchunks = (p.cin + kKC - 1) / kKC;
+    const bool vec = p.vec_ok && (tx0 + TW <= p.wd);  // uniform per workgroup
+
+    if (vec) {
+        // ---------------- vector staging with register prefetch ----------------
+        float4 pv[IPT];
+        float4 wv[WPT];
+        unsigned okmask = 0;  // bit i: patch item i holds real (in-image) data
+        // variants with > 64 accumulators have no registers left to hold the weight prefetch:
+        // they prefetch the patch only and fetch the (L2-resident) weights in the store phase
+        constexpr bool kPrefetchW = MB * NB * 16 <= 64;
+        auto load_patch = [&](int c0) {
+            okmask = 0;
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int e = tid + i * kThreads;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NPI) {
+                    const int kc = e / (PH * VROW), rem = e - kc * (PH * VROW);
+                    const int py = rem / VROW, slot = rem - py * VROW;
+                    const int c = c0 + kc, gy = ty0 + py - HALO;
+                    if (c < p.cin && gy >= 0 && gy < p.h) {
+                        const float* row = xin + (unsigned)c * uhw + (unsigned)gy * (unsigned)p.wd;
+                        if (slot < TW4) {
+                            v = *reinterpret_cast<const float4*>(row + tx0 + 4 * slot);
+                            okmask |= 1u << i;
+                        } else {
+                            const int gx = slot == TW4 ? tx0 - 1 : tx0 + TW;
+                            if (gx >= 0 && gx < p.wd) {
+                                v.x = row[gx];
+                                okmask |= 1u << i;
+                            }
+                        }
+                    }
+                }
+                pv[i] = v;
+            }
+        };
+        auto load_weights = [&](int c0) {
+            const int wvalid = (p.cin - c0) * TAPS;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int e = tid + i * kThreads;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NWI) {
+                    const int row = e / CT4, col = (e - row * CT4) * 4;
+                    if (row < wvalid && co0 + col < p.cout)
+                        v = *reinterpret_cast<const float4*>(
+                            p.w + ((unsigned)c0 * TAPS + row) * (unsigned)p.cout + (unsigned)(co0 + col));
+                }
+                wv[i] = v;
+            }
+        };
+        auto store_chunk = [&](int c0) {
+            if (!kPrefetchW) load_weights(c0);
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int e = tid + i * kThreads;
+                if (e < NPI) {
+                    const int kc = e / (PH * VROW), rem = e - kc * (PH * VROW);
+                    const int py = rem / VROW, slot = rem - py * VROW;
+                    float4 v = pv[i];
+                    if (pro && (okmask >> i & 1u)) {
+                        const float sc = p.in_scale[c0 + kc], sh = p.in_shift[c0 + kc];
+                        v.x = pro_apply(v.x, sc, sh, p.in_relu);
+                        v.y = pro_apply(v.y, sc, sh, p.in_relu);
+                        v.z = pro_apply(v.z, sc, sh, p.in_relu);
+                        v.w = pro_apply(v.w, sc, sh, p.in_relu);
+                    }
+                    float* dst = lp + kc * PP + py * PW;
+                    if (slot < TW4) {
+                        dst += HALO + 4 * slot;
+                        dst[0] = v.x;
+                        dst[1] = v.y;
+                        dst[2] = v.z;
+                        dst[3] = v.w;
+                    } else {
+                        dst[slot == TW4 ? 0 : PW - 1] = v.x;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int e = tid + i * kThreads;
+                if (e < NWI) reinterpret_cast<float4*>(lw)[e] = wv[i];  // lw[row*CT + col]
+            }
+        };
+        load_patch(0);
+        if (kPrefetchW) load_weights(0);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();  // previous chunk's LDS reads are done
+            store_chunk(ch * kKC);
+            __syncthreads();
+            if (ch + 1 < nchunks) {  // in flight during the MFMAs
+                load_patch((ch + 1) * kKC);
+                if (kPrefetchW) load_weights((ch + 1) * kKC);
+            }
+            compute_chunk();
+        }
+    } else {
+        // ---------------- scalar staging (ragged shapes / partial tiles) ----------------
+        // a thread owns one patch position (two when the patch has more than 256) and walks
+        // the chunk's channels: every load is base + c*H*W
+        constexpr int SLOTS = PP <= 64 ? 64 : (PP <= 128 ? 128 : 256);
+        constexpr int G = kThreads / SLOTS;
+        constexpr int ROUNDS = (PP + SLOTS - 1) / SLOTS;
+        const int slot = tid % SLOTS, grp = tid / SLOTS;
+        constexpr int WROWS = kKC * TAPS, RPP = kThreads / CT;
+        const int wcol = tid % CT, wrow0 = tid / CT;
+        const bool wcol_ok = co0 + wcol < p.cout;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int c0 = ch * kKC;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int pos = slot + r * SLOTS;
+                if (pos < PP) {
+                    const int py = pos / PW, px = pos - py * PW;
+                    const int gy = ty0 + py - HALO, gx = tx0 + px - HALO;
+                    const bool inb = gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd;
+                    const unsigned goff = inb ? (unsigned)gy * (unsigned)p.wd + (unsigned)gx : 0u;
+#pragma unroll 4
+                    for (int kc = grp; kc < kKC; kc += G) {
+                        const int c = c0 + kc;
+                        float v = 0.f;
+                        if (inb && c < p.cin) {
+                            v = xin[(unsigned)c * uhw + goff];
+                            if (pro) v = pro_apply(v, p.in_scale[c], p.in_shift[c], p.in_relu);
+                        }
+                        lp[kc * PP + pos] = v;
+                    }
+                }
+            }
+            const int wvalid = (p.cin - c0) * TAPS;
+#pragma unroll 4
+            for (int row = wrow0; row < WROWS; row += RPP) {
+                float v = 0.f;
+                if (wcol_ok && row < wvalid)
+                    v = p.w[((unsigned)c0 * TAPS + row) * (unsigned)p.cout + (unsigned)(co0 + wcol)];
+                lw[row * CT + wcol] = v;
+            }
+            __syncthreads();
+            compute_chunk();
         }
     }
 
@@ -208,19 +316,25 @@ struct WgradArgs {
     int n, cin, cout, h, wd;
     int tiles_x, tiles_y, items, items_per_split;
     int in_relu;
+    int vec_ok;
 };
 
 template <int TAPS, int TW, int TH, int WCI, int WCO, int KSPL>
 __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kernel(WgradArgs p) {
     static_assert(WCI * WCO * KSPL == 4, "wave decomposition");
-    static_assert(TH % KSPL == 0 && TW % 2 == 0, "rows split across waves, pixel pairs");
+    static_assert(TH % KSPL == 0 && TW % 4 == 0, "rows split across waves, float4 rows");
     constexpr int HALO = TAPS == 9 ? 1 : 0;
     constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO;
     constexpr int PP = (PW * PH) | 1;  // odd plane pitch: 32 lanes on 32 channels hit 32 banks
     constexpr int DP = (TW * TH) | 1;
     constexpr int CI_T = 32 * WCI, CO_T = 32 * WCO;
     constexpr int XSZ = CI_T * PP, DSZ = CO_T * DP;
-    __shared__ float lds[XSZ + DSZ];
+    constexpr int RED = KSPL > 1 ? TAPS * 1024 : 0;  // one wave's accumulators
+    constexpr int LDSF = XSZ + DSZ > RED ? XSZ + DSZ : RED;
+    constexpr int TW4 = TW / 4, VROW = TW4 + 2 * HALO;
+    constexpr int NXI = CI_T * PH * VROW, XPT = (NXI + kThreads - 1) / kThreads;
+    constexpr int NDI = CO_T * TH * TW4, DPT = (NDI + kThreads - 1) / kThreads;
+    __shared__ float lds[LDSF];
     float* lx = lds;
     float* ld = lds + XSZ;
 
@@ -229,6 +343,7 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
     const int ci0 = blockIdx.y * CI_T, co0 = blockIdx.z * CO_T;
     const int khalf = lane >> 5, j = lane & 31;
     const size_t hw = (size_t)p.h * p.wd;
+    const unsigned uhw = (unsigned)hw;
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -240,66 +355,14 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
     const int bbase = (w_co * 32 + j) * DP + khalf;
     const bool pro = p.in_scale != nullptr;
 
-    const unsigned uhw = (unsigned)hw;
-    // thread -> one tile position, walking channels (see conv_mfma_kernel's staging map)
-    constexpr int XPOS = PW * PH, DPOS = TW * TH;
-    constexpr int XSLOTS = XPOS <= 64 ? 64 : (XPOS <= 128 ? 128 : 256);
-    constexpr int DSLOTS = DPOS <= 64 ? 64 : (DPOS <= 128 ? 128 : 256);
-    constexpr int XG = kThreads / XSLOTS, DG = kThreads / DSLOTS;
-    static_assert(XPOS <= 256 && DPOS <= 256, "wgrad tiles are at most 256 positions");
-    const int xslot = tid % XSLOTS, xgrp = tid / XSLOTS;
-    const int dslot = tid % DSLOTS, dgrp = tid / DSLOTS;
-    const int xpy = xslot / PW, xpx = xslot - xpy * PW;
-    const int dpy = dslot / TW, dpx = dslot - dpy * TW;
-
-    auto stage_item = [&](int item) {
-        const int n = item / (p.tiles_x * p.tiles_y), t = item - n * (p.tiles_x * p.tiles_y);
-        const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
-        const float* xin = p.x + (size_t)n * p.cin * hw;
-        const float* din = p.dy + (size_t)n * p.cout * hw;
-        if (xslot < XPOS) {
-            const int gy = ty0 + xpy - HALO, gx = tx0 + xpx - HALO;
-            const bool ok = gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd;
-            const unsigned off = ok ? (unsigned)gy * (unsigned)p.wd + (unsigned)gx : 0u;
-#pragma unroll 4
-            for (int c = xgrp; c < CI_T; c += XG) {
-                const int gc = ci0 + c;
-                float v = 0.f;
-                if (ok && gc < p.cin) {
-                    v = xin[(unsigned)gc * uhw + off];
-                    if (pro) {
-                        v = fmaf(v, p.in_scale[gc], p.in_shift[gc]);
-                        if (p.in_relu) v = fmaxf(v, 0.f);
-                    }
-                }
-                lx[c * PP + xslot] = v;
-            }
-        }
-        if (dslot < DPOS) {
-            const int gy = ty0 + dpy, gx = tx0 + dpx;
-            const bool ok = gy < p.h && gx < p.wd;
-            const unsigned off = ok ? (unsigned)gy * (unsigned)p.wd + (unsigned)gx : 0u;
-#pragma unroll 4
-            for (int c = dgrp; c < CO_T; c += DG) {
-                const int gc = co0 + c;
-                float v = 0.f;
-                if (ok && gc < p.cout) v = din[(unsigned)gc * uhw + off];
-                ld[c * DP + dslot] = v;
-            }
-        }
-    };
-
-    const int first = blockIdx.x * p.items_per_split;
-    const int last = min(first + p.items_per_split, p.items);
-    for (int item = first; item < last; ++item) {
-        __syncthreads();
-        stage_item(item);
-        __syncthreads();
+    auto compute_item = [&]() {
         constexpr int ROWS = TH / KSPL;
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
             const int row = w_k * ROWS + rr;
-#pragma unroll 4
+            // 9 MFMAs (576 cycles) per pixel pair: a shallow unroll already hides the LDS
+            // latency and keeps the 144 accumulators + staging registers under 256
+#pragma unroll 2
             for (int xx = 0; xx < TW; xx += 2) {
                 const float b = ld[bbase + row * TW + xx];
 #pragma unroll
@@ -310,11 +373,220 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
                 }
             }
         }
+    };
+
+    const int first = blockIdx.x * p.items_per_split;
+    const int last = min(first + p.items_per_split, p.items);
+    const int tiles = p.tiles_x * p.tiles_y;
+
+    if (p.vec_ok) {  // every tile is full in x (host guarantees W % TW == 0 for this path)
+        float4 xv[XPT], dv[DPT];
+        unsigned xok = 0;
+        auto load_x = [&](int item, auto i0c, auto i1c) {
+            constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+            const int n = item / tiles, t = item - n * tiles;
+            const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
+            const float* xin = p.x + (size_t)n * p.cin * hw;
+            if (I0 == 0) xok = 0;
+#pragma unroll
+            for (int i = I0; i < I1; ++i) {
+                const int e = tid + i * kThreads;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NXI) {
+                    const int c = e / (PH * VROW), rem = e - c * (PH * VROW);
+                    const int py = rem / VROW, slot = rem - py * VROW;
+                    const int gc = ci0 + c, gy = ty0 + py - HALO;
+                    if (gc < p.cin && gy >= 0 && gy < p.h) {
+                        const float* row = xin + (unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd;
+                        if (slot < TW4) {
+                            v = *reinterpret_cast<const float4*>(row + tx0 + 4 * slot);
+                            xok |= 1u << i;
+                        } else {
+                            const int gx = slot == TW4 ? tx0 - 1 : tx0 + TW;
+                            if (gx >= 0 && gx < p.wd) {
+                                v.x = row[gx];
+                                xok |= 1u << i;
+                            }
+                        }
+                    }
+                }
+                xv[i] = v;
+            }
+        };
+        auto load_d = [&](int item) {
+            const int n = item / tiles, t = item - n * tiles;
+            const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
+            const float* din = p.dy + (size_t)n * p.cout * hw;
+#pragma unroll
+            for (int i = 0; i < DPT; ++i) {
+                const int e = tid + i * kThreads;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NDI) {
+                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                    const int py = rem / TW4, slot = rem - py * TW4;
+                    const int gc = co0 + c, gy = ty0 + py;
+                    if (gc < p.cout && gy < p.h)
+                        v = *reinterpret_cast<const float4*>(din + (unsigned)gc * uhw +
+                                                             (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                }
+                dv[i] = v;
+            }
+        };
+        auto store_x = [&](auto i0c, auto i1c) {
+            constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+#pragma unroll
+            for (int i = I0; i < I1; ++i) {
+                const int e = tid + i * kThreads;
+                if (e < NXI) {
+                    const int c = e / (PH * VROW), rem = e - c * (PH * VROW);
+                    const int py = rem / VROW, slot = rem - py * VROW;
+                    float4 v = xv[i];
+                    if (pro && (xok >> i & 1u)) {
+                        const float sc = p.in_scale[ci0 + c], sh = p.in_shift[ci0 + c];
+                        v.x = pro_apply(v.x, sc, sh, p.in_relu);
+                        v.y = pro_apply(v.y, sc, sh, p.in_relu);
+                        v.z = pro_apply(v.z, sc, sh, p.in_relu);
+                        v.w = pro_apply(v.w, sc, sh, p.in_relu);
+                    }
+                    float* dst = lx + c * PP + py * PW;
+                    if (slot < TW4) {
+                        dst += HALO + 4 * slot;
+                        dst[0] = v.x;
+                        dst[1] = v.y;
+                        dst[2] = v.z;
+                        dst[3] = v.w;
+                    } else {
+                        dst[slot == TW4 ? 0 : PW - 1] = v.x;
+                    }
+                }
+            }
+        };
+        auto store_d = [&]() {
+#pragma unroll
+            for (int i = 0; i < DPT; ++i) {
+                const int e = tid + i * kThreads;
+                if (e < NDI) {
+                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                    float* dst = ld + c * DP + rem * 4;
+                    dst[0] = dv[i].x;
+                    dst[1] = dv[i].y;
+                    dst[2] = dv[i].z;
+                    dst[3] = dv[i].w;
+                }
+            }
+        };
+        if (TAPS == 1) {  // few accumulators: next item's loads stay in registers over the MFMAs
+            using Z = std::integral_constant<int, 0>;
+            using E = std::integral_constant<int, XPT>;
+            if (first < last) {
+                load_x(first, Z{}, E{});
+                load_d(first);
+            }
+            for (int item = first; item < last; ++item) {
+                __syncthreads();
+                store_x(Z{}, E{});
+                store_d();
+                __syncthreads();
+                if (item + 1 < last) {
+                    load_x(item + 1, Z{}, E{});
+                    load_d(item + 1);
+                }
+                compute_item();
+            }
+        } else {
+            // 144 accumulators leave ~100 registers: stage X in two halves (XPT/2 float4 in
+            // flight per thread), then dY
+            using Z = std::integral_constant<int, 0>;
+            using H = std::integral_constant<int, (XPT + 1) / 2>;
+            using E = std::integral_constant<int, XPT>;
+            for (int item = first; item < last; ++item) {
+                __syncthreads();
+                load_x(item, Z{}, H{});
+                store_x(Z{}, H{});
+                load_x(item, H{}, E{});
+                store_x(H{}, E{});
+                load_d(item);
+                store_d();
+                __syncthreads();
+                compute_item();
+            }
+        }
+    } else {
+        // scalar staging: thread -> one tile position, walking channels
+        constexpr int XPOS = PW * PH, DPOS = TW * TH;
+        constexpr int XSLOTS = XPOS <= 64 ? 64 : (XPOS <= 128 ? 128 : 256);
+        constexpr int DSLOTS = DPOS <= 64 ? 64 : (DPOS <= 128 ? 128 : 256);
+        constexpr int XG = kThreads / XSLOTS, DG = kThreads / DSLOTS;
+        static_assert(XPOS <= 256 && DPOS <= 256, "wgrad tiles are at most 256 positions");
+        const int xslot = tid % XSLOTS, xgrp = tid / XSLOTS;
+        const int dslot = tid % DSLOTS, dgrp = tid / DSLOTS;
+        const int xpy = xslot / PW, xpx = xslot - xpy * PW;
+        const int dpy = dslot / TW, dpx = dslot - dpy * TW;
+        for (int item = first; item < last; ++item) {
+            const int n = item / tiles, t = item - n * tiles;
+            const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
+            const float* xin = p.x + (size_t)n * p.cin * hw;
+            const float* din = p.dy + (size_t)n * p.cout * hw;
+            __syncthreads();
+            if (xslot < XPOS) {
+                const int gy = ty0 + xpy - HALO, gx = tx0 + xpx - HALO;
+                const bool ok = gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd;
+                const unsigned off = ok ? (unsigned)gy * (unsigned)p.wd + (unsigned)gx : 0u;
+#pragma unroll 4
+                for (int c = xgrp; c < CI_T; c += XG) {
+                    const int gc = ci0 + c;
+                    float v = 0.f;
+                    if (ok && gc < p.cin) {
+                        v = xin[(unsigned)gc * uhw + off];
+                        if (pro) v = pro_apply(v, p.in_scale[gc], p.in_shift[gc], p.in_relu);
+                    }
+                    lx[c * PP + xslot] = v;
+                }
+            }
+            if (dslot < DPOS) {
+                const int gy = ty0 + dpy, gx = tx0 + dpx;
+                const bool ok = gy < p.h && gx < p.wd;
+                const unsigned off = ok ? (unsigned)gy * (unsigned)p.wd + (unsigned)gx : 0u;
+#pragma unroll 4
+                for (int c = dgrp; c < CO_T; c += DG) {
+                    const int gc = co0 + c;
+                    float v = 0.f;
+                    if (ok && gc < p.cout) v = din[(unsigned)gc * uhw + off];
+                    ld[c * DP + dslot] = v;
+                }
+            }
+            __syncthreads();
+            compute_item();
+        }
     }
 
-    // every K-split wave writes its own partial slab (no LDS reduction, no atomics)
-    {
-        float* out = p.part + ((size_t)blockIdx.x * KSPL + w_k) * p.cin * TAPS * p.cout;
+    // K-split waves fold their accumulators into wave k = 0 through LDS, one (ci,co) block
+    // at a time, in a fixed order
+    if (KSPL > 1) {
+        const int q = w_co * WCI + w_ci;
+#pragma unroll 1
+        for (int k = 1; k < KSPL; ++k) {
+#pragma unroll 1
+            for (int qq = 0; qq < WCI * WCO; ++qq) {
+                __syncthreads();
+                if (w_k == k && q == qq) {
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) lds[t * 1024 + r * 64 + lane] = acc[t][r];
+                }
+                __syncthreads();
+                if (w_k == 0 && q == qq) {
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] += lds[t * 1024 + r * 64 + lane];
+                }
+            }
+        }
+    }
+    if (w_k == 0) {
+        float* out = p.part + (size_t)blockIdx.x * p.cin * TAPS * p.cout;
         const int co = co0 + w_co * 32 + j;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
@@ -326,15 +598,132 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
     }
 }
 
-// sum the per-split slabs: dw[i] = sum_s part[s][i]  (fixed order -> deterministic)
+// Small-Cin 3x3 wgrad (the stem, Cin*9 <= 32): D[(ci,tap)][co] — the 27 (ci, tap) pairs ride
+// the MFMA's M dimension, so a pixel pair costs ONE MFMA per 32 output channels instead of 9.
+// Tile 32 x 8; 4 waves split the 8 rows; X patch [cin][10][34] (+ one zero plane for the
+// unused M rows), dY tile [32][256].  grid = (splits, 1, cout/32 blocks).
+template <int TW, int TH>
+__global__ __launch_bounds__(kThreads, 4) void wgrad_smallcin_kernel(WgradArgs p) {
+    constexpr int PW = TW + 2, PH = TH + 2, PP = PW * PH;
+    constexpr int DP = (TW * TH) | 1;
+    constexpr int MAXC = 3;
+    constexpr int TW4 = TW / 4;
+    __shared__ float lds[(MAXC + 1) * PP + 32 * DP];
+    float* lx = lds;
+    float* ld = lds + (MAXC + 1) * PP;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int khalf = lane >> 5, j = lane & 31;
+    const int co0 = blockIdx.z * 32;
+    const size_t hw = (size_t)p.h * p.wd;
+    const unsigned uhw = (unsigned)hw;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // lane j < cin*9 reads channel j/9 at tap j%9; other lanes read the zero plane
+    const int ktot = p.cin * 9;
+    const int aci = j < ktot ? j / 9 : MAXC, atap = j < ktot ? j % 9 : 0;
+    const int abase = aci * PP + (atap / 3) * PW + (atap % 3) + khalf;
+    const int bbase = j * DP + khalf;
+    for (int i = tid; i < PP; i += kThreads) lx[MAXC * PP + i] = 0.f;
+    const int first = blockIdx.x * p.items_per_split;
+    const int last = min(first + p.items_per_split, p.items);
+    const int tiles = p.tiles_x * p.tiles_y;
+    const bool pro = p.in_scale != nullptr;
+    constexpr int ROWS = TH / 4;
+    for (int item = first; item < last; ++item) {
+        const int n = item / tiles, t = item - n * tiles;
+        const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
+        const float* xin = p.x + (size_t)n * p.cin * hw;
+        const float* din = p.dy + (size_t)n * p.cout * hw;
+        __syncthreads();
+        for (int e = tid; e < p.cin * PP; e += kThreads) {
+            const int c = e / PP, rem = e - c * PP;
+            const int py = rem / PW, px = rem - py * PW;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            float v = 0.f;
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd) {
+                v = xin[(unsigned)c * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx];
+                if (pro) v = pro_apply(v, p.in_scale[c], p.in_shift[c], p.in_relu);
+            }
+            lx[e] = v;
+        }
+        if (p.vec_ok) {
+#pragma unroll
+            for (int i = 0; i < 32 * TH * TW4 / kThreads; ++i) {
+                const int e = tid + i * kThreads;
+                const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                const int py = rem / TW4, slot = rem - py * TW4;
+                const int gc = co0 + c, gy = ty0 + py;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gc < p.cout && gy < p.h)
+                    v = *reinterpret_cast<const float4*>(din + (unsigned)gc * uhw +
+                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                float* dst = ld + c * DP + rem * 4;
+                dst[0] = v.x;
+                dst[1] = v.y;
+                dst[2] = v.z;
+                dst[3] = v.w;
+            }
+        } else {
+            for (int e = tid; e < 32 * TW * TH; e += kThreads) {
+                const int c = e / (TW * TH), rem = e - c * (TW * TH);
+                const int py = rem / TW, px = rem - py * TW;
+                const int gc = co0 + c, gy = ty0 + py, gx = tx0 + px;
+                float v = 0.f;
+                if (gc < p.cout && gy < p.h && gx < p.wd)
+                    v = din[(unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx];
+                ld[c * DP + rem] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int row = wid * ROWS + rr;
+#pragma unroll 8
+            for (int xx = 0; xx < TW; xx += 2) {
+                const float a = lx[abase + row * PW + xx];
+                const float b = ld[bbase + row * TW + xx];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        }
+    }
+    // fold the 4 row-split waves through LDS
+#pragma unroll 1
+    for (int k = 1; k < 4; ++k) {
+        __syncthreads();
+        if (wid == k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds[r * 64 + lane] = acc[r];
+        __syncthreads();
+        if (wid == 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += lds[r * 64 + lane];
+    }
+    if (wid == 0) {
+        float* out = p.part + (size_t)blockIdx.x * p.cin * 9 * p.cout;
+        const int co = co0 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kidx = (r & 3) + 8 * (r >> 2) + 4 * khalf;  // = ci*9 + tap
+            if (kidx < ktot && co < p.cout) out[(size_t)kidx * p.cout + co] = acc[r];
+        }
+    }
+}
+
+// dst[g][i] = sum over slabs s in group g of part[s][i]; with one group and dw given this is
+// the final dw = beta*dw + sum.  Fixed order -> deterministic.
 __global__ __launch_bounds__(kThreads) void slab_reduce_kernel(const float* __restrict__ part,
-                                                               float* __restrict__ dw, size_t count,
-                                                               int splits, float beta) {
+                                                               float* __restrict__ dst, size_t count,
+                                                               int nslabs, int per_group, float beta,
+                                                               int final_pass) {
+    const int g = blockIdx.y;
+    const int s0 = g * per_group, s1 = min(s0 + per_group, nslabs);
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count;
          i += (size_t)gridDim.x * kThreads) {
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(size_t)k * count + i];
-        dw[i] = beta != 0.f ? fmaf(beta, dw[i], s) : s;
+        for (int k = s0; k < s1; ++k) s += part[(size_t)k * count + i];
+        float* o = dst + (size_t)g * count + i;
+        *o = (final_pass && beta != 0.f) ? fmaf(beta, *o, s) : s;
     }
 }
 
@@ -384,6 +773,7 @@ struct WgVariant {
 };
 constexpr WgVariant kWgVariants[] = {{32, 4, 32, 32, 4}, {16, 8, 32, 64, 2}, {16, 4, 64, 64, 1},
                                      {28, 2, 64, 64, 1}, {32, 4, 32, 64, 2}};
+constexpr int kWgSmallCin = 5;  // variant id of wgrad_smallcin_kernel<32, 8>
 
 template <int TAPS>
 int launch_wgrad(int variant, const WgradArgs& a, dim3 grid, hipStream_t s) {
@@ -399,68 +789,53 @@ int launch_wgrad(int variant, const WgradArgs& a, dim3 grid, hipStream_t s) {
 }
 
 struct WgPlan {
-    int variant, tiles_x, tiles_y, items, splits, items_per_split, gy, gz, slabs;
+    int variant, tw, tiles_x, tiles_y, items, splits, items_per_split, gy, gz;
 };
 
-WgPlan plan_wgrad(int n, int cin, int cout, int h, int w) {
+WgPlan plan_wgrad(int n, int cin, int cout, int h, int w, int ksize) {
     WgPlan best{};
-    long long best_cost = -1;
-    for (int v = 0; v < (int)(sizeof(kWgVariants) / sizeof(kWgVariants[0])); ++v) {
-        const WgVariant& k = kWgVariants[v];
-        const long long tx = (w + k.tw - 1) / k.tw, ty = (h + k.th - 1) / k.th;
-        const long long gy = (cin + k.ci_t - 1) / k.ci_t, gz = (cout + k.co_t - 1) / k.co_t;
-        const long long cost = tx * k.tw * ty * k.th * gy * k.ci_t * gz * k.co_t;
-        if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            best.variant = v;
-            best.tiles_x = (int)tx;
-            best.tiles_y = (int)ty;
-            best.gy = (int)gy;
-            best.gz = (int)gz;
+    if (ksize == 3 && cin * 9 <= 32) {
+        best.variant = kWgSmallCin;
+        best.tw = 32;
+        best.tiles_x = (w + 31) / 32;
+        best.tiles_y = (h + 7) / 8;
+        best.gy = 1;
+        best.gz = (cout + 31) / 32;
+    } else {
+        long long best_cost = -1;
+        for (int v = 0; v < (int)(sizeof(kWgVariants) / sizeof(kWgVariants[0])); ++v) {
+            const WgVariant& k = kWgVariants[v];
+            const long long tx = (w + k.tw - 1) / k.tw, ty = (h + k.th - 1) / k.th;
+            const long long gy = (cin + k.ci_t - 1) / k.ci_t, gz = (cout + k.co_t - 1) / k.co_t;
+            const long long cost = tx * k.tw * ty * k.th * gy * k.ci_t * gz * k.co_t;
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best.variant = v;
+                best.tw = k.tw;
+                best.tiles_x = (int)tx;
+                best.tiles_y = (int)ty;
+                best.gy = (int)gy;
+                best.gz = (int)gz;
+            }
         }
     }
     best.items = n * best.tiles_x * best.tiles_y;
-    // ~4 workgroups per CU overall; every split gets the same number of items
-    int splits = (256 * 4) / (best.gy * best.gz);
+    // ~2-3 resident workgroups per CU overall; every split gets the same number of items
+    int splits = (256 * 3) / (best.gy * best.gz);
     if (splits < 1) splits = 1;
     if (splits > best.items) splits = best.items;
     best.items_per_split = (best.items + splits - 1) / splits;
     best.splits = (best.items + best.items_per_split - 1) / best.items_per_split;
-    best.slabs = best.splits * kWgVariants[best.variant].kspl;
     return best;
 }
+
+constexpr int kReduceGroup = 32;  // slabs summed per first-stage workgroup row
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
 }  // namespace
 
 extern "C" {
-
-int lf_conv2d_variant(int h, int wd, int cout);
-
-int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
-                  int ksize, const float* in_scale, const float* in_shift, int in_relu,
-                  int accumulate, lf_stream_t stream) {
-    LF_REQUIRE(x && w && y, "lf_conv2d: null buffer");
-    LF_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && wd > 0,
-               "lf_conv2d: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, wd);
-    LF_REQUIRE(ksize == 3 || ksize == 1, "lf_conv2d: ksize must be 1 or 3 (got %d)", ksize);
-    LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr),
-               "lf_conv2d: in_scale/in_shift must both be set");
-    LF_REQUIRE(n <= 65535, "lf_conv2d: batch too large for grid.z");
-    const int best = lf_conv2d_variant(h, wd, cout);
-    const FwdVariant& v = kFwdVariants[best];
-    ConvArgs a;
-    a.x = x; a.w = w; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
-    a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.wd = wd;
-    a.tiles_x = (wd + v.tw - 1) / v.tw;
-    a.tiles_y = (h + v.th - 1) / v.th;
-    a.in_relu = in_relu;
-    a.accumulate = accumulate;
-    dim3 grid(a.tiles_x * a.tiles_y, (cout + v.ct - 1) / v.ct, n);
-    hipStream_t s = lf::as_stream(stream);
-    const int rc = ksize == 3 ? launch_fwd<9>(best, a, grid, s) : launch_fwd<1>(best, a, grid, s);
-    if (rc != LF_OK) return rc;
-    return lf::check_launch("lf_conv2d");
-}
 
 int lf_conv2d_variant(int h, int wd, int cout) {
     int best = 0;
@@ -475,9 +850,38 @@ int lf_conv2d_variant(int h, int wd, int cout) {
     return best;
 }
 
-int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout) {
+int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout, int ksize) {
     if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || wd <= 0) return -1;
-    return plan_wgrad(n, cin, cout, h, wd).variant;
+    return plan_wgrad(n, cin, cout, h, wd, ksize).variant;
+}
+
+int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
+                  int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                  int accumulate, lf_stream_t stream) {
+    LF_REQUIRE(x && w && y, "lf_conv2d: null buffer");
+    LF_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && wd > 0,
+               "lf_conv2d: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, wd);
+    LF_REQUIRE(ksize == 3 || ksize == 1, "lf_conv2d: ksize must be 1 or 3 (got %d)", ksize);
+    LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr),
+               "lf_conv2d: in_scale/in_shift must both be set");
+    LF_REQUIRE(n <= 65535, "lf_conv2d: batch too large for grid.z");
+    LF_REQUIRE((size_t)cin * h * wd < (1ull << 30) && (size_t)cin * ksize * ksize * cout < (1ull << 30),
+               "lf_conv2d: per-image tensor too large for 32-bit offsets");
+    const int best = lf_conv2d_variant(h, wd, cout);
+    const FwdVariant& v = kFwdVariants[best];
+    ConvArgs a;
+    a.x = x; a.w = w; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.wd = wd;
+    a.tiles_x = (wd + v.tw - 1) / v.tw;
+    a.tiles_y = (h + v.th - 1) / v.th;
+    a.in_relu = in_relu;
+    a.accumulate = accumulate;
+    a.vec_ok = (wd % 4 == 0) && (cout % 4 == 0) && aligned16(x) && aligned16(w);
+    dim3 grid(a.tiles_x * a.tiles_y, (cout + v.ct - 1) / v.ct, n);
+    hipStream_t s = lf::as_stream(stream);
+    const int rc = ksize == 3 ? launch_fwd<9>(best, a, grid, s) : launch_fwd<1>(best, a, grid, s);
+    if (rc != LF_OK) return rc;
+    return lf::check_launch("lf_conv2d");
 }
 
 int lf_conv2d_dgrad_weights_f32(const float* w, float* wt, int cin, int ksize, int cout,
@@ -492,8 +896,10 @@ int lf_conv2d_dgrad_weights_f32(const float* w, float* wt, int cin, int ksize, i
 
 size_t lf_conv2d_wgrad_workspace(int n, int cin, int h, int wd, int cout, int ksize) {
     if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || wd <= 0) return 0;
-    const WgPlan pl = plan_wgrad(n, cin, cout, h, wd);
-    return (size_t)pl.slabs * cin * ksize * ksize * cout * sizeof(float);
+    const WgPlan pl = plan_wgrad(n, cin, cout, h, wd, ksize);
+    const size_t count = (size_t)cin * ksize * ksize * cout;
+    const size_t groups = (pl.splits + kReduceGroup - 1) / kReduceGroup;
+    return ((size_t)pl.splits + groups) * count * sizeof(float);
 }
 
 int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, int wd, int cout,
@@ -505,11 +911,12 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, 
     LF_REQUIRE(ksize == 3 || ksize == 1, "lf_conv2d_wgrad: ksize must be 1 or 3 (got %d)", ksize);
     LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr),
                "lf_conv2d_wgrad: in_scale/in_shift must both be set");
-    const WgPlan pl = plan_wgrad(n, cin, cout, h, wd);
-    const size_t count = (size_t)cin * ksize * ksize * cout;
-    if (ws_bytes < (size_t)pl.slabs * count * sizeof(float)) {
+    LF_REQUIRE((size_t)cin * h * wd < (1ull << 30) && (size_t)cout * h * wd < (1ull << 30),
+               "lf_conv2d_wgrad: per-image tensor too large for 32-bit offsets");
+    const WgPlan pl = plan_wgrad(n, cin, cout, h, wd, ksize);
+    if (ws_bytes < lf_conv2d_wgrad_workspace(n, cin, h, wd, cout, ksize)) {
         lf::set_error("lf_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes,
-                      (size_t)pl.slabs * count * sizeof(float));
+                      lf_conv2d_wgrad_workspace(n, cin, h, wd, cout, ksize));
         return LF_ERR_WORKSPACE;
     }
     WgradArgs a;
@@ -519,23 +926,37 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, 
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.items = pl.items;
     a.items_per_split = pl.items_per_split;
     a.in_relu = in_relu;
+    a.vec_ok = (wd % pl.tw == 0) && (wd % 4 == 0) && aligned16(x) && aligned16(dy);
     dim3 grid(pl.splits, pl.gy, pl.gz);
     hipStream_t s = lf::as_stream(stream);
-    const int rc = ksize == 3 ? launch_wgrad<9>(pl.variant, a, grid, s)
-                              : launch_wgrad<1>(pl.variant, a, grid, s);
+    int rc = LF_OK;
+    if (pl.variant == kWgSmallCin)
+        wgrad_smallcin_kernel<32, 8><<<grid, kThreads, 0, s>>>(a);
+    else
+        rc = ksize == 3 ? launch_wgrad<9>(pl.variant, a, grid, s) : launch_wgrad<1>(pl.variant, a, grid, s);
     if (rc != LF_OK) return rc;
     return lf::check_launch("lf_conv2d_wgrad");
 }
 
-int lf_conv2d_wgrad_reduce_f32(const void* workspace, float* dw, int n, int cin, int h, int wd,
-                               int cout, int ksize, float beta, lf_stream_t stream) {
+int lf_conv2d_wgrad_reduce_f32(void* workspace, float* dw, int n, int cin, int h, int wd, int cout,
+                               int ksize, float beta, lf_stream_t stream) {
     LF_REQUIRE(workspace && dw, "lf_conv2d_wgrad_reduce: null buffer");
     LF_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && wd > 0 && (ksize == 1 || ksize == 3),
                "lf_conv2d_wgrad_reduce: bad dims");
-    const WgPlan pl = plan_wgrad(n, cin, cout, h, wd);
+    const WgPlan pl = plan_wgrad(n, cin, cout, h, wd, ksize);
     const size_t count = (size_t)cin * ksize * ksize * cout;
-    slab_reduce_kernel<<<lf::stream_grid(count, kThreads), kThreads, 0, lf::as_stream(stream)>>>(
-        static_cast<const float*>(workspace), dw, count, pl.slabs, beta);
+    float* part = static_cast<float*>(workspace);
+    hipStream_t s = lf::as_stream(stream);
+    const unsigned gx = lf::stream_grid(count, kThreads, 1024);
+    if (pl.splits <= kReduceGroup) {
+        slab_reduce_kernel<<<dim3(gx, 1), kThreads, 0, s>>>(part, dw, count, pl.splits, pl.splits, beta, 1);
+    } else {
+        const int groups = (pl.splits + kReduceGroup - 1) / kReduceGroup;
+        float* stage = part + (size_t)pl.splits * count;
+        slab_reduce_kernel<<<dim3(gx, groups), kThreads, 0, s>>>(part, stage, count, pl.splits,
+                                                                 kReduceGroup, 0.f, 0);
+        slab_reduce_kernel<<<dim3(gx, 1), kThreads, 0, s>>>(stage, dw, count, groups, groups, beta, 1);
+    }
     return lf::check_launch("lf_conv2d_wgrad_reduce");
 }
 
