@@ -219,17 +219,21 @@ int lf_bn_train_stats_f32(const float* y, int n, int c, int hw, const float* gam
 int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
                                 const float* moving_mean, const float* moving_var, float eps,
                                 float* scale, float* shift, lf_stream_t stream);
-/* BatchNorm backward with the upstream chain folded in: dz = (g*alpha_nc[n][c] + add_nc[n][c])
- * where mask > 0 (alpha/add/mask optional), dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat));
- * dgamma = sum dz*xhat, dbeta = sum dz. */
-int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* mask,
-                  const float* y, const float* mean, const float* invstd, const float* gamma,
-                  float* dy, float* dgamma, float* dbeta, int n, int c, int hw, void* workspace,
-                  size_t ws_bytes, lf_stream_t stream);
+/* BatchNorm backward with the upstream chain folded in: dz = g*alpha_nc[n][c] + add_nc[n][c]
+ * (both optional), zeroed where the forward's ReLU was inactive when relu != 0 — the mask is
+ * recomputed as y*scale[c]+shift[c] > 0 from the pre-BN tensor, so the activation is never
+ * stored; dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma = sum dz*xhat,
+ * dbeta = sum dz. */
+int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* y,
+                  const float* mean, const float* invstd, const float* scale, const float* shift,
+                  int relu, const float* gamma, float* dy, float* dgamma, float* dbeta, int n, int c,
+                  int hw, void* workspace, size_t ws_bytes, lf_stream_t stream);
 
 /* ---- pooling / broadcast ---- */
-/* out[p] = mean over hw of x[p][:] (GlobalAveragePooling2D, cnn.py:13,98). */
-int lf_gap_f32(const float* x, float* out, int planes, int hw, lf_stream_t stream);
+/* out[p] = mean over hw of act(x[p][:]*scale[c]+shift[c]), c = p % C (GlobalAveragePooling2D,
+ * cnn.py:13,98; scale/shift null = plain mean; relu applies with the prologue). */
+int lf_gap_f32(const float* x, float* out, int planes, int hw, int c, const float* scale,
+               const float* shift, int relu, lf_stream_t stream);
 /* out[p][:] = v[p]*scale (GAP backward). */
 int lf_bcast_planes_f32(const float* v, float* out, int planes, int hw, float scale,
                         lf_stream_t stream);
@@ -245,15 +249,18 @@ int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float*
                   lf_stream_t stream);
 
 /* ---- residual tail (cnn.py:47-48,94-96): Add -> ReLU -> SpatialDropout2D -> MaxPool2D(2) ---- */
-/* r = relu(sc' + a*s[n][c]), sc' = sc*sc_scale[c]+sc_shift[c] (projection BN) or sc;
- * p = drop[n][c] * maxpool2x2(r) (drop = 0 or 1/(1-rate), null = 1). */
-int lf_block_tail_fwd_f32(const float* a, const float* s, const float* sc, const float* sc_scale,
-                          const float* sc_shift, const float* drop, float* r, float* p, int n,
+/* r = relu(sc' + a*s[n][c]) with a = relu(y*a_scale[c]+a_shift[c]) (BN2+ReLU fused; a = y when
+ * a_scale is null) and sc' = act(sc*sc_scale[c]+sc_shift[c]) (projection BN, or BN+ReLU of the
+ * producer when sc_relu) or sc;  p = drop[n][c] * maxpool2x2(r) (drop = 0 or 1/(1-rate)). */
+int lf_block_tail_fwd_f32(const float* y, const float* a_scale, const float* a_shift,
+                          const float* s, const float* sc, const float* sc_scale,
+                          const float* sc_shift, int sc_relu, const float* drop, float* r, float* p,
+                          int n, int c, int h, int w, lf_stream_t stream);
+/* dr = gradient wrt (sc' + a*s): dp*drop routed to the first maximum of each window where
+ * r > 0; ds[n][c] = sum_hw dr*a (SE gate gradient; y/ds optional together). */
+int lf_block_tail_bwd_f32(const float* dp, const float* r, const float* y, const float* a_scale,
+                          const float* a_shift, const float* drop, float* dr, float* ds, int n,
                           int c, int h, int w, lf_stream_t stream);
-/* dr = gradient wrt (sc' + a*s) : dp*drop routed to the first maximum of each window where
- * r > 0; ds[n][c] = sum_hw dr*a (SE gate gradient; a/ds optional together). */
-int lf_block_tail_bwd_f32(const float* dp, const float* r, const float* a, const float* drop,
-                          float* dr, float* ds, int n, int c, int h, int w, lf_stream_t stream);
 
 /* ---- head (cnn.py:98-101; train/utils.py:30-35) ---- */
 /* probs = softmax(feat w + b), w [f][c]; loss[n] = -sum_j ytrue[n][j] log(clip(probs)). */

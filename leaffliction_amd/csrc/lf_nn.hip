@@ -241,32 +241,53 @@ struct BnBwdArgs {
     const float* g;      // upstream gradient [N][C][HW]
     const float* alpha;  // [N][C] or null (1)
     const float* addnc;  // [N][C] or null (0)
-    const float* mask;   // [N][C][HW] or null: gradient passes where mask > 0
     const float* y;      // pre-BN activations
     const float* mean;
     const float* invstd;
+    const float* scale;  // gamma*invstd, beta - mean*scale: the forward's BN apply
+    const float* shift;
+    int relu;            // 1: the BN was followed by ReLU -> gradient passes where y*scale+shift > 0
     int n, c, hw;
 };
 
-__device__ __forceinline__ float bn_dz(const BnBwdArgs& a, size_t idx, float al, float ad) {
-    float dz = fmaf(a.g[idx], al, ad);
-    if (a.mask != nullptr && !(a.mask[idx] > 0.f)) dz = 0.f;
+// dz for one element: the ReLU mask is recomputed from y with the forward's own fmaf, so the
+// activation tensor is never materialised
+__device__ __forceinline__ float bn_dz1(float g, float y, float al, float ad, float sc, float sh,
+                                        int relu) {
+    float dz = fmaf(g, al, ad);
+    if (relu && !(fmaf(y, sc, sh) > 0.f)) dz = 0.f;
     return dz;
 }
 
 __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(BnBwdArgs a, float* __restrict__ part) {
     __shared__ float red[8];
     const int ch = blockIdx.y, s = blockIdx.x;
-    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    const float mean = a.mean[ch], invstd = a.invstd[ch], sc = a.scale[ch], sh = a.shift[ch];
     float acc[2] = {0.f, 0.f};
     for (int img = s; img < a.n; img += kBnSplit) {
         const size_t base = ((size_t)img * a.c + ch) * a.hw;
         const float al = a.alpha ? a.alpha[img * a.c + ch] : 1.f;
         const float ad = a.addnc ? a.addnc[img * a.c + ch] : 0.f;
-        for (int i = threadIdx.x; i < a.hw; i += kBlock) {
-            const float dz = bn_dz(a, base + i, al, ad);
-            acc[0] += dz;
-            acc[1] += dz * ((a.y[base + i] - mean) * invstd);
+        if ((a.hw & 3) == 0) {
+            const float4* g4 = reinterpret_cast<const float4*>(a.g + base);
+            const float4* y4 = reinterpret_cast<const float4*>(a.y + base);
+            for (int i = threadIdx.x; i < a.hw / 4; i += kBlock) {
+                const float4 g = g4[i], y = y4[i];
+                const float d0 = bn_dz1(g.x, y.x, al, ad, sc, sh, a.relu);
+                const float d1 = bn_dz1(g.y, y.y, al, ad, sc, sh, a.relu);
+                const float d2 = bn_dz1(g.z, y.z, al, ad, sc, sh, a.relu);
+                const float d3 = bn_dz1(g.w, y.w, al, ad, sc, sh, a.relu);
+                acc[0] += (d0 + d1) + (d2 + d3);
+                acc[1] += (d0 * ((y.x - mean) * invstd) + d1 * ((y.y - mean) * invstd)) +
+                          (d2 * ((y.z - mean) * invstd) + d3 * ((y.w - mean) * invstd));
+            }
+        } else {
+            for (int i = threadIdx.x; i < a.hw; i += kBlock) {
+                const float y = a.y[base + i];
+                const float dz = bn_dz1(a.g[base + i], y, al, ad, sc, sh, a.relu);
+                acc[0] += dz;
+                acc[1] += dz * ((y - mean) * invstd);
+            }
         }
     }
     block_sum<2>(acc, red);
@@ -296,28 +317,67 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(BnBwdArgs a,
                                                               float inv_count,
                                                               float* __restrict__ dy) {
     const int plane = blockIdx.x, ch = plane % a.c;
-    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    const float mean = a.mean[ch], invstd = a.invstd[ch], sc = a.scale[ch], sh = a.shift[ch];
     const float k = gamma[ch] * invstd;
     const float mdz = dbeta[ch] * inv_count, mdzx = dgamma[ch] * inv_count;
     const float al = a.alpha ? a.alpha[plane] : 1.f;
     const float ad = a.addnc ? a.addnc[plane] : 0.f;
     const size_t base = (size_t)plane * a.hw;
-    for (int i = blockIdx.y * kBlock + threadIdx.x; i < a.hw; i += gridDim.y * kBlock) {
-        const float dz = bn_dz(a, base + i, al, ad);
-        const float xh = (a.y[base + i] - mean) * invstd;
-        dy[base + i] = k * (dz - mdz - xh * mdzx);
+    if ((a.hw & 3) == 0) {
+        const float4* g4 = reinterpret_cast<const float4*>(a.g + base);
+        const float4* y4 = reinterpret_cast<const float4*>(a.y + base);
+        float4* o4 = reinterpret_cast<float4*>(dy + base);
+        for (int i = blockIdx.y * kBlock + threadIdx.x; i < a.hw / 4; i += gridDim.y * kBlock) {
+            const float4 g = g4[i], y = y4[i];
+            float4 o;
+            o.x = k * (bn_dz1(g.x, y.x, al, ad, sc, sh, a.relu) - mdz - ((y.x - mean) * invstd) * mdzx);
+            o.y = k * (bn_dz1(g.y, y.y, al, ad, sc, sh, a.relu) - mdz - ((y.y - mean) * invstd) * mdzx);
+            o.z = k * (bn_dz1(g.z, y.z, al, ad, sc, sh, a.relu) - mdz - ((y.z - mean) * invstd) * mdzx);
+            o.w = k * (bn_dz1(g.w, y.w, al, ad, sc, sh, a.relu) - mdz - ((y.w - mean) * invstd) * mdzx);
+            o4[i] = o;
+        }
+    } else {
+        for (int i = blockIdx.y * kBlock + threadIdx.x; i < a.hw; i += gridDim.y * kBlock) {
+            const float y = a.y[base + i];
+            const float dz = bn_dz1(a.g[base + i], y, al, ad, sc, sh, a.relu);
+            dy[base + i] = k * (dz - mdz - ((y - mean) * invstd) * mdzx);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
 // global average pool per plane, and its broadcast backward
 // ---------------------------------------------------------------------------
+// out[plane] = mean_hw act(x*scale[c]+shift[c]) (scale null = plain mean)
 __global__ __launch_bounds__(kBlock) void gap_kernel(const float* __restrict__ x,
-                                                     float* __restrict__ out, int hw) {
+                                                     float* __restrict__ out, int hw, int c,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int relu) {
     __shared__ float red[4];
     const size_t base = (size_t)blockIdx.x * hw;
+    const bool pro = scale != nullptr;
+    const float sc = pro ? scale[blockIdx.x % c] : 1.f, sh = pro ? shift[blockIdx.x % c] : 0.f;
     float acc[1] = {0.f};
-    for (int i = threadIdx.x; i < hw; i += kBlock) acc[0] += x[base + i];
+    if ((hw & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x + base);
+        for (int i = threadIdx.x; i < hw / 4; i += kBlock) {
+            float4 v = x4[i];
+            if (pro) {
+                v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            acc[0] += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += kBlock) {
+            float v = x[base + i];
+            if (pro) {
+                v = fmaf(v, sc, sh);
+                if (relu) v = fmaxf(v, 0.f);
+            }
+            acc[0] += v;
+        }
+    }
     block_sum<1>(acc, red);
     if (threadIdx.x == 0) out[blockIdx.x] = acc[0] / (float)hw;
 }
@@ -416,55 +476,105 @@ __global__ __launch_bounds__(kBlock) void outer_sum_kernel(const float* __restri
 // ---------------------------------------------------------------------------
 // residual tail: r = relu(sc' + a*s[n,c]); p = drop[n,c] * maxpool2x2(r)
 // ---------------------------------------------------------------------------
-// sc' = sc*sc_scale[c] + sc_shift[c] when the shortcut is a projection (BN of the 1x1 conv).
-__global__ __launch_bounds__(kBlock) void tail_fwd_kernel(
-    const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ sc,
-    const float* __restrict__ sc_scale, const float* __restrict__ sc_shift,
-    const float* __restrict__ drop, float* __restrict__ r, float* __restrict__ p, int c, int h,
-    int w) {
-    const int plane = blockIdx.x, ch = plane % c;
-    const float sv = s ? s[plane] : 1.f;
-    const float ks = sc_scale ? sc_scale[ch] : 1.f, kb = sc_shift ? sc_shift[ch] : 0.f;
-    const float dv = drop ? drop[plane] : 1.f;
-    const int ph = h / 2, pw = w / 2;
+// a = relu(y*a_scale[c]+a_shift[c]) when a_scale is given (BN2+ReLU fused), else a = y;
+// sc' = act(sc*sc_scale[c] + sc_shift[c]) (projection BN, or the stem's BN+ReLU) or sc.
+struct TailArgs {
+    const float* y;
+    const float* a_scale;
+    const float* a_shift;
+    const float* s;
+    const float* sc;
+    const float* sc_scale;
+    const float* sc_shift;
+    const float* drop;
+    int sc_relu;
+    int c, h, w;
+};
+
+__device__ __forceinline__ float tail_r(const TailArgs& t, float yv, float scv, float as, float ab,
+                                        float sv, float ks, float kb) {
+    float a = yv;
+    if (t.a_scale) a = fmaxf(fmaf(yv, as, ab), 0.f);
+    float sh = scv;
+    if (t.sc_scale) {
+        sh = fmaf(scv, ks, kb);
+        if (t.sc_relu) sh = fmaxf(sh, 0.f);
+    }
+    return fmaxf(sh + a * sv, 0.f);
+}
+
+__global__ __launch_bounds__(kBlock) void tail_fwd_kernel(TailArgs t, float* __restrict__ r,
+                                                          float* __restrict__ p) {
+    const int plane = blockIdx.x, ch = plane % t.c;
+    const float sv = t.s ? t.s[plane] : 1.f;
+    const float as = t.a_scale ? t.a_scale[ch] : 1.f, ab = t.a_scale ? t.a_shift[ch] : 0.f;
+    const float ks = t.sc_scale ? t.sc_scale[ch] : 1.f, kb = t.sc_scale ? t.sc_shift[ch] : 0.f;
+    const float dv = t.drop ? t.drop[plane] : 1.f;
+    const int h = t.h, w = t.w, ph = h / 2, pw = w / 2;
     const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
-    // one thread per pooled output (2x2 window); odd trailing row/col handled below
-    for (int t = blockIdx.y * kBlock + threadIdx.x; t < ph * pw; t += gridDim.y * kBlock) {
-        const int py = t / pw, px = t - py * pw;
-        float mx = 0.f;  // r >= 0
+    if ((w & 3) == 0) {
+        // one thread = 2 pooled outputs: a 2x4 window pair, float4 rows
+        const int pw2 = pw / 2;
+        for (int q = blockIdx.y * kBlock + threadIdx.x; q < ph * pw2; q += gridDim.y * kBlock) {
+            const int py = q / pw2, px2 = q - py * pw2;
+            float m0 = 0.f, m1 = 0.f;  // r >= 0
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            const size_t o = base + (size_t)(2 * py + dy) * w + 2 * px;
-            const float2 av = *reinterpret_cast<const float2*>(a + o);
-            const float2 sv2 = *reinterpret_cast<const float2*>(sc + o);
-            float2 rv;
-            rv.x = fmaxf(fmaf(sv2.x, ks, kb) + av.x * sv, 0.f);
-            rv.y = fmaxf(fmaf(sv2.y, ks, kb) + av.y * sv, 0.f);
-            *reinterpret_cast<float2*>(r + o) = rv;
-            mx = fmaxf(mx, fmaxf(rv.x, rv.y));
+            for (int dy = 0; dy < 2; ++dy) {
+                const size_t o = base + (size_t)(2 * py + dy) * w + 4 * px2;
+                const float4 yv = *reinterpret_cast<const float4*>(t.y + o);
+                const float4 sv4 = *reinterpret_cast<const float4*>(t.sc + o);
+                float4 rv;
+                rv.x = tail_r(t, yv.x, sv4.x, as, ab, sv, ks, kb);
+                rv.y = tail_r(t, yv.y, sv4.y, as, ab, sv, ks, kb);
+                rv.z = tail_r(t, yv.z, sv4.z, as, ab, sv, ks, kb);
+                rv.w = tail_r(t, yv.w, sv4.w, as, ab, sv, ks, kb);
+                *reinterpret_cast<float4*>(r + o) = rv;
+                m0 = fmaxf(m0, fmaxf(rv.x, rv.y));
+                m1 = fmaxf(m1, fmaxf(rv.z, rv.w));
+            }
+            *reinterpret_cast<float2*>(p + pbase + (size_t)py * pw + 2 * px2) = make_float2(m0 * dv, m1 * dv);
         }
-        p[pbase + t] = mx * dv;
+    } else {
+        for (int q = blockIdx.y * kBlock + threadIdx.x; q < ph * pw; q += gridDim.y * kBlock) {
+            const int py = q / pw, px = q - py * pw;
+            float mx = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const size_t o = base + (size_t)(2 * py + dy) * w + 2 * px;
+                const float r0 = tail_r(t, t.y[o], t.sc[o], as, ab, sv, ks, kb);
+                const float r1 = tail_r(t, t.y[o + 1], t.sc[o + 1], as, ab, sv, ks, kb);
+                r[o] = r0;
+                r[o + 1] = r1;
+                mx = fmaxf(mx, fmaxf(r0, r1));
+            }
+            p[pbase + q] = mx * dv;
+        }
     }
     // leftover row / column when h or w is odd (not pooled, but r must be complete)
     if ((h & 1) || (w & 1)) {
-        for (int t = blockIdx.y * kBlock + threadIdx.x; t < h * w; t += gridDim.y * kBlock) {
-            const int y = t / w, x = t - y * w;
+        for (int q = blockIdx.y * kBlock + threadIdx.x; q < h * w; q += gridDim.y * kBlock) {
+            const int y = q / w, x = q - y * w;
             if (y >= 2 * ph || x >= 2 * pw)
-                r[base + t] = fmaxf(fmaf(sc[base + t], ks, kb) + a[base + t] * sv, 0.f);
+                r[base + q] = tail_r(t, t.y[base + q], t.sc[base + q], as, ab, sv, ks, kb);
         }
     }
 }
 
-// dr = dp*drop routed to the first max of each 2x2 window where r > 0; ds[n,c] = sum dr*a
+// dr = dp*drop routed to the first max of each 2x2 window where r > 0;
+// ds[n,c] = sum dr*a with a = relu(y*a_scale+a_shift) (or y)
 __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(const float* __restrict__ dp,
                                                           const float* __restrict__ r,
-                                                          const float* __restrict__ a,
+                                                          const float* __restrict__ y,
+                                                          const float* __restrict__ a_scale,
+                                                          const float* __restrict__ a_shift,
                                                           const float* __restrict__ drop,
                                                           float* __restrict__ dr,
-                                                          float* __restrict__ ds, int h, int w) {
+                                                          float* __restrict__ ds, int c, int h,
+                                                          int w) {
     __shared__ float red[4];
-    const int plane = blockIdx.x;
+    const int plane = blockIdx.x, ch = plane % c;
     const float dv = drop ? drop[plane] : 1.f;
+    const float as = a_scale ? a_scale[ch] : 1.f, ab = a_scale ? a_shift[ch] : 0.f;
     const int ph = h / 2, pw = w / 2;
     const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
     float acc[1] = {0.f};
@@ -481,19 +591,18 @@ __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(const float* __restric
         if (r1.x > best) { best = r1.x; bi = 2; }
         if (r1.y > best) { best = r1.y; bi = 3; }
         const float gg = best > 0.f ? g : 0.f;
-        float2 d0 = make_float2(bi == 0 ? gg : 0.f, bi == 1 ? gg : 0.f);
-        float2 d1 = make_float2(bi == 2 ? gg : 0.f, bi == 3 ? gg : 0.f);
-        *reinterpret_cast<float2*>(dr + o0) = d0;
-        *reinterpret_cast<float2*>(dr + o1) = d1;
-        if (a != nullptr) {
-            const float av = bi == 0 ? a[o0] : (bi == 1 ? a[o0 + 1] : (bi == 2 ? a[o1] : a[o1 + 1]));
+        *reinterpret_cast<float2*>(dr + o0) = make_float2(bi == 0 ? gg : 0.f, bi == 1 ? gg : 0.f);
+        *reinterpret_cast<float2*>(dr + o1) = make_float2(bi == 2 ? gg : 0.f, bi == 3 ? gg : 0.f);
+        if (ds != nullptr && gg != 0.f) {
+            float av = y[bi < 2 ? o0 + bi : o1 + (bi - 2)];
+            if (a_scale) av = fmaxf(fmaf(av, as, ab), 0.f);
             acc[0] += gg * av;
         }
     }
     if ((h & 1) || (w & 1)) {
         for (int t = threadIdx.x; t < h * w; t += kBlock) {
-            const int y = t / w, x = t - y * w;
-            if (y >= 2 * ph || x >= 2 * pw) dr[base + t] = 0.f;
+            const int yy = t / w, x = t - yy * w;
+            if (yy >= 2 * ph || x >= 2 * pw) dr[base + t] = 0.f;
         }
     }
     if (ds != nullptr) {
@@ -714,11 +823,11 @@ int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
     return lf::check_launch("lf_bn_infer");
 }
 
-int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* mask,
-                  const float* y, const float* mean, const float* invstd, const float* gamma,
-                  float* dy, float* dgamma, float* dbeta, int n, int c, int hw, void* workspace,
-                  size_t ws_bytes, lf_stream_t stream) {
-    LF_REQUIRE(g && y && mean && invstd && gamma && dy && dgamma && dbeta && workspace,
+int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* y,
+                  const float* mean, const float* invstd, const float* scale, const float* shift,
+                  int relu, const float* gamma, float* dy, float* dgamma, float* dbeta, int n, int c,
+                  int hw, void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(g && y && mean && invstd && scale && shift && gamma && dy && dgamma && dbeta && workspace,
                "lf_bn_bwd: null buffer");
     LF_REQUIRE(n > 0 && c > 0 && hw > 0 && c <= 65535 && (long long)n * c < (1LL << 31),
                "lf_bn_bwd: bad dims n=%d c=%d hw=%d", n, c, hw);
@@ -726,20 +835,22 @@ int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, co
         lf::set_error("lf_bn_bwd: workspace %zu < %zu", ws_bytes, lf_bn_workspace(c));
         return LF_ERR_WORKSPACE;
     }
-    BnBwdArgs a{g, alpha_nc, add_nc, mask, y, mean, invstd, n, c, hw};
+    BnBwdArgs a{g, alpha_nc, add_nc, y, mean, invstd, scale, shift, relu, n, c, hw};
     hipStream_t s = lf::as_stream(stream);
     float* part = static_cast<float*>(workspace);
     bn_bwd_reduce_kernel<<<dim3(kBnSplit, c), kBlock, 0, s>>>(a, part);
     bn_bwd_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(part, c, dgamma, dbeta);
-    bn_bwd_apply_kernel<<<dim3(n * c, plane_grid(hw)), kBlock, 0, s>>>(
+    bn_bwd_apply_kernel<<<dim3(n * c, plane_grid((hw & 3) ? hw : hw / 4)), kBlock, 0, s>>>(
         a, gamma, dgamma, dbeta, 1.0f / ((float)n * (float)hw), dy);
     return lf::check_launch("lf_bn_bwd");
 }
 
-int lf_gap_f32(const float* x, float* out, int planes, int hw, lf_stream_t stream) {
+int lf_gap_f32(const float* x, float* out, int planes, int hw, int c, const float* scale,
+               const float* shift, int relu, lf_stream_t stream) {
     LF_REQUIRE(x && out, "lf_gap: null buffer");
-    LF_REQUIRE(planes > 0 && hw > 0, "lf_gap: bad dims planes=%d hw=%d", planes, hw);
-    gap_kernel<<<planes, kBlock, 0, lf::as_stream(stream)>>>(x, out, hw);
+    LF_REQUIRE(planes > 0 && hw > 0 && c > 0, "lf_gap: bad dims planes=%d hw=%d c=%d", planes, hw, c);
+    LF_REQUIRE((scale == nullptr) == (shift == nullptr), "lf_gap: scale/shift must both be set");
+    gap_kernel<<<planes, kBlock, 0, lf::as_stream(stream)>>>(x, out, hw, c, scale, shift, relu);
     return lf::check_launch("lf_gap");
 }
 
@@ -789,26 +900,32 @@ int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float*
     return lf::check_launch("lf_se_bwd");
 }
 
-int lf_block_tail_fwd_f32(const float* a, const float* s, const float* sc, const float* sc_scale,
-                          const float* sc_shift, const float* drop, float* r, float* p, int n,
-                          int c, int h, int w, lf_stream_t stream) {
-    LF_REQUIRE(a && sc && r && p, "lf_block_tail_fwd: null buffer");
+int lf_block_tail_fwd_f32(const float* y, const float* a_scale, const float* a_shift,
+                          const float* s, const float* sc, const float* sc_scale,
+                          const float* sc_shift, int sc_relu, const float* drop, float* r, float* p,
+                          int n, int c, int h, int w, lf_stream_t stream) {
+    LF_REQUIRE(y && sc && r && p, "lf_block_tail_fwd: null buffer");
     LF_REQUIRE(n > 0 && c > 0 && h > 1 && w > 1 && (long long)n * c < (1LL << 31),
                "lf_block_tail_fwd: bad dims n=%d c=%d h=%d w=%d", n, c, h, w);
-    LF_REQUIRE((w & 1) == 0, "lf_block_tail_fwd: width must be even (float2 rows)");
+    LF_REQUIRE((w & 1) == 0, "lf_block_tail_fwd: width must be even");
     LF_REQUIRE((sc_scale == nullptr) == (sc_shift == nullptr), "lf_block_tail_fwd: sc_scale/sc_shift");
-    tail_fwd_kernel<<<dim3(n * c, plane_grid((h / 2) * (w / 2))), kBlock, 0, lf::as_stream(stream)>>>(
-        a, s, sc, sc_scale, sc_shift, drop, r, p, c, h, w);
+    LF_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "lf_block_tail_fwd: a_scale/a_shift");
+    TailArgs t{y, a_scale, a_shift, s, sc, sc_scale, sc_shift, drop, sc_relu, c, h, w};
+    const int items = (w & 3) == 0 ? (h / 2) * (w / 4) : (h / 2) * (w / 2);
+    tail_fwd_kernel<<<dim3(n * c, plane_grid(items)), kBlock, 0, lf::as_stream(stream)>>>(t, r, p);
     return lf::check_launch("lf_block_tail_fwd");
 }
 
-int lf_block_tail_bwd_f32(const float* dp, const float* r, const float* a, const float* drop,
-                          float* dr, float* ds, int n, int c, int h, int w, lf_stream_t stream) {
+int lf_block_tail_bwd_f32(const float* dp, const float* r, const float* y, const float* a_scale,
+                          const float* a_shift, const float* drop, float* dr, float* ds, int n,
+                          int c, int h, int w, lf_stream_t stream) {
     LF_REQUIRE(dp && r && dr, "lf_block_tail_bwd: null buffer");
     LF_REQUIRE(n > 0 && c > 0 && h > 1 && w > 1, "lf_block_tail_bwd: bad dims n=%d c=%d h=%d w=%d", n, c, h, w);
     LF_REQUIRE((w & 1) == 0, "lf_block_tail_bwd: width must be even (float2 rows)");
-    LF_REQUIRE((a == nullptr) == (ds == nullptr), "lf_block_tail_bwd: a and ds go together");
-    tail_bwd_kernel<<<n * c, kBlock, 0, lf::as_stream(stream)>>>(dp, r, a, drop, dr, ds, h, w);
+    LF_REQUIRE((y == nullptr) == (ds == nullptr), "lf_block_tail_bwd: y and ds go together");
+    LF_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "lf_block_tail_bwd: a_scale/a_shift");
+    tail_bwd_kernel<<<n * c, kBlock, 0, lf::as_stream(stream)>>>(dp, r, y, a_scale, a_shift, drop, dr, ds,
+                                                                c, h, w);
     return lf::check_launch("lf_block_tail_bwd");
 }
 

@@ -244,41 +244,43 @@ class LeafCNN:
         n, _c, h, w = x0.shape
         P, B = self.p, lambda k, shape: self._buf(n, k, shape)
         sv: Dict[str, Any] = {"x0": x0, "n": n}
+        # Activations a = relu(BN(y)) are never materialised: every consumer (the next conv,
+        # wgrad, GAP, the residual tail, BN backward) applies scale/shift(+ReLU) while it reads y.
         y = nn.conv2d(x0, P["stem.w"], 3, out=B("stem.y", (n, self.widths[0], h, w)))
         st = self._bn("stem.bn", y, training)
-        a = nn.scale_shift_act(y, st[2], st[3], True, out=B("stem.a", y.shape))
-        sv["stem.y"], sv["stem.a"] = y, a
+        sv["stem.y"] = y
+        xin, xin_st = y, st  # block input = relu(xin*xin_st[2]+xin_st[3]) (None = already final)
         cin = self.widths[0]
         for i, f in enumerate(self.widths):
             p = f"s{i}."
-            xin = a
-            y1 = nn.conv2d(xin, P[p + "c1.w"], 3, out=B(p + "y1", (n, f, h, w)))
+            pro = (xin_st[2], xin_st[3], True) if xin_st is not None else (None, None, False)
+            y1 = nn.conv2d(xin, P[p + "c1.w"], 3, pro[0], pro[1], pro[2], out=B(p + "y1", (n, f, h, w)))
             st1 = self._bn(p + "bn1", y1, training)
-            a1 = nn.scale_shift_act(y1, st1[2], st1[3], True, out=B(p + "a1", y1.shape))
-            y2 = nn.conv2d(a1, P[p + "c2.w"], 3, out=B(p + "y2", y1.shape))
+            y2 = nn.conv2d(y1, P[p + "c2.w"], 3, st1[2], st1[3], True, out=B(p + "y2", y1.shape))
             st2 = self._bn(p + "bn2", y2, training)
-            a2 = nn.scale_shift_act(y2, st2[2], st2[3], True, out=B(p + "a2", y1.shape))
             s = None
             if self.use_se:
-                m = nn.gap(a2, out=B(p + "m", (n, f)))
+                m = nn.gap(y2, out=B(p + "m", (n, f)), scale=st2[2], shift=st2[3], relu=True)
                 z1 = B(p + "z1", (n, f // 8))
                 s = nn.se_fwd(m, P[p + "se.w1"], P[p + "se.b1"], P[p + "se.w2"], P[p + "se.b2"], z1,
                               B(p + "s", (n, f)))
                 sv[p + "m"], sv[p + "z1"] = m, z1
             if cin != f:
-                yp = nn.conv2d(xin, P[p + "proj.w"], 1, out=B(p + "yp", y1.shape))
+                yp = nn.conv2d(xin, P[p + "proj.w"], 1, pro[0], pro[1], pro[2],
+                               out=B(p + "yp", y1.shape))
                 stp = self._bn(p + "bnp", yp, training)
-                sc, scs, scb = yp, stp[2], stp[3]
+                sc, scs, scb, scr = yp, stp[2], stp[3], False
                 sv[p + "yp"] = yp
             else:
-                sc, scs, scb = xin, None, None
+                sc, scs, scb, scr = xin, pro[0], pro[1], pro[2]
             drop = drops[i] if (training and drops is not None) else None
             r = B(p + "r", y1.shape)
             pooled = B(p + "p", (n, f, h // 2, w // 2))
-            nn.block_tail_fwd(a2, s, sc, scs, scb, drop, r, pooled)
-            sv.update({p + "xin": xin, p + "y1": y1, p + "a1": a1, p + "y2": y2, p + "a2": a2,
-                       p + "s": s, p + "r": r, p + "drop": drop, p + "hw": (h, w)})
-            a, cin, h, w = pooled, f, h // 2, w // 2
+            nn.block_tail_fwd(y2, st2[2], st2[3], s, sc, scs, scb, scr, drop, r, pooled)
+            sv.update({p + "xin": xin, p + "xin_st": xin_st, p + "y1": y1, p + "y2": y2, p + "s": s,
+                       p + "r": r, p + "drop": drop, p + "hw": (h, w)})
+            xin, xin_st, cin, h, w = pooled, None, f, h // 2, w // 2
+        a = xin
         g = nn.gap(a, out=B("g", (n, self.widths[-1])))
         feat = g
         if training and top_drop is not None:
@@ -313,43 +315,45 @@ class LeafCNN:
             cin = self.widths[i - 1] if i > 0 else self.widths[0]
             p = f"s{i}."
             h, w = sv[p + "hw"]
-            xin, y1, a1, y2, a2 = (sv[p + k] for k in ("xin", "y1", "a1", "y2", "a2"))
+            xin, xin_st, y1, y2 = (sv[p + k] for k in ("xin", "xin_st", "y1", "y2"))
+            pro = (xin_st[2], xin_st[3], True) if xin_st is not None else (None, None, False)
             s, r, drop = sv[p + "s"], sv[p + "r"], sv[p + "drop"]
+            st1, st2 = self.stats[p + "bn1"], self.stats[p + "bn2"]
             gA = B(p + "gA", y1.shape)
             gB = B(p + "gB", y1.shape)
             gC = B(p + "gC", y1.shape)
             ds = B(p + "ds", (n, f)) if self.use_se else None
-            nn.block_tail_bwd(dp, r, a2 if self.use_se else None, drop, gA, ds)
+            nn.block_tail_bwd(dp, r, y2 if self.use_se else None, st2[2] if self.use_se else None,
+                              st2[3] if self.use_se else None, drop, gA, ds)
             add_nc = None
             if self.use_se:
                 dm = B(p + "dm", (n, f))
                 nn.se_bwd(ds, sv[p + "m"], sv[p + "z1"], s, P[p + "se.w1"], P[p + "se.w2"], dm,
                           G[p + "se.w1"], G[p + "se.b1"], G[p + "se.w2"], G[p + "se.b2"])
                 add_nc = dm.mul_(1.0 / (h * w))
-            # conv2 branch: dz2 = (dr*s + dm/HW) * (a2>0) -> BN2 backward -> dy2 (gB)
-            nn.bn_bwd(gA, y2, self.stats[p + "bn2"], P[p + "bn2.gamma"], G[p + "bn2.gamma"],
-                      G[p + "bn2.beta"], alpha_nc=s, add_nc=add_nc, mask=a2, out=gB)
-            nn.conv2d_wgrad(a1, gB, 3, out=G[p + "c2.w"])
+            # conv2 branch: dz2 = (dr*s + dm/HW) * [a2 > 0] -> BN2 backward -> dy2 (gB)
+            nn.bn_bwd(gA, y2, st2, P[p + "bn2.gamma"], G[p + "bn2.gamma"], G[p + "bn2.beta"], True,
+                      alpha_nc=s, add_nc=add_nc, out=gB)
+            nn.conv2d_wgrad(y1, gB, 3, st1[2], st1[3], True, out=G[p + "c2.w"])
             nn.conv2d(gB, self._dgrad_w(p + "c2.w", 3), 3, out=gC)          # da1
-            nn.bn_bwd(gC, y1, self.stats[p + "bn1"], P[p + "bn1.gamma"], G[p + "bn1.gamma"],
-                      G[p + "bn1.beta"], mask=a1, out=gB)                     # dy1
-            nn.conv2d_wgrad(xin, gB, 3, out=G[p + "c1.w"])
-            need_dx = True
+            nn.bn_bwd(gC, y1, st1, P[p + "bn1.gamma"], G[p + "bn1.gamma"], G[p + "bn1.beta"], True,
+                      out=gB)                                                 # dy1
+            nn.conv2d_wgrad(xin, gB, 3, pro[0], pro[1], pro[2], out=G[p + "c1.w"])
             if cin != f:
-                nn.bn_bwd(gA, sv[p + "yp"], self.stats[p + "bnp"], P[p + "bnp.gamma"],
-                          G[p + "bnp.gamma"], G[p + "bnp.beta"], out=gC)       # dyp
-                nn.conv2d_wgrad(xin, gC, 1, out=G[p + "proj.w"])
+                stp = self.stats[p + "bnp"]
+                nn.bn_bwd(gA, sv[p + "yp"], stp, P[p + "bnp.gamma"], G[p + "bnp.gamma"],
+                          G[p + "bnp.beta"], False, out=gC)                   # dyp
+                nn.conv2d_wgrad(xin, gC, 1, pro[0], pro[1], pro[2], out=G[p + "proj.w"])
                 dx = B(p + "dx", xin.shape)
                 nn.conv2d(gC, self._dgrad_w(p + "proj.w", 1), 1, out=dx)
             else:
                 dx = gA  # identity shortcut: dx starts as dr
-            if need_dx:
-                nn.conv2d(gB, self._dgrad_w(p + "c1.w", 3), 3, out=dx, accumulate=True)
+            nn.conv2d(gB, self._dgrad_w(p + "c1.w", 3), 3, out=dx, accumulate=True)
             dp = dx
-        # stem: dp is the gradient wrt stem.a
+        # stem: dp is the gradient wrt relu(BN(stem.y))
         gS = self._buf(n, "stem.g", sv["stem.y"].shape)
         nn.bn_bwd(dp, sv["stem.y"], self.stats["stem.bn"], P["stem.bn.gamma"], G["stem.bn.gamma"],
-                  G["stem.bn.beta"], mask=sv["stem.a"], out=gS)
+                  G["stem.bn.beta"], True, out=gS)
         nn.conv2d_wgrad(sv["x0"], gS, 3, out=G["stem.w"])
 
     def _dgrad_w(self, name: str, k: int) -> torch.Tensor:

@@ -161,11 +161,12 @@ def bn_infer_scale_shift(gamma, beta, mmean, mvar, stats, eps=1e-3):
     return stats
 
 
-def bn_bwd(g, y, stats, gamma, dgamma, dbeta, alpha_nc=None, add_nc=None, mask=None, out=None):
+def bn_bwd(g, y, stats, gamma, dgamma, dbeta, relu: bool, alpha_nc=None, add_nc=None, out=None):
+    """BatchNorm backward; the ReLU mask (relu=True) is recomputed from y and stats[2:4]."""
     _chk(g, _F32, "bn_bwd.g", 4)
     _chk(y, _F32, "bn_bwd.y", 4)
-    if g.shape != y.shape or (mask is not None and mask.shape != y.shape):
-        raise ValueError("bn_bwd: g, y (and mask) must share a shape")
+    if g.shape != y.shape:
+        raise ValueError("bn_bwd: g and y must share a shape")
     n, c, h, w = y.shape
     for t in (alpha_nc, add_nc):
         if t is not None:
@@ -175,18 +176,21 @@ def bn_bwd(g, y, stats, gamma, dgamma, dbeta, alpha_nc=None, add_nc=None, mask=N
     if out is None:
         out = torch.empty_like(y)
     ws = _workspace(_lib.load().lf_bn_workspace(c), y.device)
-    _lib.call("lf_bn_bwd_f32", g.data_ptr(), _ptr(alpha_nc), _ptr(add_nc), _ptr(mask), y.data_ptr(),
-              stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(), out.data_ptr(),
-              dgamma.data_ptr(), dbeta.data_ptr(), n, c, h * w, ws.data_ptr(), ws.numel(), _stream())
+    _lib.call("lf_bn_bwd_f32", g.data_ptr(), _ptr(alpha_nc), _ptr(add_nc), y.data_ptr(),
+              stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+              1 if relu else 0, gamma.data_ptr(), out.data_ptr(), dgamma.data_ptr(),
+              dbeta.data_ptr(), n, c, h * w, ws.data_ptr(), ws.numel(), _stream())
     return out
 
 
-def gap(x, out=None):
+def gap(x, out=None, scale=None, shift=None, relu: bool = False):
+    """[N,C,H,W] -> [N,C] mean of act(x*scale[c]+shift[c]) (plain mean without scale)."""
     _chk(x, _F32, "gap.x", 4)
     n, c, h, w = x.shape
     if out is None:
         out = torch.empty((n, c), dtype=_F32, device=x.device)
-    _lib.call("lf_gap_f32", x.data_ptr(), out.data_ptr(), n * c, h * w, _stream())
+    _lib.call("lf_gap_f32", x.data_ptr(), out.data_ptr(), n * c, h * w, c, _ptr(scale), _ptr(shift),
+              1 if relu else 0, _stream())
     return out
 
 
@@ -221,23 +225,24 @@ def se_bwd(ds, m, z1, s, w1, w2, dm, dw1, db1, dw2, db2):
     return dm
 
 
-def block_tail_fwd(a, s, sc, sc_scale, sc_shift, drop, r, p):
-    _chk(a, _F32, "block_tail_fwd.a", 4)
-    n, c, h, w = a.shape
-    if sc.shape != a.shape or r.shape != a.shape or tuple(p.shape) != (n, c, h // 2, w // 2):
+def block_tail_fwd(y, a_scale, a_shift, s, sc, sc_scale, sc_shift, sc_relu, drop, r, p):
+    _chk(y, _F32, "block_tail_fwd.y", 4)
+    n, c, h, w = y.shape
+    if sc.shape != y.shape or r.shape != y.shape or tuple(p.shape) != (n, c, h // 2, w // 2):
         raise ValueError("block_tail_fwd: shape mismatch")
-    _lib.call("lf_block_tail_fwd_f32", a.data_ptr(), _ptr(s), sc.data_ptr(), _ptr(sc_scale),
-              _ptr(sc_shift), _ptr(drop), r.data_ptr(), p.data_ptr(), n, c, h, w, _stream())
+    _lib.call("lf_block_tail_fwd_f32", y.data_ptr(), _ptr(a_scale), _ptr(a_shift), _ptr(s),
+              sc.data_ptr(), _ptr(sc_scale), _ptr(sc_shift), 1 if sc_relu else 0, _ptr(drop),
+              r.data_ptr(), p.data_ptr(), n, c, h, w, _stream())
     return r, p
 
 
-def block_tail_bwd(dp, r, a, drop, dr, ds):
+def block_tail_bwd(dp, r, y, a_scale, a_shift, drop, dr, ds):
     _chk(r, _F32, "block_tail_bwd.r", 4)
     n, c, h, w = r.shape
     if tuple(dp.shape) != (n, c, h // 2, w // 2) or dr.shape != r.shape:
         raise ValueError("block_tail_bwd: shape mismatch")
-    _lib.call("lf_block_tail_bwd_f32", dp.data_ptr(), r.data_ptr(), _ptr(a), _ptr(drop),
-              dr.data_ptr(), _ptr(ds), n, c, h, w, _stream())
+    _lib.call("lf_block_tail_bwd_f32", dp.data_ptr(), r.data_ptr(), _ptr(y), _ptr(a_scale),
+              _ptr(a_shift), _ptr(drop), dr.data_ptr(), _ptr(ds), n, c, h, w, _stream())
     return dr, ds
 
 
