@@ -41,9 +41,12 @@ TRAIN_GFLOP_PER_IMG = 18.757  # 3 x 3.126 GMAC x 2
 FWD_NAMES = {0: "conv_mfma_kernel<T,32,8,1,1,4,2>", 1: "conv_mfma_kernel<T,32,8,1,2,4,2>",
              2: "conv_mfma_kernel<T,16,16,1,1,4,2>", 3: "conv_mfma_kernel<T,16,16,1,2,4,2>",
              4: "conv_mfma_kernel<T,28,8,4,1,1,7>", 5: "conv_mfma_kernel<T,32,8,2,2,2,4>"}
-WG_NAMES = {0: "wgrad_mfma_kernel<T,32,4,1,1,4>", 1: "wgrad_mfma_kernel<T,16,8,1,2,2>",
-            2: "wgrad_mfma_kernel<T,16,4,2,2,1>", 3: "wgrad_mfma_kernel<T,28,2,2,2,1>",
-            4: "wgrad_mfma_kernel<T,32,4,1,2,2>", 5: "wgrad_smallcin_kernel<32,8>"}
+WG_NAMES3 = {0: "wgrad3_kernel<32,4,1,1,4>", 1: "wgrad3_kernel<16,8,1,2,2>",
+             2: "wgrad3_kernel<16,4,2,2,1>", 3: "wgrad3_kernel<28,2,2,2,1>",
+             4: "wgrad3_kernel<32,4,1,2,2>", 5: "wgrad_smallcin_kernel<32,8>"}
+WG_NAMES1 = {0: "wgrad_mfma_kernel<1,32,4,1,1,4>", 1: "wgrad_mfma_kernel<1,16,8,1,2,2>",
+             2: "wgrad_mfma_kernel<1,16,4,2,2,1>", 3: "wgrad_mfma_kernel<1,28,2,2,2,1>",
+             4: "wgrad_mfma_kernel<1,32,4,1,2,2>"}
 
 
 class KernelTimer:
@@ -72,7 +75,7 @@ class KernelTimer:
                 kname = FWD_NAMES[lib.lf_conv2d_variant(h, w, cout)].replace("T", str(k * k))
             else:
                 n, cin, h, w, cout, k = args[2:8]
-                kname = WG_NAMES[lib.lf_conv2d_wgrad_variant(n, cin, h, w, cout, k)].replace("T", str(k * k))
+                kname = (WG_NAMES3 if k == 3 else WG_NAMES1)[lib.lf_conv2d_wgrad_variant(n, cin, h, w, cout, k)]
             flop = 2.0 * n * h * w * cin * cout * k * k
             timer.records.append((kname, flop, e0, e1))
             return rc

@@ -598,6 +598,233 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
     }
 }
 
+
+// 3x3 wgrad with the filter rows spread over waves: a workgroup of 3*WCI*WCO*KSPL waves owns a
+// (32*WCI ci) x (32*WCO co) weight block; wave (q, tr, k) accumulates the three taps of filter
+// row tr (48 accumulators) over its K-split share of each tile's rows.  With so few
+// accumulators the next item's tiles are prefetched into registers during the MFMAs.
+template <int TW, int TH, int WCI, int WCO, int KSPL>
+__global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(WgradArgs p) {
+    constexpr int NT = 64 * 3 * WCI * WCO * KSPL;
+    static_assert(TH % KSPL == 0 && TW % 4 == 0, "rows split across waves, float4 rows");
+    constexpr int PW = TW + 2, PH = TH + 2;
+    constexpr int PP = (PW * PH) | 1;  // odd plane pitch: 32 lanes on 32 channels hit 32 banks
+    constexpr int DP = (TW * TH) | 1;
+    constexpr int CI_T = 32 * WCI, CO_T = 32 * WCO, NQ = WCI * WCO;
+    constexpr int XSZ = CI_T * PP, DSZ = CO_T * DP;
+    constexpr int RED = KSPL > 1 ? 3 * 3 * 1024 : 0;  // one (ci,co) block's three row-waves
+    constexpr int LDSF = XSZ + DSZ > RED ? XSZ + DSZ : RED;
+    constexpr int TW4 = TW / 4, VROW = TW4 + 2;
+    constexpr int NXI = CI_T * PH * VROW, XPT = (NXI + NT - 1) / NT;
+    constexpr int NDI = CO_T * TH * TW4, DPT = (NDI + NT - 1) / NT;
+    __shared__ float lds[LDSF];
+    float* lx = lds;
+    float* ld = lds + XSZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tr = wid % 3, rest = wid / 3;
+    const int w_ci = rest % WCI, w_co = (rest / WCI) % WCO, w_k = rest / NQ;
+    const int ci0 = blockIdx.y * CI_T, co0 = blockIdx.z * CO_T;
+    const int khalf = lane >> 5, j = lane & 31;
+    const size_t hw = (size_t)p.h * p.wd;
+    const unsigned uhw = (unsigned)hw;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int abase = (w_ci * 32 + j) * PP + tr * PW + khalf;
+    const int bbase = (w_co * 32 + j) * DP + khalf;
+    const bool pro = p.in_scale != nullptr;
+
+    auto compute_item = [&]() {
+        constexpr int ROWS = TH / KSPL;
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int row = w_k * ROWS + rr;
+#pragma unroll 4
+            for (int xx = 0; xx < TW; xx += 2) {
+                const float b = ld[bbase + row * TW + xx];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float a = lx[abase + row * PW + xx + dx];
+                    acc[dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[dx], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int first = blockIdx.x * p.items_per_split;
+    const int last = min(first + p.items_per_split, p.items);
+    const int tiles = p.tiles_x * p.tiles_y;
+
+    if (p.vec_ok) {  // every tile is full in x (host guarantees W % TW == 0 for this path)
+        float4 xv[XPT], dv[DPT];
+        unsigned xok = 0;
+        auto load_item = [&](int item) {
+            const int n = item / tiles, t = item - n * tiles;
+            const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
+            const float* xin = p.x + (size_t)n * p.cin * hw;
+            const float* din = p.dy + (size_t)n * p.cout * hw;
+            xok = 0;
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int e = tid + i * NT;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NXI) {
+                    const int c = e / (PH * VROW), rem = e - c * (PH * VROW);
+                    const int py = rem / VROW, slot = rem - py * VROW;
+                    const int gc = ci0 + c, gy = ty0 + py - 1;
+                    if (gc < p.cin && gy >= 0 && gy < p.h) {
+                        const float* row = xin + (unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd;
+                        if (slot < TW4) {
+                            v = *reinterpret_cast<const float4*>(row + tx0 + 4 * slot);
+                            xok |= 1u << i;
+                        } else {
+                            const int gx = slot == TW4 ? tx0 - 1 : tx0 + TW;
+                            if (gx >= 0 && gx < p.wd) {
+                                v.x = row[gx];
+                                xok |= 1u << i;
+                            }
+                        }
+                    }
+                }
+                xv[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < DPT; ++i) {
+                const int e = tid + i * NT;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NDI) {
+                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                    const int py = rem / TW4, slot = rem - py * TW4;
+                    const int gc = co0 + c, gy = ty0 + py;
+                    if (gc < p.cout && gy < p.h)
+                        v = *reinterpret_cast<const float4*>(din + (unsigned)gc * uhw +
+                                                             (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                }
+                dv[i] = v;
+            }
+        };
+        auto store_item = [&]() {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int e = tid + i * NT;
+                if (e < NXI) {
+                    const int c = e / (PH * VROW), rem = e - c * (PH * VROW);
+                    const int py = rem / VROW, slot = rem - py * VROW;
+                    float4 v = xv[i];
+                    if (pro && (xok >> i & 1u)) {
+                        const float sc = p.in_scale[ci0 + c], sh = p.in_shift[ci0 + c];
+                        v.x = pro_apply(v.x, sc, sh, p.in_relu);
+                        v.y = pro_apply(v.y, sc, sh, p.in_relu);
+                        v.z = pro_apply(v.z, sc, sh, p.in_relu);
+                        v.w = pro_apply(v.w, sc, sh, p.in_relu);
+                    }
+                    float* dst = lx + c * PP + py * PW;
+                    if (slot < TW4) {
+                        dst += 1 + 4 * slot;
+                        dst[0] = v.x;
+                        dst[1] = v.y;
+                        dst[2] = v.z;
+                        dst[3] = v.w;
+                    } else {
+                        dst[slot == TW4 ? 0 : PW - 1] = v.x;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < DPT; ++i) {
+                const int e = tid + i * NT;
+                if (e < NDI) {
+                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                    float* dst = ld + c * DP + rem * 4;
+                    dst[0] = dv[i].x;
+                    dst[1] = dv[i].y;
+                    dst[2] = dv[i].z;
+                    dst[3] = dv[i].w;
+                }
+            }
+        };
+        if (first < last) load_item(first);
+        for (int item = first; item < last; ++item) {
+            __syncthreads();
+            store_item();
+            __syncthreads();
+            if (item + 1 < last) load_item(item + 1);  // in flight during the MFMAs
+            compute_item();
+        }
+    } else {
+        // scalar staging for ragged shapes
+        for (int item = first; item < last; ++item) {
+            const int n = item / tiles, t = item - n * tiles;
+            const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
+            const float* xin = p.x + (size_t)n * p.cin * hw;
+            const float* din = p.dy + (size_t)n * p.cout * hw;
+            __syncthreads();
+            for (int e = tid; e < CI_T * PW * PH; e += NT) {
+                const int c = e / (PW * PH), rem = e - c * (PW * PH);
+                const int py = rem / PW, px = rem - py * PW;
+                const int gc = ci0 + c, gy = ty0 + py - 1, gx = tx0 + px - 1;
+                float v = 0.f;
+                if (gc < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd) {
+                    v = xin[(unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx];
+                    if (pro) v = pro_apply(v, p.in_scale[gc], p.in_shift[gc], p.in_relu);
+                }
+                lx[c * PP + rem] = v;
+            }
+            for (int e = tid; e < CO_T * TW * TH; e += NT) {
+                const int c = e / (TW * TH), rem = e - c * (TW * TH);
+                const int py = rem / TW, px = rem - py * TW;
+                const int gc = co0 + c, gy = ty0 + py, gx = tx0 + px;
+                float v = 0.f;
+                if (gc < p.cout && gy < p.h && gx < p.wd)
+                    v = din[(unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx];
+                ld[c * DP + rem] = v;
+            }
+            __syncthreads();
+            compute_item();
+        }
+    }
+
+    // K-split partner waves fold into k = 0 through LDS, one (ci,co) block per round (fixed order)
+    const int q = w_co * WCI + w_ci;
+#pragma unroll 1
+    for (int k = 1; k < KSPL; ++k) {
+#pragma unroll 1
+        for (int qq = 0; qq < NQ; ++qq) {
+            __syncthreads();
+            if (w_k == k && q == qq) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lds[(tr * 3 + t) * 1024 + r * 64 + lane] = acc[t][r];
+            }
+            __syncthreads();
+            if (w_k == 0 && q == qq) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += lds[(tr * 3 + t) * 1024 + r * 64 + lane];
+            }
+        }
+    }
+    if (w_k == 0) {
+        float* out = p.part + (size_t)blockIdx.x * p.cin * 9 * p.cout;
+        const int co = co0 + w_co * 32 + j;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + w_ci * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (ci < p.cin && co < p.cout)
+                    out[((size_t)ci * 9 + tr * 3 + t) * p.cout + co] = acc[t][r];
+            }
+    }
+}
+
 // Small-Cin 3x3 wgrad (the stem, Cin*9 <= 32): D[(ci,tap)][co] — the 27 (ci, tap) pairs ride
 // the MFMA's M dimension, so a pixel pair costs ONE MFMA per 32 output channels instead of 9.
 // Tile 32 x 8; 4 waves split the 8 rows; X patch [cin][10][34] (+ one zero plane for the
@@ -775,15 +1002,25 @@ constexpr WgVariant kWgVariants[] = {{32, 4, 32, 32, 4}, {16, 8, 32, 64, 2}, {16
                                      {28, 2, 64, 64, 1}, {32, 4, 32, 64, 2}};
 constexpr int kWgSmallCin = 5;  // variant id of wgrad_smallcin_kernel<32, 8>
 
-template <int TAPS>
-int launch_wgrad(int variant, const WgradArgs& a, dim3 grid, hipStream_t s) {
-    switch (variant) {
-        case 0: wgrad_mfma_kernel<TAPS, 32, 4, 1, 1, 4><<<grid, kThreads, 0, s>>>(a); break;
-        case 1: wgrad_mfma_kernel<TAPS, 16, 8, 1, 2, 2><<<grid, kThreads, 0, s>>>(a); break;
-        case 2: wgrad_mfma_kernel<TAPS, 16, 4, 2, 2, 1><<<grid, kThreads, 0, s>>>(a); break;
-        case 3: wgrad_mfma_kernel<TAPS, 28, 2, 2, 2, 1><<<grid, kThreads, 0, s>>>(a); break;
-        case 4: wgrad_mfma_kernel<TAPS, 32, 4, 1, 2, 2><<<grid, kThreads, 0, s>>>(a); break;
-        default: return LF_ERR_INVALID;
+int launch_wgrad(int ksize, int variant, const WgradArgs& a, dim3 grid, hipStream_t s) {
+    if (ksize == 3) {
+        switch (variant) {
+            case 0: wgrad3_kernel<32, 4, 1, 1, 4><<<grid, 768, 0, s>>>(a); break;
+            case 1: wgrad3_kernel<16, 8, 1, 2, 2><<<grid, 768, 0, s>>>(a); break;
+            case 2: wgrad3_kernel<16, 4, 2, 2, 1><<<grid, 768, 0, s>>>(a); break;
+            case 3: wgrad3_kernel<28, 2, 2, 2, 1><<<grid, 768, 0, s>>>(a); break;
+            case 4: wgrad3_kernel<32, 4, 1, 2, 2><<<grid, 768, 0, s>>>(a); break;
+            default: return LF_ERR_INVALID;
+        }
+    } else {
+        switch (variant) {
+            case 0: wgrad_mfma_kernel<1, 32, 4, 1, 1, 4><<<grid, kThreads, 0, s>>>(a); break;
+            case 1: wgrad_mfma_kernel<1, 16, 8, 1, 2, 2><<<grid, kThreads, 0, s>>>(a); break;
+            case 2: wgrad_mfma_kernel<1, 16, 4, 2, 2, 1><<<grid, kThreads, 0, s>>>(a); break;
+            case 3: wgrad_mfma_kernel<1, 28, 2, 2, 2, 1><<<grid, kThreads, 0, s>>>(a); break;
+            case 4: wgrad_mfma_kernel<1, 32, 4, 1, 2, 2><<<grid, kThreads, 0, s>>>(a); break;
+            default: return LF_ERR_INVALID;
+        }
     }
     return LF_OK;
 }
@@ -820,8 +1057,9 @@ WgPlan plan_wgrad(int n, int cin, int cout, int h, int w, int ksize) {
         }
     }
     best.items = n * best.tiles_x * best.tiles_y;
-    // ~2-3 resident workgroups per CU overall; every split gets the same number of items
-    int splits = (256 * 3) / (best.gy * best.gz);
+    // every split gets the same number of items
+    // resident workgroups per CU: the 12-wave 3x3 kernels 1 (x2 rounds), the others ~3
+    int splits = (256 * (ksize == 3 && best.variant != kWgSmallCin ? 2 : 3)) / (best.gy * best.gz);
     if (splits < 1) splits = 1;
     if (splits > best.items) splits = best.items;
     best.items_per_split = (best.items + splits - 1) / splits;
@@ -933,7 +1171,7 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, 
     if (pl.variant == kWgSmallCin)
         wgrad_smallcin_kernel<32, 8><<<grid, kThreads, 0, s>>>(a);
     else
-        rc = ksize == 3 ? launch_wgrad<9>(pl.variant, a, grid, s) : launch_wgrad<1>(pl.variant, a, grid, s);
+        rc = launch_wgrad(ksize, pl.variant, a, grid, s);
     if (rc != LF_OK) return rc;
     return lf::check_launch("lf_conv2d_wgrad");
 }
