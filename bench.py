@@ -40,7 +40,8 @@ TRAIN_GFLOP_PER_IMG = 18.757  # 3 x 3.126 GMAC x 2
 
 FWD_NAMES = {0: "conv_mfma_kernel<T,32,8,1,1,4,2>", 1: "conv_mfma_kernel<T,32,8,1,2,4,2>",
              2: "conv_mfma_kernel<T,16,16,1,1,4,2>", 3: "conv_mfma_kernel<T,16,16,1,2,4,2>",
-             4: "conv_mfma_kernel<T,28,8,4,1,1,7>", 5: "conv_mfma_kernel<T,32,8,2,2,2,4>"}
+             4: "conv_mfma_kernel<T,28,8,4,1,1,7>", 5: "conv_mfma_kernel<T,32,8,2,2,2,4>",
+             6: "conv_mfma_kernel<T,56,8,2,1,2,7>"}
 WG_NAMES3 = {0: "wgrad3_kernel<32,4,1,1,4>", 1: "wgrad3_kernel<16,8,1,2,2>",
              2: "wgrad3_kernel<16,4,2,2,1>", 3: "wgrad3_kernel<28,2,2,2,1>",
              4: "wgrad3_kernel<32,4,1,2,2>", 5: "wgrad_smallcin_kernel<32,8>"}

@@ -33,7 +33,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-constexpr int kKC = 8;  // input channels per K-chunk
+#ifndef LF_KC_SMALL
+#define LF_KC_SMALL 8
+#endif
 
 __device__ __forceinline__ float pro_apply(float v, float sc, float sh, int relu) {
     v = fmaf(v, sc, sh);
@@ -60,7 +62,7 @@ struct ConvArgs {
 // Waves: WCO x WPX = 4; each wave computes MB cout-blocks x NB pixel-blocks.
 // min waves/SIMD asked of the register allocator: accumulators + VGPRs share one 512-entry
 // file per SIMD lane; with the prefetch registers <=32 accumulators fit 3 waves, more fit 2.
-template <int TAPS, int TW, int TH, int WCO, int MB, int WPX, int NB>
+template <int TAPS, int TW, int TH, int WCO, int MB, int WPX, int NB, int kKC>
 __global__ __launch_bounds__(kThreads, (MB * NB * 16 <= 32 ? 3 : 2))
 void conv_mfma_kernel(ConvArgs p) {
     constexpr int NPB = TW * TH / 32;
@@ -110,17 +112,21 @@ void conv_mfma_kernel(ConvArgs p) {
 
     const bool pro = p.in_scale != nullptr;
 
+    // cp loop only partially unrolled: the scheduler otherwise hoists dozens of LDS reads and
+    // the accumulators + prefetch registers no longer fit
     auto compute_chunk = [&]() {
-#pragma unroll
+#pragma unroll 2
         for (int cp = 0; cp < kKC / 2; ++cp) {
+            const float* lwc = lw + abase + 2 * cp * TAPS * CT;
+            const float* lpc = lp + 2 * cp * PP;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
                 float a[MB], b[NB];
 #pragma unroll
-                for (int m = 0; m < MB; ++m) a[m] = lw[abase + (2 * cp * TAPS + tap) * CT + m * 32];
+                for (int m = 0; m < MB; ++m) a[m] = lwc[tap * CT + m * 32];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) b[nb] = lp[bbase[nb] + 2 * cp * PP + dy * PW + dx];
+                for (int nb = 0; nb < NB; ++nb) b[nb] = lpc[bbase[nb] + dy * PW + dx];
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -971,8 +977,8 @@ __global__ __launch_bounds__(kThreads) void weight_dgrad_kernel(const float* __r
 struct FwdVariant {
     int tw, th, ct;
 };
-constexpr FwdVariant kFwdVariants[] = {{32, 8, 32}, {32, 8, 64}, {16, 16, 32},
-                                       {16, 16, 64}, {28, 8, 128}, {32, 8, 128}};
+constexpr FwdVariant kFwdVariants[] = {{32, 8, 32}, {32, 8, 64}, {16, 16, 32}, {16, 16, 64},
+                                       {28, 8, 128}, {32, 8, 128}, {56, 8, 64}};
 constexpr int kNumFwd = sizeof(kFwdVariants) / sizeof(kFwdVariants[0]);
 
 inline long long padded_work(const FwdVariant& v, int h, int w, int cout) {
@@ -981,15 +987,18 @@ inline long long padded_work(const FwdVariant& v, int h, int w, int cout) {
     return tx * v.tw * ty * v.th * tc * v.ct;
 }
 
+// K-chunk of 8 input channels everywhere (16 measured slower: more prefetch registers, fewer resident waves)
 template <int TAPS>
 int launch_fwd(int variant, const ConvArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int KS = TAPS == 9 ? LF_KC_SMALL : 8;
     switch (variant) {
-        case 0: conv_mfma_kernel<TAPS, 32, 8, 1, 1, 4, 2><<<grid, kThreads, 0, s>>>(a); break;
-        case 1: conv_mfma_kernel<TAPS, 32, 8, 1, 2, 4, 2><<<grid, kThreads, 0, s>>>(a); break;
-        case 2: conv_mfma_kernel<TAPS, 16, 16, 1, 1, 4, 2><<<grid, kThreads, 0, s>>>(a); break;
-        case 3: conv_mfma_kernel<TAPS, 16, 16, 1, 2, 4, 2><<<grid, kThreads, 0, s>>>(a); break;
-        case 4: conv_mfma_kernel<TAPS, 28, 8, 4, 1, 1, 7><<<grid, kThreads, 0, s>>>(a); break;
-        case 5: conv_mfma_kernel<TAPS, 32, 8, 2, 2, 2, 4><<<grid, kThreads, 0, s>>>(a); break;
+        case 0: conv_mfma_kernel<TAPS, 32, 8, 1, 1, 4, 2, KS><<<grid, kThreads, 0, s>>>(a); break;
+        case 1: conv_mfma_kernel<TAPS, 32, 8, 1, 2, 4, 2, KS><<<grid, kThreads, 0, s>>>(a); break;
+        case 2: conv_mfma_kernel<TAPS, 16, 16, 1, 1, 4, 2, KS><<<grid, kThreads, 0, s>>>(a); break;
+        case 3: conv_mfma_kernel<TAPS, 16, 16, 1, 2, 4, 2, KS><<<grid, kThreads, 0, s>>>(a); break;
+        case 4: conv_mfma_kernel<TAPS, 28, 8, 4, 1, 1, 7, 8><<<grid, kThreads, 0, s>>>(a); break;
+        case 5: conv_mfma_kernel<TAPS, 32, 8, 2, 2, 2, 4, 8><<<grid, kThreads, 0, s>>>(a); break;
+        case 6: conv_mfma_kernel<TAPS, 56, 8, 2, 1, 2, 7, 8><<<grid, kThreads, 0, s>>>(a); break;
         default: return LF_ERR_INVALID;
     }
     return LF_OK;
