@@ -151,6 +151,8 @@ class LeafCNN:
         self._bufs: Dict[Any, Dict[str, torch.Tensor]] = {}
         self._wt: Dict[str, torch.Tensor] = {}
         self._saved: Dict[str, Any] = {}
+        self._global_n: Optional[int] = None
+        self._compiled: Dict[str, Any] = {}
 
     # ------------------------------------------------------------------ init
     def _init_weights(self) -> None:
@@ -304,7 +306,7 @@ class LeafCNN:
         dlogits = B("dlogits", (n, self.num_classes))
         dfeat = B("dfeat", (n, f_last))
         nn.head_bwd(sv["feat"], P["dense.w"], sv["probs"], sv["y_true"], dlogits, dfeat,
-                    G["dense.w"], G["dense.b"], 1.0 / n)
+                    G["dense.w"], G["dense.b"], 1.0 / (self._global_n or n))
         dg = dfeat
         if sv["top_drop"] is not None:
             dg = nn.mul(dfeat, sv["top_drop"], B("dg", dfeat.shape))
@@ -376,11 +378,14 @@ class LeafCNN:
 
     def train_step(self, x, y_true: torch.Tensor, lr: float, *, weight_decay: float = 1e-4,
                    clipnorm: float = 0.5, ema_decay: float = 0.999, adamw: bool = True,
-                   grad_sync=None):
+                   grad_sync=None, global_n: Optional[int] = None):
         """One optimisation step on a batch.  y_true: f32 [N,C] (already label-smoothed).
         grad_sync(flat_g) is called between backward and the optimizer (data-parallel
-        all-reduce).  Returns (probs, per-sample loss) device tensors (no host sync)."""
+        all-reduce); with global_n the local gradient is scaled by 1/global_n so that a SUM
+        all-reduce yields the global-batch mean.  Returns (probs, per-sample loss) device
+        tensors (no host sync)."""
         n = x.shape[0]
+        self._global_n = global_n
         drops, top = self.draw_dropout(n)
         x0 = self._input(x, True)
         probs, loss = self.forward(x0, True, y_true, drops, top)
@@ -406,6 +411,92 @@ class LeafCNN:
                     tot = tot + self.l2_reg * (self.p[name] ** 2).sum()
         return tot
 
+    # --------------------------------------------------------- keras-like API
+    def compile(self, optimizer=None, loss=None, metrics=None) -> None:
+        """optimizer: dict from train.utils.build_optimizer; loss: dict from build_loss."""
+        self._compiled = {"optimizer": optimizer or {}, "loss": loss or {}, "metrics": metrics or []}
+
+    def _targets(self, by) -> Tuple[torch.Tensor, torch.Tensor]:
+        """labels (one-hot [B,C] or sparse [B]) -> (smoothed one-hot f32 on device, indices)."""
+        by = torch.as_tensor(np.asarray(by)).to(self.device)
+        if by.dim() == 1:
+            idx = by.long()
+            yt = torch.nn.functional.one_hot(idx, self.num_classes).float()
+        else:
+            yt = by.float()
+            idx = yt.argmax(-1)
+        ls = float(self._compiled.get("loss", {}).get("label_smoothing", 0.0) or 0.0)
+        if ls > 0:
+            yt = yt * (1.0 - ls) + ls / self.num_classes
+        return yt.contiguous(), idx
+
+    def fit(self, train_seq, validation_data=None, epochs: int = 1, callbacks=None, dp=None,
+            verbose: int = 1):
+        """Keras `Model.fit` for a ManifestSequence: per epoch the batch order is shuffled
+        (keras shuffles Sequence batches), every batch is one `train_step`, then validation,
+        callbacks and `train_seq.on_epoch_end()`.  `dp` is a train.parallel.DataParallel."""
+        import logging
+        import random as _random
+        log = logging.getLogger(__name__)
+        opt = self._compiled.get("optimizer", {})
+        callbacks = callbacks or []
+        hist: Dict[str, List[float]] = {}
+        steps_per_epoch = len(train_seq)
+        order_rng = _random.Random(12345)
+        for cb in callbacks:
+            cb.set_model(self)
+            cb.on_train_begin()
+        self.stop_training = False
+        for epoch in range(epochs):
+            order = list(range(steps_per_epoch))
+            order_rng.shuffle(order)
+            acc_loss = torch.zeros((), device=self.device)
+            acc_correct = torch.zeros((), device=self.device)
+            seen = 0
+            for bi in order:
+                bx, by = train_seq[bi]
+                if bx.shape[0] == 0:
+                    continue
+                yt, idx = self._targets(by)
+                lr = opt["schedule"](self.opt_step) if "schedule" in opt else opt.get("lr", 1e-3)
+                gn = train_seq.global_batch_size(bi) if dp is not None and dp.active else None
+                probs, loss = self.train_step(
+                    bx, yt, lr, weight_decay=opt.get("weight_decay", 0.0),
+                    clipnorm=opt.get("clipnorm", 0.0), ema_decay=opt.get("ema_decay", 0.0),
+                    adamw=opt.get("name", "adamw") == "adamw",
+                    grad_sync=dp.allreduce_grads if dp is not None and dp.active else None,
+                    global_n=gn)
+                acc_loss += loss.sum()
+                acc_correct += (probs.argmax(-1) == idx).sum()
+                seen += int(bx.shape[0])
+                for cb in callbacks:
+                    cb.on_train_batch_end(bi)
+            tl, tc, tn = float(acc_loss), float(acc_correct), float(seen)
+            if dp is not None and dp.active:
+                tl, tc, tn = dp.allreduce_scalars([tl, tc, tn])
+            logs = {"loss": tl / max(tn, 1.0) + float(self.l2_penalty()), "accuracy": tc / max(tn, 1.0)}
+            if validation_data is not None:
+                vl, va = self.evaluate(validation_data, dp=dp)
+                logs["val_loss"], logs["val_accuracy"] = vl, va
+            logs["learning_rate"] = float(opt["schedule"](self.opt_step) if "schedule" in opt
+                                          else opt.get("lr", 0.0))
+            for k, v in logs.items():
+                hist.setdefault(k, []).append(float(v))
+            if verbose and (dp is None or dp.rank == 0):
+                log.info("Epoch %d/%d - %s", epoch + 1, epochs,
+                         " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()))
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+            train_seq.on_epoch_end()
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            cb.on_train_end()
+
+        class History:
+            history = hist
+        return History()
+
     # ----------------------------------------------------------- inference
     @torch.no_grad()
     def predict(self, x, batch_size: int = 256, verbose: Any = 0) -> np.ndarray:
@@ -423,24 +514,26 @@ class LeafCNN:
         probs, _ = self.forward(self._input(x, False), False)
         return probs
 
-    def evaluate(self, data, verbose: Any = 0) -> List[float]:
-        """[loss, accuracy] over an iterable of (X, y) batches (one-hot or sparse labels)."""
-        tot_loss, correct, count = 0.0, 0, 0
+    def evaluate(self, data, verbose: Any = 0, dp=None) -> List[float]:
+        """[loss, accuracy] over a sequence of (X, y) batches (one-hot or sparse labels); the
+        loss uses the compiled label smoothing like keras' compiled loss.  With `dp`, sums are
+        all-reduced so every rank returns the global result."""
+        tot_loss = torch.zeros((), device=self.device)
+        correct = torch.zeros((), device=self.device)
+        count = 0
         for i in range(len(data)):
             bx, by = data[i]
-            by = torch.as_tensor(np.asarray(by)).to(self.device)
-            if by.dim() == 1:
-                yt = torch.nn.functional.one_hot(by.long(), self.num_classes).float()
-                idx = by.long()
-            else:
-                yt = by.float()
-                idx = by.argmax(-1)
-            probs, loss = self.forward(self._input(bx, False), False, yt.contiguous())
-            tot_loss += float(loss.sum())
-            correct += int((probs.argmax(-1) == idx).sum())
+            if bx.shape[0] == 0:
+                continue
+            yt, idx = self._targets(by)
+            probs, loss = self.forward(self._input(bx, False), False, yt)
+            tot_loss += loss.sum()
+            correct += (probs.argmax(-1) == idx).sum()
             count += int(idx.numel())
-        reg = float(self.l2_penalty())
-        return [tot_loss / max(count, 1) + reg, correct / max(count, 1)]
+        tl, tc, tn = float(tot_loss), float(correct), float(count)
+        if dp is not None and dp.active:
+            tl, tc, tn = dp.allreduce_scalars([tl, tc, tn])
+        return [tl / max(tn, 1.0) + float(self.l2_penalty()), tc / max(tn, 1.0)]
 
     # ------------------------------------------------------------- weights
     def weight_names(self) -> List[str]:

@@ -1,0 +1,78 @@
+"""Predictor with the reference's interface (srcs/predict/predictor.py:16-147).
+
+`predict_batch` decodes every image on the host, resizes groups of equal native size with
+the Pillow-exact LANCZOS kernel on the GPU, and runs ONE batched forward (the reference
+stacks all images and calls `model.predict`).  The mask/transform subprocess of the
+reference's ImageProcessor is display-only and not part of the model input path
+(`enable_subprocess=False` at predictor.py:46,99), so it is not reproduced.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Any, Dict, List
+
+import numpy as np
+
+from .model_loader import ModelLoader
+from ..utils.common import get_logger
+from ..utils.image_utils import ImageLoader
+
+logger = get_logger(__name__)
+
+
+class Predictor:
+    def __init__(self, learnings_dir):
+        self.learnings_dir = Path(learnings_dir)
+        self.model_loader = None
+        self._initialized = False
+
+    def load(self):
+        self.model_loader = ModelLoader(self.learnings_dir)
+        self.model_loader.load()
+        self._initialized = True
+
+    def _prepare(self, arrays: List[np.ndarray]) -> np.ndarray:
+        import torch
+
+        from .. import ops
+        S = self.model_loader.img_size
+        out = np.empty((len(arrays), S, S, 3), np.uint8)
+        groups: Dict[tuple, List[int]] = {}
+        for k, a in enumerate(arrays):
+            groups.setdefault(a.shape[:2], []).append(k)
+        for (h, w), ks in groups.items():
+            batch = torch.from_numpy(np.stack([arrays[k] for k in ks])).cuda()
+            res = ops.resize_lanczos_u8(batch, S).cpu().numpy()
+            for j, k in enumerate(ks):
+                out[k] = res[j]
+        return out
+
+    def _result(self, path, original, probs) -> Dict[str, Any]:
+        labels = self.model_loader.labels
+        top = int(np.argmax(probs))
+        return {"image_path": path, "top_prediction": labels[top], "confidence": float(probs[top]),
+                "all_probabilities": {labels[j]: float(probs[j]) for j in range(len(labels))},
+                "original_array": original, "processed_array": original}
+
+    def predict_single(self, image_path, use_transform: bool = False) -> Dict[str, Any]:
+        if not self._initialized:
+            raise RuntimeError("Predictor not initialized. Call load() first.")
+        image_path = Path(image_path)
+        original = ImageLoader.load_as_array(image_path)
+        probs = self.model_loader.model.predict(self._prepare([original]))[0]
+        return self._result(image_path, original, probs)
+
+    def predict_batch(self, image_paths) -> List[Dict[str, Any]]:
+        if not self._initialized:
+            raise RuntimeError("Predictor not initialized. Call load() first.")
+        loaded = []
+        for p in [Path(p) for p in image_paths]:
+            try:
+                loaded.append((p, ImageLoader.load_as_array(p)))
+            except Exception as e:  # noqa: BLE001 — skipped like the reference
+                logger.error(f"Error processing image {p}: {e}")
+        if not loaded:
+            logger.warning("No valid images to predict.")
+            return []
+        probs = self.model_loader.model.predict(self._prepare([a for _p, a in loaded]))
+        return [self._result(p, a, probs[i]) for i, (p, a) in enumerate(loaded)]

@@ -1,0 +1,74 @@
+"""Data-parallel glue: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI
+on the GPU box, "gloo" in CPU tests).  The training path has exactly one exchange step per
+optimisation step: an all-reduce (sum) of the flat gradient bucket; BatchNorm statistics
+stay per-GPU (the reference has no multi-device semantics to match).
+Validation counts (confusion matrices, correct/total) are integer all-reduces (exact)."""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+
+
+class DataParallel:
+    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None) -> None:
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        self.active = self.world > 1
+        if self.active and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            kw = {}
+            if backend == "nccl" and device is not None:
+                kw["device_id"] = device
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+
+    # -- the one exchange step of the training path
+    def allreduce_grads(self, flat_g: torch.Tensor) -> torch.Tensor:
+        """Sum the flat gradient bucket over ranks (local gradients are already scaled by
+        1/global_batch, so the sum is the global-batch mean gradient)."""
+        if self.active:
+            self.dist.all_reduce(flat_g, op=self.dist.ReduceOp.SUM)
+        return flat_g
+
+    def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        if self.active:
+            self.dist.broadcast(t, src)
+        return t
+
+    def allreduce_counts(self, counts: torch.Tensor) -> torch.Tensor:
+        """Integer counters (confusion matrix, correct/total): exact sum over ranks."""
+        if self.active:
+            self.dist.all_reduce(counts, op=self.dist.ReduceOp.SUM)
+        return counts
+
+    def allreduce_scalars(self, vals: List[float]) -> List[float]:
+        if not self.active:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64, device=self.device or "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def barrier(self) -> None:
+        if self.active:
+            self.dist.barrier()
+
+    def shutdown(self) -> None:
+        if self.active and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def shard_slice(indexes: List[int], rank: int, world: int) -> List[int]:
+    """Rank-strided slice of one global batch (same permutation on every rank)."""
+    return indexes[rank::world]
+
+
+def split_counts(total: int, world: int) -> Tuple[int, ...]:
+    return tuple(len(range(r, total, world)) for r in range(world))

@@ -1,0 +1,158 @@
+"""CPU tests of the host-side mirrors: loader batching/shuffle/sharding, metrics, schedules,
+and the world_size-2 gloo path of the data-parallel glue."""
+import json
+import os
+import random
+import socket
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+from PIL import Image
+
+from conftest import leaf_like
+from leaffliction_amd.dataio.manifest import ManifestItem, build_label_mapping
+from leaffliction_amd.dataio.sequence import ManifestSequence
+from leaffliction_amd.train.parallel import shard_slice, split_counts
+from leaffliction_amd.train.utils import CosineDecay, build_loss, build_optimizer
+from leaffliction_amd.utils.metrics import compute_classification_metrics
+
+
+def make_items(tmp_path, n, size=16):
+    items = []
+    for i in range(n):
+        p = tmp_path / f"img_{i}.jpg"
+        Image.fromarray(leaf_like(size, size, i)).save(p, quality=95)
+        lab = f"P__c{i % 3}"
+        items.append(ManifestItem(id=str(i), plant="P", cls=f"c{i % 3}", label=lab, split="train", src=p))
+    return items
+
+
+def test_sequence_batching_shuffle_and_labels(tmp_path):
+    """sequence.py:47,61-72,92-99,116-119: seeded shuffle at init and per epoch, short last batch."""
+    items = make_items(tmp_path, 11)
+    l2i = build_label_mapping(items)
+    seq = ManifestSequence(items, l2i, 16, 4, shuffle=True, seed=7, num_classes=3, one_hot=True,
+                           as_numpy=True)
+    rng = random.Random(7)
+    idx = list(range(11))
+    rng.shuffle(idx)
+    assert seq.indexes == idx and len(seq) == 3
+    X, y = seq[2]
+    assert X.shape == (3, 16, 16, 3) and X.dtype == np.float32 and y.shape == (3, 3)
+    assert 0.0 <= X.min() and X.max() <= 1.0
+    assert [int(v) for v in y.argmax(-1)] == [l2i[items[i].label] for i in idx[8:]]
+    seq.on_epoch_end()
+    rng.shuffle(idx)
+    assert seq.indexes == idx
+    sparse = ManifestSequence(items, l2i, 16, 4, shuffle=False, seed=7, as_numpy=True)
+    _x, ys = sparse[0]
+    assert ys.dtype == np.int32 and ys.tolist() == [0, 1, 2, 0]
+    with pytest.raises(ValueError):
+        ManifestSequence(items, l2i, 16, 4, shuffle=False, seed=1, one_hot=True)
+    assert len(list(iter(sparse))) == 3
+
+
+def test_sequence_rank_sharding_partitions_every_global_batch(tmp_path):
+    items = make_items(tmp_path, 10)
+    l2i = build_label_mapping(items)
+    seqs = [ManifestSequence(items, l2i, 16, 4, shuffle=True, seed=3, as_numpy=True, rank=r, world=3)
+            for r in range(3)]
+    for b in range(len(seqs[0])):
+        parts = [s.batch_indexes(b) for s in seqs]
+        merged = sorted(i for p in parts for i in p)
+        start = b * 4
+        assert merged == sorted(seqs[0].indexes[start:start + 4])
+        assert sum(len(p) for p in parts) == seqs[0].global_batch_size(b)
+    assert shard_slice(list(range(7)), 1, 3) == [1, 4]
+    assert split_counts(7, 3) == (3, 2, 2)
+
+
+def test_cosine_and_optimizer_config():
+    sched = CosineDecay(2e-3, 100)
+    assert sched(0) == pytest.approx(2e-3) and sched(50) == pytest.approx(1e-3)
+    assert sched(100) == pytest.approx(0.0, abs=1e-12) and sched(1000) == pytest.approx(0.0, abs=1e-12)
+    reg = {"optimizer": "adamw", "lr": 0.002, "weight_decay": 1e-4, "label_smoothing": 0.02,
+           "clipnorm": 0.5, "ema_decay": 0.999}
+    opt = build_optimizer(reg, sched)
+    assert opt["name"] == "adamw" and opt["weight_decay"] == 1e-4 and opt["clipnorm"] == 0.5
+    fast = build_optimizer({"optimizer": "adam", "weight_decay": 0.0, "clipnorm": 0.0}, 3e-3)
+    assert fast["name"] == "adam" and fast["weight_decay"] == 0.0 and fast["lr"] == 3e-3
+    assert build_loss(reg)["label_smoothing"] == 0.02
+    assert build_loss({"label_smoothing": 0.0})["name"] == "sparse_categorical_crossentropy"
+
+
+def test_metrics_match_sklearn():
+    sk = pytest.importorskip("sklearn.metrics")
+    rng = np.random.RandomState(0)
+    yt, yp = rng.randint(0, 4, 300).tolist(), rng.randint(0, 4, 300).tolist()
+    labels = ["a", "b", "c", "d"]
+    m = compute_classification_metrics(yt, yp, labels)
+    assert m["accuracy"] == pytest.approx(sk.accuracy_score(yt, yp))
+    for avg in ("macro", "weighted"):
+        assert m[f"{avg}_f1"] == pytest.approx(sk.f1_score(yt, yp, average=avg, zero_division=0))
+        assert m[f"{avg}_precision"] == pytest.approx(sk.precision_score(yt, yp, average=avg, zero_division=0))
+        assert m[f"{avg}_recall"] == pytest.approx(sk.recall_score(yt, yp, average=avg, zero_division=0))
+    per = sk.f1_score(yt, yp, average=None, zero_division=0)
+    assert [m[f"f1_{x}"] for x in labels] == pytest.approx(per.tolist())
+    b = compute_classification_metrics([0, 1, 1, 0], [0, 1, 0, 0], ["n", "p"])
+    assert b["binary_recall"] == pytest.approx(0.5) and b["binary_precision"] == pytest.approx(1.0)
+
+
+# ----------------------------------------------------------------- gloo, world_size 2
+def _dp_worker(rank, world, port, out_dir):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    from leaffliction_amd.train.parallel import DataParallel
+    dp = DataParallel(backend="gloo")
+    assert dp.active and dp.world == world
+    # the one exchange step: SUM of flat gradient buckets scaled by 1/global_n
+    g_full = torch.arange(12, dtype=torch.float32).reshape(6, 2)       # per-sample "gradients"
+    mine = g_full[rank::world].sum(0) / 6.0
+    flat = mine.clone()
+    dp.allreduce_grads(flat)
+    assert torch.allclose(flat, g_full.mean(0))
+    # replicas start identical
+    p = torch.full((5,), float(rank))
+    dp.broadcast_(p, 0)
+    assert (p == 0).all()
+    # integer confusion counts: exact
+    cm = torch.tensor([[rank + 1, 0], [2, rank]], dtype=torch.int64)
+    dp.allreduce_counts(cm)
+    assert cm.tolist() == [[3, 0], [4, 1]]
+    assert dp.allreduce_scalars([1.5, float(rank)]) == [3.0, 1.0]
+    dp.barrier()
+    Path(out_dir, f"ok_{rank}").write_text("ok")
+    dp.shutdown()
+
+
+def test_data_parallel_glue_gloo_world2(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+def test_balancer_task_list_matches_reference(tmp_path):
+    """build_tasks consumes the global `random` stream exactly like the reference loop."""
+    from leaffliction_amd.preprocessing.dataset_balancer import DatasetBalancer
+    gold = json.loads((Path(__file__).parent / "golden" / "balancer_golden.json").read_text())
+    root = tmp_path / "images"
+    for plant, classes in gold["layout"].items():
+        for cls, n in classes.items():
+            d = root / plant / cls
+            d.mkdir(parents=True)
+            for i in range(n):
+                (d / f"image ({i + 1}).JPG").write_bytes(b"x")
+    bal = DatasetBalancer(source_dir=str(root), target_dir=str(tmp_path / "aug"), seed=gold["seed"],
+                          workers=1)
+    bal.analyze_distribution()
+    assert bal.calculate_plan() == gold["plan"]
+    images = {cls: sorted((root / "Apple" / cls).glob("*.JPG")) for cls in gold["layout"]["Apple"]}
+    tasks = bal.build_tasks(images)
+    assert [(Path(t["source_img"]).name, Path(t["output_path"]).name, t["transform_name"], t["seed"])
+            for t in tasks] == [(t["source"], t["output"], t["transform"], t["seed"])
+                                for t in gold["tasks"]]

@@ -1,0 +1,152 @@
+"""Known-answer tests that guard the UNPINNED halves of the oracle (OpenCV 8-bit conventions
+and the Keras layer/optimizer semantics restated in oracle/cv_ops.py and oracle/cnn_ref.py).
+The list follows SURVEY §8c "Build-side KATs to create"."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cnn_ref as R
+from oracle import cv_ops as CV
+
+
+# ------------------------------------------------------------------ OpenCV conventions
+def test_hsv_cube_corners_and_greys():
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255],
+                    [255, 0, 255], [0, 0, 0], [255, 255, 255], [128, 128, 128], [17, 17, 17]]],
+                  dtype=np.uint8)
+    hsv = CV.rgb2hsv(px)[0].tolist()
+    assert hsv[0] == [0, 255, 255]      # red
+    assert hsv[1] == [60, 255, 255]     # green  (H in [0,180): 120 deg / 2)
+    assert hsv[2] == [120, 255, 255]    # blue
+    assert hsv[3] == [30, 255, 255]     # yellow
+    assert hsv[4] == [90, 255, 255]     # cyan
+    assert hsv[5] == [150, 255, 255]    # magenta
+    for g in hsv[6:]:                   # greys: H = 0, S = 0, V = value
+        assert g[0] == 0 and g[1] == 0
+    assert [g[2] for g in hsv[6:]] == [0, 255, 128, 17]
+    assert CV.rgb2hsv(np.random.RandomState(0).randint(0, 256, (50, 50, 3)).astype(np.uint8))[..., 0].max() < 180
+
+
+def test_gray_coefficients():
+    assert 4899 + 9617 + 1868 == 1 << 14           # weights sum to one in Q14
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
+    assert CV.rgb2gray(px)[0].tolist() == [255, 0, 76, 150, 29]   # 0.299 / 0.587 / 0.114
+
+
+def test_gaussian_kernel_rules():
+    for k, s in [(15, 0.0), (5, 1.5), (3, 0.0), (7, 2.0)]:
+        q = CV.gaussian_kernel_q8(k, s)
+        assert q.sum() == 256 and (q == q[::-1]).all() and q.argmax() == k // 2
+    # sigma=0 rule: 0.3*((k-1)*0.5 - 1) + 0.8 -> 2.6 for k = 15 (blur.py:61)
+    assert abs(0.3 * ((15 - 1) * 0.5 - 1) + 0.8 - 2.6) < 1e-12
+    q0 = CV.gaussian_kernel_q8(15, 0.0)
+    q26 = CV.gaussian_kernel_q8(15, 2.6)
+    assert (q0 == q26).all()
+
+
+def test_blur_reflect101_and_constants():
+    flat = np.full((9, 11, 3), 93, np.uint8)
+    assert (CV.gaussian_blur(flat, 15, 0.0) == 93).all()           # taps sum to 1: constants stay
+    ramp = np.tile(np.arange(0, 80, 4, dtype=np.uint8), (6, 1))     # linear ramp in x
+    out = CV.gaussian_blur(ramp, 5, 1.5)
+    assert (out[:, 2:-2] == ramp[:, 2:-2]).all()                    # symmetric kernel keeps a ramp
+    # BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba): the edge pixel is not duplicated
+    assert CV._reflect101(np.array([-1, -2, 5, 6]), 5).tolist() == [1, 2, 3, 2]
+
+
+def test_apply_mask_docstring_example():
+    """srcs/utils/mask_utils.py:29-41."""
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 255, (100, 100, 3)).astype(np.uint8)
+    mask = rng.randint(0, 2, (100, 100)).astype(np.uint8) * 255
+    w, b = CV.apply_mask(img, mask, "white"), CV.apply_mask(img, mask, "black")
+    assert (w[mask == 0] == 255).all() and (b[mask == 0] == 0).all()
+    assert (w[mask == 255] == img[mask == 255]).all()
+    with pytest.raises(ValueError):
+        CV.apply_mask(img, mask, "green")
+
+
+def test_region_stats_consistency():
+    img = np.zeros((4, 4, 3), np.uint8)
+    img[:2] = (60, 140, 50)     # healthy green
+    img[2:] = (120, 70, 30)     # brown
+    c, hist = CV.hsv_region_stats(img)
+    assert c[0] == 16 and c[1] == 8 and c[4] == 8     # leaf, Vert Sain, Brun/Orange
+    assert hist.sum(axis=1).tolist() == [16, 16, 16]
+
+
+# ------------------------------------------------------------------ Keras layer semantics
+def test_conv_delta_kernel_is_identity():
+    x = torch.randn(2, 3, 5, 7)
+    w = torch.zeros(3, 9, 3)
+    for c in range(3):
+        w[c, 4, c] = 1.0
+    assert torch.equal(R.conv(x, w, 3), x)
+
+
+def test_batchnorm_hand_moments():
+    y = torch.tensor([1.0, 3.0, 5.0, 7.0]).view(4, 1, 1, 1)        # mean 4, biased var 5
+    st = {"bn.mean": torch.zeros(1), "bn.var": torch.ones(1)}
+    out = R.batchnorm(y, torch.tensor([2.0]), torch.tensor([0.5]), st, "bn", True)
+    exp = (y - 4.0) / math.sqrt(5.0 + 1e-3) * 2.0 + 0.5
+    assert torch.allclose(out, exp, atol=1e-6)
+    assert st["bn.mean"].item() == pytest.approx(0.04)              # 0*0.99 + 4*0.01
+    assert st["bn.var"].item() == pytest.approx(0.99 + 0.05)        # biased variance, no Bessel
+    inf = R.batchnorm(y, torch.tensor([1.0]), torch.tensor([0.0]), st, "bn", False)
+    assert torch.allclose(inf, (y - 0.04) / math.sqrt(1.04 + 1e-3), atol=1e-6)
+
+
+def test_se_zero_weights_scale_by_half():
+    widths, classes = [16], 2
+    p = R.init_params(classes, widths, seed=1)
+    for k in ("s0.se.w1", "s0.se.w2"):
+        p[k].zero_()
+    st = R.init_state(widths)
+    got = {}
+    R.forward(p, st, torch.randn(2, 3, 8, 8), widths, False, collect=got)
+    p2 = {k: v.clone() for k, v in p.items()}
+    p2["s0.se.b2"] = torch.full_like(p["s0.se.b2"], 50.0)          # sigmoid -> 1
+    got2 = {}
+    R.forward(p2, R.init_state(widths), torch.randn(2, 3, 8, 8), widths, False, collect=got2)
+    # with zero SE weights the gate is sigmoid(0) = 0.5 for every channel
+    z = torch.sigmoid(torch.zeros(1))
+    assert z.item() == 0.5
+
+
+def test_label_smoothed_cce_uniform_is_log_c():
+    c = 8
+    probs = torch.full((3, c), 1.0 / c)
+    y = R.smooth_labels(torch.nn.functional.one_hot(torch.tensor([0, 3, 7]), c).float(), 0.02)
+    assert torch.allclose(y.sum(-1), torch.ones(3))
+    assert y[0, 0].item() == pytest.approx(0.98 + 0.02 / 8)
+    assert torch.allclose(R.cce_loss(probs, y), torch.full((3,), math.log(c)), atol=1e-6)
+
+
+def test_adamw_one_step_closed_form():
+    w0 = torch.tensor([1.0, -2.0])
+    g = torch.tensor([0.3, 0.4])                                   # norm 0.5: at the clip edge
+    p, m, v = R.adamw_step({"w": w0.clone()}, {"w": g}, {"w": torch.zeros(2)}, {"w": torch.zeros(2)},
+                           step=1, lr=1e-2, wd=1e-4, clipnorm=0.5)
+    # first step: m_hat = g, v_hat = g^2 -> update = lr * g/(|g| + eps*...) ~ lr * sign(g)
+    exp = w0 - w0 * 1e-4 * 1e-2 - 1e-2 * torch.sign(g)
+    assert torch.allclose(p["w"], exp, atol=1e-6)
+    g_big = torch.tensor([3.0, 4.0])                               # norm 5 -> scaled to 0.5
+    p2, m2, _ = R.adamw_step({"w": w0.clone()}, {"w": g_big}, {"w": torch.zeros(2)},
+                             {"w": torch.zeros(2)}, step=1, lr=1e-2, clipnorm=0.5)
+    assert torch.allclose(m2["w"], torch.tensor([0.3, 0.4]) * 0.1, atol=1e-7)
+
+
+def test_maxpool_and_gap_on_ramps():
+    x = torch.arange(16.0).view(1, 1, 4, 4)
+    assert torch.nn.functional.max_pool2d(x, 2).flatten().tolist() == [5.0, 7.0, 13.0, 15.0]
+    assert x.mean(dim=(2, 3)).item() == 7.5
+
+
+def test_param_count_matches_survey():
+    """base preset, 8 classes -> 1,250,756 trainable parameters."""
+    n = sum(int(np.prod(s)) for _n, s, _k in R.param_specs(8, [32, 64, 128, 256]))
+    assert n == 1_250_756
+    assert sum(int(np.prod(s)) for _n, s, _k in R.param_specs(8, [32, 64, 128])) == 314_020
+    assert sum(int(np.prod(s)) for _n, s, _k in R.param_specs(8, [16, 32, 64])) == 79_382

@@ -1,0 +1,166 @@
+"""End-to-end entrypoints on the GPU: Augmentation (balancer golden), train (config C1:
+2 classes, img 64, batch 8, 1 epoch), predict (batch + JSON schema + accuracy gate)."""
+import json
+import os
+import random
+from pathlib import Path
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import leaf_like
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def build_tree(root: Path, layout, size, seed0):
+    k = 0
+    for plant, classes in layout.items():
+        for cls, n in classes.items():
+            d = root / plant / cls
+            d.mkdir(parents=True)
+            for i in range(n):
+                Image.fromarray(leaf_like(size, size, seed0 + k)).save(d / f"image ({i + 1}).JPG", quality=95)
+                k += 1
+
+
+def test_balancer_outputs_match_reference_pixels(cuda, tmp_path, monkeypatch):
+    """GPU DatasetBalancer == the reference's DatasetBalancer: names, seeds and decoded pixels."""
+    from leaffliction_amd.preprocessing.dataset_balancer import DatasetBalancer
+    gold = json.loads((GOLD / "balancer_golden.json").read_text())
+    arrays = np.load(GOLD / "balancer_golden.npz")
+    monkeypatch.chdir(tmp_path)
+    src, dst = tmp_path / "images", tmp_path / "augmented"
+    build_tree(src, gold["layout"], gold["size"], 500)
+    bal = DatasetBalancer(source_dir=str(src), target_dir=str(dst), seed=gold["seed"], workers=2)
+    orig = bal._get_images_by_class
+    bal._get_images_by_class = lambda: {k: sorted(v) for k, v in orig().items()}
+    bal.run()
+    assert bal.completed == len(gold["tasks"]) and bal.failed == 0
+    for t in gold["tasks"]:
+        out = dst / "Apple" / t["class"] / t["output"]
+        assert out.exists(), t
+        got = np.array(Image.open(out).convert("RGB"))
+        assert np.array_equal(got, arrays[t["array"]]), t
+    man = json.loads((tmp_path / "artifacts/datasets/manifest_augmented.json").read_text())
+    assert man["meta"]["augmented_images"] == len(gold["tasks"]) and man["meta"]["augmentation_seed"] == 42
+    assert all(it["split"] == "train" and it["label"] == f"{it['plant']}__{it['class']}" for it in man["items"])
+
+
+def test_augmentation_cli_single_image(cuda, tmp_path, monkeypatch):
+    from leaffliction_amd.cli import Augmentation
+    monkeypatch.chdir(tmp_path)
+    img = tmp_path / "leaf.jpg"
+    Image.fromarray(leaf_like(64, 64, 1)).save(img, quality=95)
+    Augmentation.main([str(img), "-out", str(tmp_path / "ex"), "-seed", "42"])
+    names = sorted(p.name for p in (tmp_path / "ex").iterdir())
+    assert names == sorted(["original_leaf.jpg"] + [f"{t}_leaf.jpg" for t in Augmentation.TRANSFORMATIONS])
+    with pytest.raises(SystemExit) as e:
+        Augmentation.main([str(tmp_path / "nope")])
+    assert e.value.code == 1
+
+
+def write_split_manifest(root: Path, out: Path, val_every=4):
+    items = []
+    for plant_dir in sorted(root.iterdir()):
+        for class_dir in sorted(plant_dir.iterdir()):
+            for i, f in enumerate(sorted(class_dir.glob("*.JPG"))):
+                items.append({"plant": plant_dir.name, "class": class_dir.name,
+                              "label": f"{plant_dir.name}__{class_dir.name}",
+                              "split": "val" if i % val_every == 0 else "train",
+                              "src": str(f.resolve()), "id": f"{plant_dir.name}/{class_dir.name}/{f.name}"})
+    out.parent.mkdir(parents=True, exist_ok=True)
+    out.write_text(json.dumps({"meta": {"seed": 32}, "items": items}))
+
+
+def colour_tree(root: Path, n_per_class, size):
+    """Two trivially separable classes (green vs brown leaves) so 1 epoch learns something."""
+    rng = np.random.RandomState(0)
+    for cls, col in (("Apple_healthy", (60, 140, 50)), ("Apple_rust", (150, 80, 30))):
+        d = root / "Apple" / cls
+        d.mkdir(parents=True)
+        for i in range(n_per_class):
+            img = np.clip(rng.normal(0, 12, (size, size, 3)) + np.array(col), 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(d / f"image ({i + 1}).JPG", quality=95)
+
+
+def test_train_and_predict_cli_config_c1(cuda, tmp_path, monkeypatch):
+    """BASELINE configs[0]: Apple subset, 2 classes, img-size 64, batch 8, 1 epoch — plumbing."""
+    from leaffliction_amd.cli import predict as predict_cli
+    from leaffliction_amd.cli import train as train_cli
+    monkeypatch.chdir(tmp_path)
+    colour_tree(tmp_path / "images", 24, 80)   # 80x80 sources: exercises the GPU LANCZOS resize
+    man = tmp_path / "artifacts/datasets/manifest_split.json"
+    write_split_manifest(tmp_path / "images", man)
+    train_cli.main(["--manifest", str(man), "--epochs", "2", "--batch-size", "8", "--img-size", "64",
+                    "--no-mixed-precision", "--seed", "42"])
+    mdir = tmp_path / "artifacts/models"
+    for f in ("leaf_cnn.keras", "labels.json", "history.json", "meta.json", "confusion_matrix.json"):
+        assert (mdir / f).exists(), f
+    labels = json.loads((mdir / "labels.json").read_text())["label2idx"]
+    assert labels == {"Apple__Apple_healthy": 0, "Apple__Apple_rust": 1}
+    hist = json.loads((mdir / "history.json").read_text())
+    assert set(hist) == {"loss", "accuracy", "val_loss", "val_accuracy", "learning_rate"}
+    assert len(hist["loss"]) == 2 and all(np.isfinite(hist["loss"]))
+    meta = json.loads((mdir / "meta.json").read_text())
+    assert meta["data"]["img_size"] == 64 and meta["model"]["widths"] == [32, 64, 128, 256]
+    assert meta["saved_variant"] in ("base", "ema") and meta["labels"] == sorted(labels, key=labels.get)
+    cm = json.loads((mdir / "confusion_matrix.json").read_text())
+    n_val = sum(1 for it in json.loads(man.read_text())["items"] if it["split"] == "val")
+    assert np.array(cm["matrix"]).sum() == n_val and cm["labels"] == meta["labels"]
+    # missing manifest: logs and returns (exit code 0), like the reference
+    train_cli.main(["--manifest", str(tmp_path / "nope.json"), "--epochs", "1"])
+
+    # predict: batch mode -> JSON schema
+    predict_cli.main([str(tmp_path / "images/Apple/Apple_rust"), "-batch", "-learnings", str(mdir),
+                      "-json", "artifacts/prediction_output/batch_results.json"])
+    out = json.loads((tmp_path / "artifacts/prediction_output/batch_results.json").read_text())
+    # 24 files, listed twice: the reference's get_image_files globs "*.JPG" and "**/*.JPG"
+    # (image_utils.py:81-88) — the quirk is part of the contract
+    assert set(out) == {"batch_results", "summary"} and out["summary"]["total_images"] == 48
+    r0 = out["batch_results"][0]
+    assert set(r0) == {"image_path", "top_prediction", "confidence", "all_probabilities"}
+    assert abs(sum(r0["all_probabilities"].values()) - 1.0) < 1e-4
+    # evaluate gate: unreachable target -> exit code 2, nothing emitted
+    with pytest.raises(SystemExit) as e:
+        predict_cli.main([str(tmp_path / "images"), "-batch", "--evaluate", "--manifest", str(man),
+                          "--split", "val", "--sample-size", "6", "--target-acc", "1.01",
+                          "--max-attempts", "2", "-learnings", str(mdir)])
+    assert e.value.code == 2
+    with pytest.raises(SystemExit) as e:
+        predict_cli.main([str(tmp_path / "missing.jpg"), "-learnings", str(mdir)])
+    assert e.value.code == 1
+
+
+def test_fit_learns_separable_classes(cuda, tmp_path):
+    """Accuracy on two trivially separable classes reaches 100% within a few epochs (fit loop,
+    callbacks, EMA variant selection)."""
+    from leaffliction_amd.dataio.manifest import load_manifest, select_items, build_label_mapping
+    from leaffliction_amd.dataio.sequence import ManifestSequence
+    from leaffliction_amd.model.cnn import build_leafcnn, adapt_normalization
+    from leaffliction_amd.train.utils import (CosineDecay, build_callbacks, build_loss, build_optimizer,
+                                              save_best_variant)
+    colour_tree(tmp_path / "images", 20, 32)
+    man = tmp_path / "m.json"
+    write_split_manifest(tmp_path / "images", man)
+    items = load_manifest(man)
+    tr, va = select_items(items, "train"), select_items(items, "val")
+    l2i = build_label_mapping(tr)
+    cfg = {"optimizer": "adamw", "lr": 2e-3, "weight_decay": 1e-4, "label_smoothing": 0.02,
+           "cosine_decay": True, "ema_decay": 0.999, "clipnorm": 0.5}
+    tseq = ManifestSequence(tr, l2i, 32, 8, True, 42, num_classes=2, one_hot=True)
+    vseq = ManifestSequence(va, l2i, 32, 8, False, 42, num_classes=2, one_hot=True, cache=True)
+    model, norm = build_leafcnn(num_classes=2, img_size=32, widths=[16, 32, 64], drop_block=0.1,
+                                drop_top=0.3, l2_reg=1e-4, seed=1)
+    adapt_normalization(norm, tseq)
+    assert norm.adapted and norm.mean.shape == (3,)
+    model.compile(build_optimizer(cfg, CosineDecay(2e-3, len(tseq) * 6)), build_loss(cfg), ["accuracy"])
+    cbs, ema = build_callbacks(cfg)
+    hist = model.fit(tseq, validation_data=vseq, epochs=6, callbacks=cbs, verbose=0)
+    assert hist.history["accuracy"][-1] > 0.9
+    variant = save_best_variant(model, vseq, ema, tmp_path / "out", l2i, hist, meta={"x": 1})
+    assert variant in ("base", "ema")
+    cm = json.loads((tmp_path / "out/confusion_matrix.json").read_text())["matrix"]
+    assert cm[0][0] + cm[1][1] == len(va)      # after best-variant selection: all correct
