@@ -124,6 +124,69 @@ def cpu_baseline(seconds_budget: float = 25.0):
                       f"(oracle/cnn_ref.py on torch CPU, {threads} threads)"}
 
 
+def augment_throughput(dev, n=4096, iters=5):
+    """Second half of the headline metric: the augmentation pass on synthetic 224x224x3 images
+    resident in HBM (BASELINE configs[2]; op mix 1/6 each like the balancer's plan).  Host-side
+    parameter tables are built outside the timed region (they are inputs); JPEG decode/encode
+    is excluded.  GB/s = algorithmic bytes (input once + output once) / time."""
+    import math as _m
+
+    import numpy as np
+
+    from leaffliction_amd import ops
+    g = torch.Generator().manual_seed(42)
+    x = torch.randint(0, 256, (n, IMG, IMG, 3), dtype=torch.uint8, generator=g).to(dev)
+    rng = np.random.RandomState(42)
+    img_b = IMG * IMG * 3
+    mode = torch.from_numpy(rng.randint(0, 2, n).astype(np.int32)).to(dev)
+    f = rng.uniform(0.05, 0.15, n)
+    skew = torch.tensor([[1 + v, 0, -v * IMG, 0, 1 + v, -v * IMG, 0, 0] for v in f],
+                        dtype=torch.float64, device=dev)
+    sh = rng.uniform(-0.2, 0.2, n)
+    shear = torch.tensor([[1, v, 0, 0, 1, 0, 0, 0] if i % 2 else [1, 0, 0, v, 1, 0, 0, 0]
+                          for i, v in enumerate(sh)], dtype=torch.float64, device=dev)
+    angles = rng.uniform(-30, 30, n)
+    rplan = ops.rotate_expand_plan(IMG, IMG, angles, dev)
+    rbuf = torch.empty(rplan["total"], dtype=torch.uint8, device=dev)
+    boxes = []
+    for _ in range(n):
+        r = rng.uniform(0.8, 0.95)
+        nw = nh = int(IMG * r)
+        boxes.append((rng.randint(0, IMG - nw + 1), rng.randint(0, IMG - nh + 1), nw, nh))
+    ctab = ops.crop_resize_plan(IMG, IMG, boxes, dev)
+    cut = torch.from_numpy(rng.uniform(0, 2, n)).to(dev)
+    rot_out_b = sum(a * b * 3 for a, b in rplan["sizes"]) / n
+    cases = {
+        "flip": (lambda: ops.flip_u8(x, mode), 2 * img_b),
+        "rotate": (lambda: ops.rotate_expand_apply(x, rplan, 255, rbuf), img_b + rot_out_b),
+        "skew": (lambda: ops.warp_bicubic_u8(x, skew, True), 2 * img_b),
+        "shear": (lambda: ops.warp_bicubic_u8(x, shear, False), 2 * img_b),
+        "crop": (lambda: ops.resample_u8(x, IMG, IMG, ctab[0], ctab[1], ctab[2], ctab[3], True), 2 * img_b),
+        # distortion = noise add (2 passes) + histogram (1 read) + LUT apply (2): 5 image passes
+        "distortion": (lambda: ops.autocontrast_u8(ops.noise_philox_add_u8(x, 42, 5.0), cut), 5 * img_b),
+        "pack": (lambda: ops.pack_hwc_u8_to_nchw_f32(x), img_b + 4 * img_b),
+        "hist": (lambda: ops.hist_u8(x), img_b + 3072),
+    }
+    out, inv = {}, 0.0
+    for name, (fn, nbytes) in cases.items():
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / iters
+        out[name] = {"images_per_sec": round(n / sec), "GB_s": round(n * nbytes / sec / 1e9, 1),
+                     "frac_hbm_8TBs": round(n * nbytes / sec / 8e12, 3)}
+        if name in ("flip", "rotate", "skew", "shear", "crop", "distortion"):
+            inv += sec / n / 6.0
+    out["mix_images_per_sec"] = round(1.0 / inv)
+    out["n_images"] = n
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +194,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-augment", action="store_true", help="skip the augmentation-pass measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -247,6 +311,10 @@ def main() -> None:
             "step_tflops": round(TRAIN_GFLOP_PER_IMG * n * args.steps / elapsed / 1e3, 2),
             "final_loss": round(final_loss, 4),
         }
+        if not args.no_augment and world == 1:
+            del model
+            torch.cuda.empty_cache()
+            out["augment"] = augment_throughput(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

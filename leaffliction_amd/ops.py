@@ -225,6 +225,36 @@ def warp_bicubic_u8(x: torch.Tensor, coeffs: torch.Tensor, perspective: bool) ->
     return out
 
 
+def rotate_expand_plan(w: int, h: int, angles: Sequence[float], device):
+    """Host-side part of Image.rotate(expand=True): fixed-point coefficients, canvas sizes and
+    packed output offsets for a batch (device tensors) — reusable across launches."""
+    fix, ohw, offs, off = [], [], [], 0
+    for a in angles:
+        m, nw, nh = _geo.rotate_expand_matrix(w, h, float(a))
+        fix.append(_geo.affine_fixed_coeffs(m))
+        ohw.append((nh, nw))
+        offs.append(off)
+        off += ((nh * nw * 3 + 15) // 16) * 16
+    return {"fix": torch.tensor(fix, dtype=_I32, device=device),
+            "ohw": torch.tensor(ohw, dtype=_I32, device=device),
+            "off": torch.tensor(offs, dtype=torch.int64, device=device),
+            "sizes": ohw, "offsets": offs, "total": off, "maxpx": max(a * b for a, b in ohw)}
+
+
+def rotate_expand_apply(x: torch.Tensor, plan, fill: int = 255, out: Optional[torch.Tensor] = None):
+    n, h, w = _hwc(x, "rotate_expand.x")
+    if plan["fix"].shape[0] != n:
+        raise ValueError("rotate_expand: one angle per image")
+    if out is None:
+        out = torch.empty(plan["total"], dtype=_U8, device=x.device)
+    elif out.numel() < plan["total"] or out.dtype != _U8:
+        raise ValueError("rotate_expand: output buffer too small")
+    _lib.call("lf_affine_nearest_fixed_u8", x.data_ptr(), out.data_ptr(), plan["fix"].data_ptr(),
+              plan["ohw"].data_ptr(), plan["off"].data_ptr(), n, h, w, plan["maxpx"], int(fill),
+              _stream())
+    return out
+
+
 def rotate_expand_u8(x: torch.Tensor, angles: Sequence[float], fill: int = 255):
     """Image.rotate(angle, expand=True, fillcolor=white) (NEAREST) for each image of a batch.
 
@@ -233,22 +263,9 @@ def rotate_expand_u8(x: torch.Tensor, angles: Sequence[float], fill: int = 255):
     n, h, w = _hwc(x, "rotate_expand.x")
     if len(angles) != n:
         raise ValueError("rotate_expand: one angle per image")
-    fix, ohw, offs, off = [], [], [], 0
-    for a in angles:
-        m, nw, nh = _geo.rotate_expand_matrix(w, h, float(a))
-        fix.append(_geo.affine_fixed_coeffs(m))
-        ohw.append((nh, nw))
-        offs.append(off)
-        off += ((nh * nw * 3 + 15) // 16) * 16
-    dev = x.device
-    fix_t = torch.tensor(fix, dtype=_I32, device=dev)
-    ohw_t = torch.tensor(ohw, dtype=_I32, device=dev)
-    off_t = torch.tensor(offs, dtype=torch.int64, device=dev)
-    out = torch.empty(off, dtype=_U8, device=dev)
-    _lib.call("lf_affine_nearest_fixed_u8", x.data_ptr(), out.data_ptr(), fix_t.data_ptr(),
-              ohw_t.data_ptr(), off_t.data_ptr(), n, h, w, max(a * b for a, b in ohw), int(fill),
-              _stream())
-    return [out[o:o + oh * ow * 3].view(oh, ow, 3) for o, (oh, ow) in zip(offs, ohw)]
+    plan = rotate_expand_plan(w, h, angles, x.device)
+    out = rotate_expand_apply(x, plan, fill)
+    return [out[o:o + oh * ow * 3].view(oh, ow, 3) for o, (oh, ow) in zip(plan["offsets"], plan["sizes"])]
 
 
 def resample_u8(x: torch.Tensor, oh: int, ow: int, xb: torch.Tensor, xk: torch.Tensor,
@@ -288,18 +305,20 @@ def resize_lanczos_u8(x: torch.Tensor, size: int) -> torch.Tensor:
     return resample_u8(x, size, size, t[0], t[1], t[2], t[3], per_image=False)
 
 
+def crop_resize_plan(w: int, h: int, boxes: Sequence[Sequence[int]], device):
+    """Host-side Pillow resampling tables for per-image crops (device int32 tensors)."""
+    tabs = [_geo.crop_resize_tables(w, h, *[int(v) for v in b]) for b in boxes]
+    kx = max(t[2] for t in tabs)
+    ky = max(t[5] for t in tabs)
+    arrs = (np.stack([t[0] for t in tabs]), np.stack([_geo.pad_k(t[1], kx) for t in tabs]),
+            np.stack([t[3] for t in tabs]), np.stack([_geo.pad_k(t[4], ky) for t in tabs]))
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in arrs]
+
+
 def crop_resize_lanczos_u8(x: torch.Tensor, boxes: Sequence[Sequence[int]]) -> torch.Tensor:
     """ImageAugmenter.crop: per image (left, top, nw, nh) crop then LANCZOS back to (W,H)."""
     n, h, w = _hwc(x, "crop_resize.x")
     if len(boxes) != n:
         raise ValueError("crop_resize: one box per image")
-    tabs = [_geo.crop_resize_tables(w, h, *[int(v) for v in b]) for b in boxes]
-    kx = max(t[2] for t in tabs)
-    ky = max(t[5] for t in tabs)
-    xb = np.stack([t[0] for t in tabs])
-    xk = np.stack([_geo.pad_k(t[1], kx) for t in tabs])
-    yb = np.stack([t[3] for t in tabs])
-    yk = np.stack([_geo.pad_k(t[4], ky) for t in tabs])
-    dev = x.device
-    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (xb, xk, yb, yk)]
+    t = crop_resize_plan(w, h, boxes, x.device)
     return resample_u8(x, h, w, t[0], t[1], t[2], t[3], per_image=True)
