@@ -159,7 +159,7 @@ def augment_throughput(dev, n=4096, iters=5):
     cases = {
         "flip": (lambda: ops.flip_u8(x, mode), 2 * img_b),
         "rotate": (lambda: ops.rotate_expand_apply(x, rplan, 255, rbuf), img_b + rot_out_b),
-        "skew": (lambda: ops.warp_bicubic_u8(x, skew, True), 2 * img_b),
+        "skew": (lambda: ops.warp_bicubic_u8(x, skew, True, True), 2 * img_b),
         "shear": (lambda: ops.warp_bicubic_u8(x, shear, False), 2 * img_b),
         "crop": (lambda: ops.resample_u8(x, IMG, IMG, ctab[0], ctab[1], ctab[2], ctab[3], True), 2 * img_b),
         # distortion = noise add (2 passes) + histogram (1 read) + LUT apply (2): 5 image passes

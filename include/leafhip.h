@@ -123,7 +123,10 @@ int lf_hsv_region_stats(const uint8_t* rgb, int32_t* counts, int32_t* hsv_hist, 
 
 /* Image.transform(size, AFFINE|PERSPECTIVE, coeffs, BICUBIC) (image_augmenter.py:44-94).
  * coeffs[n][8] double (affine uses the first 6, a6 = a7 = 0), output same size,
- * outside pixels black.  */
+ * outside pixels black.  `perspective` bit 0: PERSPECTIVE (vs AFFINE) map; bit 1: hint that
+ * the maps are axis-aligned scales (a1 = a3 = 0, e.g. ImageAugmenter.skew) — selects a kernel
+ * that reuses horizontally interpolated rows down a column; the hint is verified per image
+ * and never changes results. */
 int lf_warp_bicubic_u8(const uint8_t* in, uint8_t* out, const double* coeffs, int perspective,
                        int n, int h, int w, lf_stream_t stream);
 

@@ -23,6 +23,46 @@ __device__ __forceinline__ double bicubic(double v1, double v2, double v3, doubl
 }
 
 // One thread per output pixel (3 channels).  grid = (ceil(h*w/256), n).
+// The 4x4 footprint is fetched with ONE unaligned 12-byte load per footprint row (4 pixels x
+// RGB; gfx950 runs in unaligned-access mode) instead of 48 byte gathers — the byte-gather
+// version was bound by the texture-address unit, not by HBM or the f64 pipe.  Two exact
+// shortcuts trim the double-precision work without changing a bit of the result:
+//   * a6 == a7 == 0  ->  the perspective denominator is exactly 1.0 and x/1.0 == x;
+//   * d == 0.0       ->  BICUBIC(v1..v4, 0) = v2 + 0*(...) = v2 exactly, so an axis that is
+//                        not resampled (shear along the other axis) costs no polynomial.
+struct __attribute__((packed, aligned(1))) Row12 {
+    uint32_t a, b, c;
+};
+
+__device__ __forceinline__ double bicubic_z(double v1, double v2, double v3, double v4, double d) {
+    return d == 0.0 ? v2 : bicubic(v1, v2, v3, v4, d);
+}
+
+// the three channels of one footprint row, horizontally interpolated
+__device__ __forceinline__ void hrow(const uint8_t* __restrict__ row, int x, int w, double dx,
+                                     double* v) {
+    if (x >= 0 && x + 3 < w) {  // four consecutive pixels: one 12-byte load
+        const Row12 q = *reinterpret_cast<const Row12*>(row + x * 3);
+        const unsigned wd[3] = {q.a, q.b, q.c};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            // pixel k channel b = byte 3k+b
+            const double p0 = (double)((wd[(b) >> 2] >> (8 * ((b) & 3))) & 0xffu);
+            const double p1 = (double)((wd[(3 + b) >> 2] >> (8 * ((3 + b) & 3))) & 0xffu);
+            const double p2 = (double)((wd[(6 + b) >> 2] >> (8 * ((6 + b) & 3))) & 0xffu);
+            const double p3 = (double)((wd[(9 + b) >> 2] >> (8 * ((9 + b) & 3))) & 0xffu);
+            v[b] = bicubic_z(p0, p1, p2, p3, dx);
+        }
+    } else {  // clamped columns at the image border
+        const int x0 = clampi(x, 0, w - 1) * 3, x1 = clampi(x + 1, 0, w - 1) * 3,
+                  x2 = clampi(x + 2, 0, w - 1) * 3, x3 = clampi(x + 3, 0, w - 1) * 3;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            v[b] = bicubic_z(row[x0 + b], row[x1 + b], row[x2 + b], row[x3 + b], dx);
+    }
+}
+
+// One thread per output pixel (general maps: shear, true perspective).
 __global__ __launch_bounds__(kBlock) void warp_bicubic_kernel(const uint8_t* __restrict__ in,
                                                               uint8_t* __restrict__ out,
                                                               const double* __restrict__ coeffs,
@@ -31,19 +71,18 @@ __global__ __launch_bounds__(kBlock) void warp_bicubic_kernel(const uint8_t* __r
     const double* a = coeffs + (size_t)n * 8;
     const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6],
                  a7 = a[7];
+    const bool divide = perspective && !(a6 == 0.0 && a7 == 0.0);
     const uint8_t* src = in + (size_t)n * h * w * 3;
     uint8_t* dst = out + (size_t)n * h * w * 3;
     const int total = h * w;
     for (int t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
         const int oy = t / w, ox = t - oy * w;
         const double xi = ox + 0.5, yi = oy + 0.5;
-        double xin, yin;
-        if (perspective) {
-            xin = (a0 * xi + a1 * yi + a2) / (a6 * xi + a7 * yi + 1);
-            yin = (a3 * xi + a4 * yi + a5) / (a6 * xi + a7 * yi + 1);
-        } else {
-            xin = a0 * xi + a1 * yi + a2;
-            yin = a3 * xi + a4 * yi + a5;
+        double xin = a0 * xi + a1 * yi + a2;
+        double yin = a3 * xi + a4 * yi + a5;
+        if (divide) {
+            xin = xin / (a6 * xi + a7 * yi + 1);
+            yin = yin / (a6 * xi + a7 * yi + 1);
         }
         uint8_t* o = dst + (size_t)t * 3;
         if (xin < 0.0 || xin >= w || yin < 0.0 || yin >= h) {
@@ -58,28 +97,132 @@ __global__ __launch_bounds__(kBlock) void warp_bicubic_kernel(const uint8_t* __r
         const double dx = xin - x, dy = yin - y;
         x--;
         y--;
-        const int x0 = clampi(x, 0, w - 1) * 3, x1 = clampi(x + 1, 0, w - 1) * 3,
-                  x2 = clampi(x + 2, 0, w - 1) * 3, x3 = clampi(x + 3, 0, w - 1) * 3;
-        const uint8_t* r0 = src + (size_t)clampi(y, 0, h - 1) * w * 3;
         const bool ok1 = (y + 1 >= 0 && y + 1 < h), ok2 = (y + 2 >= 0 && y + 2 < h),
                    ok3 = (y + 3 >= 0 && y + 3 < h);
-        const uint8_t* r1 = src + (size_t)(ok1 ? y + 1 : 0) * w * 3;
-        const uint8_t* r2 = src + (size_t)(ok2 ? y + 2 : 0) * w * 3;
-        const uint8_t* r3 = src + (size_t)(ok3 ? y + 3 : 0) * w * 3;
+        const int yr0 = clampi(y, 0, h - 1);
+        double v[3];
+        if (dy == 0.0) {
+            // BICUBIC(v1, v2, v3, v4, 0) = v2: only footprint row y+1 (or its fallback) matters
+            hrow(src + (size_t)(ok1 ? y + 1 : yr0) * w * 3, x, w, dx, v);
+        } else {
+            double v1[3], v2[3], v3[3], v4[3];
+            hrow(src + (size_t)yr0 * w * 3, x, w, dx, v1);
+            if (ok1) hrow(src + (size_t)(y + 1) * w * 3, x, w, dx, v2);
+            if (ok2) hrow(src + (size_t)(y + 2) * w * 3, x, w, dx, v3);
+            if (ok3) hrow(src + (size_t)(y + 3) * w * 3, x, w, dx, v4);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const double v1 = bicubic(r0[x0 + b], r0[x1 + b], r0[x2 + b], r0[x3 + b], dx);
-            double v2 = v1, v3, v4;
-            if (ok1) v2 = bicubic(r1[x0 + b], r1[x1 + b], r1[x2 + b], r1[x3 + b], dx);
-            v3 = v2;
-            if (ok2) v3 = bicubic(r2[x0 + b], r2[x1 + b], r2[x2 + b], r2[x3 + b], dx);
-            v4 = v3;
-            if (ok3) v4 = bicubic(r3[x0 + b], r3[x1 + b], r3[x2 + b], r3[x3 + b], dx);
-            const double v = bicubic(v1, v2, v3, v4, dy);
-            o[b] = v <= 0.0 ? 0 : (v >= 255.0 ? 255 : (uint8_t)v);
+            for (int b = 0; b < 3; ++b) {
+                const double u2 = ok1 ? v2[b] : v1[b];
+                const double u3 = ok2 ? v3[b] : u2;
+                const double u4 = ok3 ? v4[b] : u3;
+                v[b] = bicubic(v1[b], u2, u3, u4, dy);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o[b] = v[b] <= 0.0 ? 0 : (v[b] >= 255.0 ? 255 : (uint8_t)v[b]);
+    }
+}
+
+// Thread = one output column x a strip of kStrip output rows.  When the map is axis-aligned
+// (a1 == a3 == 0, no divide: the reference's "skew" is such a scale about a corner) the source
+// column/dx are the same for the whole strip and consecutive output rows share three of their
+// four footprint rows, so the horizontally interpolated rows are kept in a sliding window:
+// ~1.1 row interpolations per pixel instead of 4, same double arithmetic, same bits.
+constexpr int kStrip = 8;
+
+__global__ __launch_bounds__(kBlock) void warp_bicubic_strip_kernel(const uint8_t* __restrict__ in,
+                                                                    uint8_t* __restrict__ out,
+                                                                    const double* __restrict__ coeffs,
+                                                                    int perspective, int h, int w) {
+    const unsigned n = blockIdx.y;
+    const double* a = coeffs + (size_t)n * 8;
+    const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6],
+                 a7 = a[7];
+    const bool divide = perspective && !(a6 == 0.0 && a7 == 0.0);
+    const bool axis = !divide && a1 == 0.0 && a3 == 0.0;
+    const uint8_t* src = in + (size_t)n * h * w * 3;
+    uint8_t* dst = out + (size_t)n * h * w * 3;
+    const int strips = (h + kStrip - 1) / kStrip;
+    const int total = strips * w;
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
+        const int strip = t / w, ox = t - strip * w;
+        const double xi = ox + 0.5;
+        int wr = -0x40000000;        // source row held in H0 (sliding window H0..H3)
+        double H0[3], H1[3], H2[3], H3[3];
+        const int oy_end = min((strip + 1) * kStrip, h);
+        for (int oy = strip * kStrip; oy < oy_end; ++oy) {
+            const double yi = oy + 0.5;
+            double xin = a0 * xi + a1 * yi + a2;
+            double yin = a3 * xi + a4 * yi + a5;
+            if (divide) {
+                xin = xin / (a6 * xi + a7 * yi + 1);
+                yin = yin / (a6 * xi + a7 * yi + 1);
+            }
+            uint8_t* o = dst + ((size_t)oy * w + ox) * 3;
+            if (xin < 0.0 || xin >= w || yin < 0.0 || yin >= h) {
+                o[0] = 0;
+                o[1] = 0;
+                o[2] = 0;
+                continue;
+            }
+            xin -= 0.5;
+            yin -= 0.5;
+            int x = pil_floor(xin), y = pil_floor(yin);
+            const double dx = xin - x, dy = yin - y;
+            x--;
+            y--;
+            double v[3];
+            if (axis && y >= 0 && y + 3 < h) {
+                // interior rows: slide the window of horizontally interpolated rows to y..y+3
+                if (wr == y - 1) {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) { H0[b] = H1[b]; H1[b] = H2[b]; H2[b] = H3[b]; }
+                    hrow(src + (size_t)(y + 3) * w * 3, x, w, dx, H3);
+                } else if (wr == y - 2) {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) { H0[b] = H2[b]; H1[b] = H3[b]; }
+                    hrow(src + (size_t)(y + 2) * w * 3, x, w, dx, H2);
+                    hrow(src + (size_t)(y + 3) * w * 3, x, w, dx, H3);
+                } else if (wr != y) {
+                    hrow(src + (size_t)y * w * 3, x, w, dx, H0);
+                    hrow(src + (size_t)(y + 1) * w * 3, x, w, dx, H1);
+                    hrow(src + (size_t)(y + 2) * w * 3, x, w, dx, H2);
+                    hrow(src + (size_t)(y + 3) * w * 3, x, w, dx, H3);
+                }
+                wr = y;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) v[b] = bicubic_z(H0[b], H1[b], H2[b], H3[b], dy);
+            } else {
+                const bool ok1 = (y + 1 >= 0 && y + 1 < h), ok2 = (y + 2 >= 0 && y + 2 < h),
+                           ok3 = (y + 3 >= 0 && y + 3 < h);
+                const int yr0 = clampi(y, 0, h - 1);
+                if (dy == 0.0) {
+                    // BICUBIC(v1, v2, v3, v4, 0) = v2: only footprint row y+1 (or its fallback)
+                    hrow(src + (size_t)(ok1 ? y + 1 : yr0) * w * 3, x, w, dx, v);
+                } else {
+                    double v1[3], v2[3], v3[3], v4[3];
+                    hrow(src + (size_t)yr0 * w * 3, x, w, dx, v1);
+                    if (ok1) hrow(src + (size_t)(y + 1) * w * 3, x, w, dx, v2);
+                    if (ok2) hrow(src + (size_t)(y + 2) * w * 3, x, w, dx, v3);
+                    if (ok3) hrow(src + (size_t)(y + 3) * w * 3, x, w, dx, v4);
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const double u2 = ok1 ? v2[b] : v1[b];
+                        const double u3 = ok2 ? v3[b] : u2;
+                        const double u4 = ok3 ? v4[b] : u3;
+                        v[b] = bicubic(v1[b], u2, u3, u4, dy);
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) o[b] = v[b] <= 0.0 ? 0 : (v[b] >= 255.0 ? 255 : (uint8_t)v[b]);
         }
     }
 }
+
+struct __attribute__((packed, aligned(1))) Pix4 {
+    uint32_t v;
+};
 
 // Geometry.c affine_fixed: xx = a2 + a1*y + a0*x in wrapping int32 16.16.
 // Ragged batch: image n writes ohw[n] = (oh, ow) pixels at byte offset out_off[n].
@@ -89,30 +232,45 @@ __global__ __launch_bounds__(kBlock) void affine_nearest_kernel(const uint8_t* _
                                                                 const int32_t* __restrict__ ohw,
                                                                 const int64_t* __restrict__ out_off,
                                                                 int h, int w, unsigned fill) {
+    // One thread = one output DWORD (4 consecutive bytes = parts of at most 2 pixels): the
+    // packed RGB output is written with coalesced 4-byte stores instead of byte stores.
+    // out_off[n] is 16-byte aligned and each image's region is padded to 16 bytes.
     const unsigned n = blockIdx.y;
     const int32_t* a = fix6 + (size_t)n * 6;
     const unsigned a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
     const int oh = ohw[2 * n], ow = ohw[2 * n + 1];
     const uint8_t* src = in + (size_t)n * h * w * 3;
-    uint8_t* dst = out + out_off[n];
-    const int total = oh * ow;
-    for (int t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
-        const unsigned oy = t / ow, ox = t - oy * ow;
-        // unsigned arithmetic == two's-complement wrap of the C int accumulation
-        const int xx = (int)(a2 + a1 * oy + a0 * ox);
-        const int yy = (int)(a5 + a4 * oy + a3 * ox);
-        const int xin = xx >> 16, yin = yy >> 16;
-        uint8_t* o = dst + (size_t)t * 3;
-        if (xin >= 0 && xin < w && yin >= 0 && yin < h) {
-            const uint8_t* s = src + ((size_t)yin * w + xin) * 3;
-            o[0] = s[0];
-            o[1] = s[1];
-            o[2] = s[2];
-        } else {
-            o[0] = (uint8_t)fill;
-            o[1] = (uint8_t)fill;
-            o[2] = (uint8_t)fill;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + out_off[n]);
+    const int total = oh * ow;            // pixels
+    const int nd = (total * 3 + 3) / 4;   // dwords
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < nd; t += gridDim.x * kBlock) {
+        const int b0 = 4 * t, p0 = b0 / 3, c0 = b0 - 3 * p0;
+        unsigned px[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int p = p0 + k;
+            unsigned v = fill * 0x010101u;
+            if (p < total) {
+                const unsigned oy = p / ow, ox = p - oy * ow;
+                // unsigned arithmetic == two's-complement wrap of the C int accumulation
+                const int xx = (int)(a2 + a1 * oy + a0 * ox);
+                const int yy = (int)(a5 + a4 * oy + a3 * ox);
+                const int xin = xx >> 16, yin = yy >> 16;
+                if (xin >= 0 && xin < w && yin >= 0 && yin < h) {
+                    const int sp = yin * w + xin;
+                    const uint8_t* s = src + (size_t)sp * 3;
+                    if (sp + 1 < h * w) {  // 4-byte unaligned load stays inside the image
+                        v = reinterpret_cast<const Pix4*>(s)->v & 0xffffffu;
+                    } else {
+                        v = s[0] | s[1] << 8 | s[2] << 16;
+                    }
+                }
+            }
+            px[k] = v;
         }
+        // bytes c0..2 of pixel p0, then bytes of pixel p0+1
+        const unsigned long long both = (unsigned long long)px[0] | (unsigned long long)px[1] << 24;
+        dst[t] = (unsigned)(both >> (8 * c0));
     }
 }
 
@@ -124,7 +282,8 @@ __device__ __forceinline__ uint8_t clip8(int v) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
-// horizontal: in [n][h][w][3] -> tmp [n][h][ow][3]; one thread per (y, ox)
+// horizontal: in [n][h][w][3] -> tmp [n][h][ow][3]; one thread per (y, ox).  The taps are
+// fetched four pixels (12 bytes, one unaligned load) at a time.
 __global__ __launch_bounds__(kBlock) void resample_h_kernel(const uint8_t* __restrict__ in,
                                                             uint8_t* __restrict__ tmp, int h, int w,
                                                             int ow, const int32_t* __restrict__ bounds,
@@ -144,7 +303,18 @@ __global__ __launch_bounds__(kBlock) void resample_h_kernel(const uint8_t* __res
         const int32_t* k = kx + (size_t)ox * ks;
         const uint8_t* p = src + ((size_t)y * w + xmin) * 3;
         int s0 = 1 << (kPrec - 1), s1 = s0, s2 = s0;
-        for (int i = 0; i < cnt; ++i) {
+        int i = 0;
+        for (; i + 4 <= cnt; i += 4) {
+            const Row12 q = *reinterpret_cast<const Row12*>(p + 3 * i);
+            const int c0 = k[i], c1 = k[i + 1], c2 = k[i + 2], c3 = k[i + 3];
+            s0 += (int)(q.a & 0xff) * c0 + (int)(q.a >> 24) * c1 + (int)((q.b >> 16) & 0xff) * c2 +
+                  (int)((q.c >> 8) & 0xff) * c3;
+            s1 += (int)((q.a >> 8) & 0xff) * c0 + (int)(q.b & 0xff) * c1 + (int)(q.b >> 24) * c2 +
+                  (int)((q.c >> 16) & 0xff) * c3;
+            s2 += (int)((q.a >> 16) & 0xff) * c0 + (int)((q.b >> 8) & 0xff) * c1 +
+                  (int)(q.c & 0xff) * c2 + (int)(q.c >> 24) * c3;
+        }
+        for (; i < cnt; ++i) {
             const int c = k[i];
             s0 += p[3 * i] * c;
             s1 += p[3 * i + 1] * c;
@@ -157,7 +327,9 @@ __global__ __launch_bounds__(kBlock) void resample_h_kernel(const uint8_t* __res
     }
 }
 
-// vertical: tmp [n][h][ow][3] -> out [n][oh][ow][3]; one thread per (oy, byte column)
+// vertical: tmp [n][h][ow][3] -> out [n][oh][ow][3]; one thread per (oy, 4 consecutive bytes)
+// when the row is a whole number of dwords, else one thread per byte.
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void resample_v_kernel(const uint8_t* __restrict__ tmp,
                                                             uint8_t* __restrict__ out, int h, int oh,
                                                             int ow, const int32_t* __restrict__ bounds,
@@ -166,19 +338,34 @@ __global__ __launch_bounds__(kBlock) void resample_v_kernel(const uint8_t* __res
     const unsigned n = blockIdx.y;
     const int32_t* bnd = bounds + (per_image ? (size_t)n * oh * 2 : 0);
     const int32_t* ky = kk + (per_image ? (size_t)n * oh * ks : 0);
-    const int rowb = ow * 3;
+    const int rowb = ow * 3, rowv = rowb / VEC;
     const uint8_t* src = tmp + (size_t)n * h * rowb;
     uint8_t* dst = out + (size_t)n * oh * rowb;
-    const int total = oh * rowb;
+    const int total = oh * rowv;
     for (int t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
-        const int oy = t / rowb, xb = t - oy * rowb;
+        const int oy = t / rowv, xv = t - oy * rowv;
         const int ymin = clampi(bnd[2 * oy], 0, h);
         const int cnt = min(bnd[2 * oy + 1], min(ks, h - ymin));
         const int32_t* k = ky + (size_t)oy * ks;
-        const uint8_t* p = src + (size_t)ymin * rowb + xb;
-        int s = 1 << (kPrec - 1);
-        for (int i = 0; i < cnt; ++i) s += p[(size_t)i * rowb] * k[i];
-        dst[t] = clip8(s);
+        const uint8_t* p = src + (size_t)ymin * rowb + xv * VEC;
+        if (VEC == 4) {
+            int a0 = 1 << (kPrec - 1), a1 = a0, a2 = a0, a3 = a0;
+            for (int i = 0; i < cnt; ++i) {
+                const unsigned v = *reinterpret_cast<const uint32_t*>(p + (size_t)i * rowb);
+                const int c = k[i];
+                a0 += (int)(v & 0xff) * c;
+                a1 += (int)((v >> 8) & 0xff) * c;
+                a2 += (int)((v >> 16) & 0xff) * c;
+                a3 += (int)(v >> 24) * c;
+            }
+            *reinterpret_cast<uint32_t*>(dst + (size_t)oy * rowb + xv * 4) =
+                (unsigned)clip8(a0) | (unsigned)clip8(a1) << 8 | (unsigned)clip8(a2) << 16 |
+                (unsigned)clip8(a3) << 24;
+        } else {
+            int sacc = 1 << (kPrec - 1);
+            for (int i = 0; i < cnt; ++i) sacc += p[(size_t)i * rowb] * k[i];
+            dst[(size_t)oy * rowb + xv] = clip8(sacc);
+        }
     }
 }
 
@@ -192,9 +379,15 @@ int lf_warp_bicubic_u8(const uint8_t* in, uint8_t* out, const double* coeffs, in
     LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_warp_bicubic: bad dims n=%d h=%d w=%d", n, h, w);
     LF_REQUIRE((size_t)h * w < (1u << 30), "lf_warp_bicubic: image too large");
     LF_REQUIRE(in != out, "lf_warp_bicubic: in-place warp is not supported");
-    dim3 grid(lf::stream_grid((size_t)h * w, kBlock, 1024), n);
-    warp_bicubic_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, coeffs, perspective, h,
-                                                                    w);
+    const int persp = perspective & 1;
+    if (perspective & 2) {  // caller's hint: the maps are axis-aligned scales (verified per image)
+        dim3 grid(lf::stream_grid((size_t)((h + kStrip - 1) / kStrip) * w, kBlock, 1024), n);
+        warp_bicubic_strip_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, coeffs, persp, h,
+                                                                              w);
+    } else {
+        dim3 grid(lf::stream_grid((size_t)h * w, kBlock, 1024), n);
+        warp_bicubic_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, coeffs, persp, h, w);
+    }
     return lf::check_launch("lf_warp_bicubic");
 }
 
@@ -224,8 +417,13 @@ int lf_resample_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int n, int h, 
     hipStream_t s = lf::as_stream(stream);
     resample_h_kernel<<<dim3(lf::stream_grid((size_t)h * ow, kBlock, 1024), n), kBlock, 0, s>>>(
         in, tmp, h, w, ow, xbounds, xk, kx, per_image_coeffs);
-    resample_v_kernel<<<dim3(lf::stream_grid((size_t)oh * ow * 3, kBlock, 1024), n), kBlock, 0,
-                        s>>>(tmp, out, h, oh, ow, ybounds, yk, ky, per_image_coeffs);
+    const bool vec = (ow * 3) % 4 == 0 && ((reinterpret_cast<size_t>(tmp) | reinterpret_cast<size_t>(out)) & 3) == 0;
+    if (vec)
+        resample_v_kernel<4><<<dim3(lf::stream_grid((size_t)oh * ow * 3 / 4, kBlock, 1024), n), kBlock,
+                               0, s>>>(tmp, out, h, oh, ow, ybounds, yk, ky, per_image_coeffs);
+    else
+        resample_v_kernel<1><<<dim3(lf::stream_grid((size_t)oh * ow * 3, kBlock, 1024), n), kBlock, 0,
+                               s>>>(tmp, out, h, oh, ow, ybounds, yk, ky, per_image_coeffs);
     return lf::check_launch("lf_resample");
 }
 

@@ -213,15 +213,17 @@ def gauss_blur_u8(x: torch.Tensor, ksize: int, sigma: float) -> torch.Tensor:
 from .preprocessing import geometry as _geo  # noqa: E402
 
 
-def warp_bicubic_u8(x: torch.Tensor, coeffs: torch.Tensor, perspective: bool) -> torch.Tensor:
-    """Image.transform(size, AFFINE|PERSPECTIVE, coeffs, BICUBIC); coeffs f64 [N,8]."""
+def warp_bicubic_u8(x: torch.Tensor, coeffs: torch.Tensor, perspective: bool,
+                    axis_aligned: bool = False) -> torch.Tensor:
+    """Image.transform(size, AFFINE|PERSPECTIVE, coeffs, BICUBIC); coeffs f64 [N,8].
+    axis_aligned: speed hint for pure scale maps (a1 = a3 = 0); verified on the device."""
     n, h, w = _hwc(x, "warp_bicubic.x")
     _chk(coeffs, _F64, "warp_bicubic.coeffs", 2)
     if tuple(coeffs.shape) != (n, 8):
         raise ValueError("warp_bicubic.coeffs: expected [N,8] float64")
     out = torch.empty_like(x)
     _lib.call("lf_warp_bicubic_u8", x.data_ptr(), out.data_ptr(), coeffs.data_ptr(),
-              1 if perspective else 0, n, h, w, _stream())
+              (1 if perspective else 0) | (2 if axis_aligned else 0), n, h, w, _stream())
     return out
 
 

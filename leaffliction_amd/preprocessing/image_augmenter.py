@@ -64,7 +64,7 @@ def apply_batch(op: str, x, params: Sequence[Dict[str, Any]]) -> List:
         return ops.rotate_expand_u8(x, [p["angle"] for p in params], fill=255)
     if op in ("skew", "shear"):
         co = torch.tensor([p["coeffs"] for p in params], dtype=torch.float64, device=dev)
-        return list(ops.warp_bicubic_u8(x, co, perspective=(op == "skew")))
+        return list(ops.warp_bicubic_u8(x, co, perspective=(op == "skew"), axis_aligned=(op == "skew")))
     if op == "crop":
         return list(ops.crop_resize_lanczos_u8(x, [p["box"] for p in params]))
     if op == "distortion":
