@@ -73,12 +73,17 @@ void conv_mfma_kernel(ConvArgs p) {
     constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO, PP = PW * PH;
     constexpr int PATCH = kKC * PP;
     constexpr int WSZ = kKC * TAPS * CT;
-    // vector staging: per patch row TW/4 float4 interior items + 2 halo scalars
-    constexpr int TW4 = TW / 4, VROW = TW4 + 2 * HALO;
-    constexpr int NPI = kKC * PH * VROW, IPT = (NPI + kThreads - 1) / kThreads;
+    // vector staging: per patch row TW/4 float4 interior items + 2 halo scalars, kept in two
+    // homogeneous item arrays (mixing both kinds in one array makes the compiler wait for
+    // every load right where it is issued)
+    constexpr int TW4 = TW / 4;
+    constexpr int NVI = kKC * PH * TW4, IPT = (NVI + kThreads - 1) / kThreads;
+    constexpr int NHI = kKC * PH * 2 * HALO, HPT = (NHI + kThreads - 1) / kThreads;
     constexpr int CT4 = CT / 4, NWI = kKC * TAPS * CT4, WPT = (NWI + kThreads - 1) / kThreads;
+    constexpr int kMaxProC = 512;  // prologue scale/shift staged in LDS for up to this many channels
 
     __shared__ __attribute__((aligned(16))) float lds[PATCH + WSZ];
+    __shared__ float lsc[2 * kMaxProC];
     float* lp = lds;
     float* lw = lds + PATCH;
 
@@ -143,36 +148,46 @@ void conv_mfma_kernel(ConvArgs p) {
     if (vec) {
         // ---------------- vector staging with register prefetch ----------------
         float4 pv[IPT];
+        float ph[HPT > 0 ? HPT : 1];
         float4 wv[WPT];
-        unsigned okmask = 0;  // bit i: patch item i holds real (in-image) data
+        unsigned okmask = 0;  // bit i: interior item i in-image; bit 16+i: halo item i in-image
         // variants with > 64 accumulators have no registers left to hold the weight prefetch:
         // they prefetch the patch only and fetch the (L2-resident) weights in the store phase
         constexpr bool kPrefetchW = MB * NB * 16 <= 64;
+        if (pro) {  // BatchNorm scale/shift of the producer: staged once per workgroup
+            for (int c = tid; c < p.cin && c < kMaxProC; c += kThreads) {
+                lsc[c] = p.in_scale[c];
+                lsc[kMaxProC + c] = p.in_shift[c];
+            }
+        }
         auto load_patch = [&](int c0) {
             okmask = 0;
 #pragma unroll
             for (int i = 0; i < IPT; ++i) {
                 const int e = tid + i * kThreads;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < NPI) {
-                    const int kc = e / (PH * VROW), rem = e - kc * (PH * VROW);
-                    const int py = rem / VROW, slot = rem - py * VROW;
-                    const int c = c0 + kc, gy = ty0 + py - HALO;
-                    if (c < p.cin && gy >= 0 && gy < p.h) {
-                        const float* row = xin + (unsigned)c * uhw + (unsigned)gy * (unsigned)p.wd;
-                        if (slot < TW4) {
-                            v = *reinterpret_cast<const float4*>(row + tx0 + 4 * slot);
-                            okmask |= 1u << i;
-                        } else {
-                            const int gx = slot == TW4 ? tx0 - 1 : tx0 + TW;
-                            if (gx >= 0 && gx < p.wd) {
-                                v.x = row[gx];
-                                okmask |= 1u << i;
-                            }
-                        }
-                    }
+                const int kc = e / (PH * TW4), rem = e - kc * (PH * TW4);
+                const int py = rem / TW4, slot = rem - py * TW4;
+                const int c = c0 + kc, gy = ty0 + py - HALO;
+                if (e < NVI && c < p.cin && gy >= 0 && gy < p.h) {
+                    v = *reinterpret_cast<const float4*>(xin + (unsigned)c * uhw +
+                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                    okmask |= 1u << i;
                 }
                 pv[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) {
+                const int e = tid + i * kThreads;
+                float v = 0.f;
+                const int kc = e / (PH * 2), rem = e - kc * (PH * 2);
+                const int py = rem >> 1, side = rem & 1;
+                const int c = c0 + kc, gy = ty0 + py - HALO, gx = side ? tx0 + TW : tx0 - 1;
+                if (e < NHI && c < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd) {
+                    v = xin[(unsigned)c * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx];
+                    okmask |= 1u << (16 + i);
+                }
+                ph[i] = v;
             }
         };
         auto load_weights = [&](int c0) {
@@ -181,41 +196,48 @@ void conv_mfma_kernel(ConvArgs p) {
             for (int i = 0; i < WPT; ++i) {
                 const int e = tid + i * kThreads;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < NWI) {
-                    const int row = e / CT4, col = (e - row * CT4) * 4;
-                    if (row < wvalid && co0 + col < p.cout)
-                        v = *reinterpret_cast<const float4*>(
-                            p.w + ((unsigned)c0 * TAPS + row) * (unsigned)p.cout + (unsigned)(co0 + col));
-                }
+                const int row = e / CT4, col = (e - row * CT4) * 4;
+                if (e < NWI && row < wvalid && co0 + col < p.cout)
+                    v = *reinterpret_cast<const float4*>(
+                        p.w + ((unsigned)c0 * TAPS + row) * (unsigned)p.cout + (unsigned)(co0 + col));
                 wv[i] = v;
             }
         };
+        auto pro_sc = [&](int c) { return c < kMaxProC ? lsc[c] : p.in_scale[c]; };
+        auto pro_sh = [&](int c) { return c < kMaxProC ? lsc[kMaxProC + c] : p.in_shift[c]; };
         auto store_chunk = [&](int c0) {
             if (!kPrefetchW) load_weights(c0);
 #pragma unroll
             for (int i = 0; i < IPT; ++i) {
                 const int e = tid + i * kThreads;
-                if (e < NPI) {
-                    const int kc = e / (PH * VROW), rem = e - kc * (PH * VROW);
-                    const int py = rem / VROW, slot = rem - py * VROW;
+                if (e < NVI) {
+                    const int kc = e / (PH * TW4), rem = e - kc * (PH * TW4);
+                    const int py = rem / TW4, slot = rem - py * TW4;
                     float4 v = pv[i];
                     if (pro && (okmask >> i & 1u)) {
-                        const float sc = p.in_scale[c0 + kc], sh = p.in_shift[c0 + kc];
+                        const float sc = pro_sc(c0 + kc), sh = pro_sh(c0 + kc);
                         v.x = pro_apply(v.x, sc, sh, p.in_relu);
                         v.y = pro_apply(v.y, sc, sh, p.in_relu);
                         v.z = pro_apply(v.z, sc, sh, p.in_relu);
                         v.w = pro_apply(v.w, sc, sh, p.in_relu);
                     }
-                    float* dst = lp + kc * PP + py * PW;
-                    if (slot < TW4) {
-                        dst += HALO + 4 * slot;
-                        dst[0] = v.x;
-                        dst[1] = v.y;
-                        dst[2] = v.z;
-                        dst[3] = v.w;
-                    } else {
-                        dst[slot == TW4 ? 0 : PW - 1] = v.x;
-                    }
+                    float* dst = lp + kc * PP + py * PW + HALO + 4 * slot;
+                    dst[0] = v.x;
+                    dst[1] = v.y;
+                    dst[2] = v.z;
+                    dst[3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) {
+                const int e = tid + i * kThreads;
+                if (e < NHI) {
+                    const int kc = e / (PH * 2), rem = e - kc * (PH * 2);
+                    const int py = rem >> 1, side = rem & 1;
+                    float v = ph[i];
+                    if (pro && (okmask >> (16 + i) & 1u))
+                        v = pro_apply(v, pro_sc(c0 + kc), pro_sh(c0 + kc), p.in_relu);
+                    lp[kc * PP + py * PW + (side ? PW - 1 : 0)] = v;
                 }
             }
 #pragma unroll
@@ -337,9 +359,11 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
     constexpr int XSZ = CI_T * PP, DSZ = CO_T * DP;
     constexpr int RED = KSPL > 1 ? TAPS * 1024 : 0;  // one wave's accumulators
     constexpr int LDSF = XSZ + DSZ > RED ? XSZ + DSZ : RED;
-    constexpr int TW4 = TW / 4, VROW = TW4 + 2 * HALO;
-    constexpr int NXI = CI_T * PH * VROW, XPT = (NXI + kThreads - 1) / kThreads;
+    constexpr int TW4 = TW / 4;
+    constexpr int NXI = CI_T * PH * TW4, XPT = (NXI + kThreads - 1) / kThreads;      // interior float4 items
+    constexpr int NHI = CI_T * PH * 2 * HALO, HPT = (NHI + kThreads - 1) / kThreads;  // halo scalars
     constexpr int NDI = CO_T * TH * TW4, DPT = (NDI + kThreads - 1) / kThreads;
+    constexpr int kMaxProC = 512;
     __shared__ float lds[LDSF];
     float* lx = lds;
     float* ld = lds + XSZ;
@@ -387,7 +411,17 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
 
     if (p.vec_ok) {  // every tile is full in x (host guarantees W % TW == 0 for this path)
         float4 xv[XPT], dv[DPT];
+        float xh[HPT > 0 ? HPT : 1];
         unsigned xok = 0;
+        // producer BatchNorm scale/shift of this workgroup's CI_T channels, staged once in LDS
+        __shared__ float lsc[kMaxProC / 2];
+        if (pro) {
+            for (int c = tid; c < CI_T; c += kThreads) {
+                const int gc = ci0 + c;
+                lsc[c] = gc < p.cin ? p.in_scale[gc] : 1.f;
+                lsc[kMaxProC / 4 + c] = gc < p.cin ? p.in_shift[gc] : 0.f;
+            }
+        }
         auto load_x = [&](int item, auto i0c, auto i1c) {
             constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
             const int n = item / tiles, t = item - n * tiles;
@@ -398,25 +432,30 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
             for (int i = I0; i < I1; ++i) {
                 const int e = tid + i * kThreads;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < NXI) {
-                    const int c = e / (PH * VROW), rem = e - c * (PH * VROW);
-                    const int py = rem / VROW, slot = rem - py * VROW;
-                    const int gc = ci0 + c, gy = ty0 + py - HALO;
-                    if (gc < p.cin && gy >= 0 && gy < p.h) {
-                        const float* row = xin + (unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd;
-                        if (slot < TW4) {
-                            v = *reinterpret_cast<const float4*>(row + tx0 + 4 * slot);
-                            xok |= 1u << i;
-                        } else {
-                            const int gx = slot == TW4 ? tx0 - 1 : tx0 + TW;
-                            if (gx >= 0 && gx < p.wd) {
-                                v.x = row[gx];
-                                xok |= 1u << i;
-                            }
-                        }
-                    }
+                const int c = e / (PH * TW4), rem = e - c * (PH * TW4);
+                const int py = rem / TW4, slot = rem - py * TW4;
+                const int gc = ci0 + c, gy = ty0 + py - HALO;
+                if (e < NXI && gc < p.cin && gy >= 0 && gy < p.h) {
+                    v = *reinterpret_cast<const float4*>(xin + (unsigned)gc * uhw +
+                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                    xok |= 1u << i;
                 }
                 xv[i] = v;
+            }
+            if (I1 == XPT) {
+#pragma unroll
+                for (int i = 0; i < HPT; ++i) {
+                    const int e = tid + i * kThreads;
+                    float v = 0.f;
+                    const int c = e / (PH * 2), rem = e - c * (PH * 2);
+                    const int py = rem >> 1, side = rem & 1;
+                    const int gc = ci0 + c, gy = ty0 + py - HALO, gx = side ? tx0 + TW : tx0 - 1;
+                    if (e < NHI && gc < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd) {
+                        v = xin[(unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx];
+                        xok |= 1u << (16 + i);
+                    }
+                    xh[i] = v;
+                }
             }
         };
         auto load_d = [&](int item) {
@@ -444,25 +483,34 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
             for (int i = I0; i < I1; ++i) {
                 const int e = tid + i * kThreads;
                 if (e < NXI) {
-                    const int c = e / (PH * VROW), rem = e - c * (PH * VROW);
-                    const int py = rem / VROW, slot = rem - py * VROW;
+                    const int c = e / (PH * TW4), rem = e - c * (PH * TW4);
+                    const int py = rem / TW4, slot = rem - py * TW4;
                     float4 v = xv[i];
                     if (pro && (xok >> i & 1u)) {
-                        const float sc = p.in_scale[ci0 + c], sh = p.in_shift[ci0 + c];
+                        const float sc = lsc[c], sh = lsc[kMaxProC / 4 + c];
                         v.x = pro_apply(v.x, sc, sh, p.in_relu);
                         v.y = pro_apply(v.y, sc, sh, p.in_relu);
                         v.z = pro_apply(v.z, sc, sh, p.in_relu);
                         v.w = pro_apply(v.w, sc, sh, p.in_relu);
                     }
-                    float* dst = lx + c * PP + py * PW;
-                    if (slot < TW4) {
-                        dst += HALO + 4 * slot;
-                        dst[0] = v.x;
-                        dst[1] = v.y;
-                        dst[2] = v.z;
-                        dst[3] = v.w;
-                    } else {
-                        dst[slot == TW4 ? 0 : PW - 1] = v.x;
+                    float* dst = lx + c * PP + py * PW + HALO + 4 * slot;
+                    dst[0] = v.x;
+                    dst[1] = v.y;
+                    dst[2] = v.z;
+                    dst[3] = v.w;
+                }
+            }
+            if (I1 == XPT) {
+#pragma unroll
+                for (int i = 0; i < HPT; ++i) {
+                    const int e = tid + i * kThreads;
+                    if (e < NHI) {
+                        const int c = e / (PH * 2), rem = e - c * (PH * 2);
+                        const int py = rem >> 1, side = rem & 1;
+                        float v = xh[i];
+                        if (pro && (xok >> (16 + i) & 1u))
+                            v = pro_apply(v, lsc[c], lsc[kMaxProC / 4 + c], p.in_relu);
+                        lx[c * PP + py * PW + (side ? PW - 1 : 0)] = v;
                     }
                 }
             }
@@ -620,9 +668,11 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
     constexpr int XSZ = CI_T * PP, DSZ = CO_T * DP;
     constexpr int RED = KSPL > 1 ? 3 * 3 * 1024 : 0;  // one (ci,co) block's three row-waves
     constexpr int LDSF = XSZ + DSZ > RED ? XSZ + DSZ : RED;
-    constexpr int TW4 = TW / 4, VROW = TW4 + 2;
-    constexpr int NXI = CI_T * PH * VROW, XPT = (NXI + NT - 1) / NT;
+    constexpr int TW4 = TW / 4;
+    constexpr int NXI = CI_T * PH * TW4, XPT = (NXI + NT - 1) / NT;      // interior float4 items
+    constexpr int NHI = CI_T * PH * 2 * 1, HPT = (NHI + NT - 1) / NT;  // halo scalars
     constexpr int NDI = CO_T * TH * TW4, DPT = (NDI + NT - 1) / NT;
+    constexpr int kMaxProC = 512;
     __shared__ float lds[LDSF];
     float* lx = lds;
     float* ld = lds + XSZ;
@@ -668,7 +718,17 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
 
     if (p.vec_ok) {  // every tile is full in x (host guarantees W % TW == 0 for this path)
         float4 xv[XPT], dv[DPT];
+        float xh[HPT];
         unsigned xok = 0;
+        // producer BatchNorm scale/shift of this workgroup's CI_T channels, staged once in LDS
+        __shared__ float lsc[kMaxProC / 2];
+        if (pro) {
+            for (int c = tid; c < CI_T; c += NT) {
+                const int gc = ci0 + c;
+                lsc[c] = gc < p.cin ? p.in_scale[gc] : 1.f;
+                lsc[kMaxProC / 4 + c] = gc < p.cin ? p.in_shift[gc] : 0.f;
+            }
+        }
         auto load_item = [&](int item) {
             const int n = item / tiles, t = item - n * tiles;
             const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
@@ -679,38 +739,39 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             for (int i = 0; i < XPT; ++i) {
                 const int e = tid + i * NT;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < NXI) {
-                    const int c = e / (PH * VROW), rem = e - c * (PH * VROW);
-                    const int py = rem / VROW, slot = rem - py * VROW;
-                    const int gc = ci0 + c, gy = ty0 + py - 1;
-                    if (gc < p.cin && gy >= 0 && gy < p.h) {
-                        const float* row = xin + (unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd;
-                        if (slot < TW4) {
-                            v = *reinterpret_cast<const float4*>(row + tx0 + 4 * slot);
-                            xok |= 1u << i;
-                        } else {
-                            const int gx = slot == TW4 ? tx0 - 1 : tx0 + TW;
-                            if (gx >= 0 && gx < p.wd) {
-                                v.x = row[gx];
-                                xok |= 1u << i;
-                            }
-                        }
-                    }
+                const int c = e / (PH * TW4), rem = e - c * (PH * TW4);
+                const int py = rem / TW4, slot = rem - py * TW4;
+                const int gc = ci0 + c, gy = ty0 + py - 1;
+                if (e < NXI && gc < p.cin && gy >= 0 && gy < p.h) {
+                    v = *reinterpret_cast<const float4*>(xin + (unsigned)gc * uhw +
+                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                    xok |= 1u << i;
                 }
                 xv[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) {
+                const int e = tid + i * NT;
+                float v = 0.f;
+                const int c = e / (PH * 2), rem = e - c * (PH * 2);
+                const int py = rem >> 1, side = rem & 1;
+                const int gc = ci0 + c, gy = ty0 + py - 1, gx = side ? tx0 + TW : tx0 - 1;
+                if (e < NHI && gc < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd) {
+                    v = xin[(unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx];
+                    xok |= 1u << (16 + i);
+                }
+                xh[i] = v;
             }
 #pragma unroll
             for (int i = 0; i < DPT; ++i) {
                 const int e = tid + i * NT;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < NDI) {
-                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
-                    const int py = rem / TW4, slot = rem - py * TW4;
-                    const int gc = co0 + c, gy = ty0 + py;
-                    if (gc < p.cout && gy < p.h)
-                        v = *reinterpret_cast<const float4*>(din + (unsigned)gc * uhw +
-                                                             (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
-                }
+                const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                const int py = rem / TW4, slot = rem - py * TW4;
+                const int gc = co0 + c, gy = ty0 + py;
+                if (e < NDI && gc < p.cout && gy < p.h)
+                    v = *reinterpret_cast<const float4*>(din + (unsigned)gc * uhw +
+                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
                 dv[i] = v;
             }
         };
@@ -719,26 +780,33 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             for (int i = 0; i < XPT; ++i) {
                 const int e = tid + i * NT;
                 if (e < NXI) {
-                    const int c = e / (PH * VROW), rem = e - c * (PH * VROW);
-                    const int py = rem / VROW, slot = rem - py * VROW;
+                    const int c = e / (PH * TW4), rem = e - c * (PH * TW4);
+                    const int py = rem / TW4, slot = rem - py * TW4;
                     float4 v = xv[i];
                     if (pro && (xok >> i & 1u)) {
-                        const float sc = p.in_scale[ci0 + c], sh = p.in_shift[ci0 + c];
+                        const float sc = lsc[c], sh = lsc[kMaxProC / 4 + c];
                         v.x = pro_apply(v.x, sc, sh, p.in_relu);
                         v.y = pro_apply(v.y, sc, sh, p.in_relu);
                         v.z = pro_apply(v.z, sc, sh, p.in_relu);
                         v.w = pro_apply(v.w, sc, sh, p.in_relu);
                     }
-                    float* dst = lx + c * PP + py * PW;
-                    if (slot < TW4) {
-                        dst += 1 + 4 * slot;
-                        dst[0] = v.x;
-                        dst[1] = v.y;
-                        dst[2] = v.z;
-                        dst[3] = v.w;
-                    } else {
-                        dst[slot == TW4 ? 0 : PW - 1] = v.x;
-                    }
+                    float* dst = lx + c * PP + py * PW + 1 + 4 * slot;
+                    dst[0] = v.x;
+                    dst[1] = v.y;
+                    dst[2] = v.z;
+                    dst[3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) {
+                const int e = tid + i * NT;
+                if (e < NHI) {
+                    const int c = e / (PH * 2), rem = e - c * (PH * 2);
+                    const int py = rem >> 1, side = rem & 1;
+                    float v = xh[i];
+                    if (pro && (xok >> (16 + i) & 1u))
+                        v = pro_apply(v, lsc[c], lsc[kMaxProC / 4 + c], p.in_relu);
+                    lx[c * PP + py * PW + (side ? PW - 1 : 0)] = v;
                 }
             }
 #pragma unroll
