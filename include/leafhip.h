@@ -242,14 +242,16 @@ int lf_bcast_planes_f32(const float* v, float* out, int planes, int hw, float sc
                         lf_stream_t stream);
 
 /* ---- Squeeze-Excite (cnn.py:9-17): s = sigmoid(relu(m w1 + b1) w2 + b2) ---- */
-/* m [n][c], w1 [c][cr], w2 [cr][c]; z1 = hidden activations (saved for backward). */
+/* m [n][c], w1 [c][cr], w2 [cr][c]; z1 = hidden activations (saved for backward).
+ * Backward writes dm = dL/dm * dm_scale (dm_scale = 1/(H*W) folds the GlobalAveragePooling2D
+ * the squeeze came through). */
 int lf_se_fwd_f32(const float* m, const float* w1, const float* b1, const float* w2,
                   const float* b2, float* z1, float* s, int n, int c, int cr, lf_stream_t stream);
 size_t lf_se_bwd_workspace(int n, int c, int cr);
 int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float* s,
                   const float* w1, const float* w2, float* dm, float* dw1, float* db1, float* dw2,
-                  float* db2, int n, int c, int cr, void* workspace, size_t ws_bytes,
-                  lf_stream_t stream);
+                  float* db2, int n, int c, int cr, float dm_scale, void* workspace,
+                  size_t ws_bytes, lf_stream_t stream);
 
 /* ---- residual tail (cnn.py:47-48,94-96): Add -> ReLU -> SpatialDropout2D -> MaxPool2D(2) ---- */
 /* r = relu(sc' + a*s[n][c]) with a = relu(y*a_scale[c]+a_shift[c]) (BN2+ReLU fused; a = y when

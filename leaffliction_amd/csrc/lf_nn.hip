@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void se_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(kBlock) void se_bwd_sample_kernel(
     const float* __restrict__ ds, const float* __restrict__ s, const float* __restrict__ z1,
     const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ dpre2,
-    float* __restrict__ dpre1, float* __restrict__ dm, int c, int cr) {
+    float* __restrict__ dpre1, float* __restrict__ dm, int c, int cr, float dm_scale) {
     extern __shared__ float sm[];  // [c] dpre2, [cr] dpre1
     float* l2 = sm;
     float* l1 = sm + c;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void se_bwd_sample_kernel(
     for (int i = threadIdx.x; i < c; i += kBlock) {
         float acc = 0.f;
         for (int j = 0; j < cr; ++j) acc = fmaf(l1[j], w1[(size_t)i * cr + j], acc);
-        dm[(size_t)n * c + i] = acc;
+        dm[(size_t)n * c + i] = acc * dm_scale;
     }
 }
 
@@ -878,8 +878,8 @@ size_t lf_se_bwd_workspace(int n, int c, int cr) {
 
 int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float* s,
                   const float* w1, const float* w2, float* dm, float* dw1, float* db1, float* dw2,
-                  float* db2, int n, int c, int cr, void* workspace, size_t ws_bytes,
-                  lf_stream_t stream) {
+                  float* db2, int n, int c, int cr, float dm_scale, void* workspace,
+                  size_t ws_bytes, lf_stream_t stream) {
     LF_REQUIRE(ds && m && z1 && s && w1 && w2 && dm && dw1 && db1 && dw2 && db2 && workspace,
                "lf_se_bwd: null buffer");
     LF_REQUIRE(n > 0 && c > 0 && cr > 0 && c + cr <= 8192, "lf_se_bwd: bad dims n=%d c=%d cr=%d", n, c, cr);
@@ -891,7 +891,7 @@ int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float*
     float* dpre2 = static_cast<float*>(workspace);
     float* dpre1 = dpre2 + (size_t)n * c;
     se_bwd_sample_kernel<<<n, kBlock, (size_t)(c + cr) * sizeof(float), st>>>(ds, s, z1, w1, w2, dpre2,
-                                                                              dpre1, dm, c, cr);
+                                                                              dpre1, dm, c, cr, dm_scale);
     // dw1[c][cr] = sum_n m[n][c] dpre1[n][cr]; dw2[cr][c] = sum_n z1[n][cr] dpre2[n][c]
     outer_sum_kernel<<<lf::stream_grid((size_t)(c + 1) * cr, kBlock), kBlock, 0, st>>>(m, dpre1, dw1, db1,
                                                                                     n, c, cr);

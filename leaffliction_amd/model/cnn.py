@@ -149,6 +149,7 @@ class LeafCNN:
         self.opt_step = 0
         self.ema_started = False
         self._bufs: Dict[Any, Dict[str, torch.Tensor]] = {}
+        self._stage: Dict[Any, Dict[str, Any]] = {}
         self._wt: Dict[str, torch.Tensor] = {}
         self._saved: Dict[str, Any] = {}
         self._global_n: Optional[int] = None
@@ -187,14 +188,81 @@ class LeafCNN:
         return [float(v) for v in self.norm.mean], [float(v) for v in self.norm.denom]
 
     # --------------------------------------------------------------- input
-    def draw_augmentation(self, n: int) -> torch.Tensor:
-        """Per-image {flip, cos, sin, contrast}: RandomFlip("horizontal"), RandomRotation(0.05)
-        (angle ~ U(-0.05, 0.05) * 2 pi), RandomContrast(0.1) (factor ~ U(0.9, 1.1)); cnn.py:76-80."""
+    def _host_augmentation(self, n: int) -> np.ndarray:
         flip = (self.np_rng.uniform(size=n) <= 0.5).astype(np.float32)
         ang = self.np_rng.uniform(-0.05, 0.05, size=n) * 2.0 * math.pi
         ct = self.np_rng.uniform(0.9, 1.1, size=n).astype(np.float32)
-        a = np.stack([flip, np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32), ct], 1)
+        return np.stack([flip, np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32), ct], 1)
+
+    def draw_augmentation(self, n: int) -> torch.Tensor:
+        """Per-image {flip, cos, sin, contrast}: RandomFlip("horizontal"), RandomRotation(0.05)
+        (angle ~ U(-0.05, 0.05) * 2 pi), RandomContrast(0.1) (factor ~ U(0.9, 1.1)); cnn.py:76-80."""
+        a = self._host_augmentation(n)
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def _host_dropout(self, n: int, out: List[torch.Tensor]) -> None:
+        """Keep-scales written into the host views `out` (one per stage, then the head)."""
+        k = 0
+        if self.drop_block > 0:
+            for f in self.widths:
+                keep = (torch.rand((n, f), generator=self.gen) >= self.drop_block).float()
+                torch.div(keep, 1.0 - self.drop_block, out=out[k])
+                k += 1
+        if self.drop_top > 0:
+            keep = (torch.rand((n, self.widths[-1]), generator=self.gen) >= self.drop_top).float()
+            torch.div(keep, 1.0 - self.drop_top, out=out[k])
+
+    def draw_step_randoms(self, n: int, augment: bool):
+        """All per-step host draws (SpatialDropout2D / Dropout keep-scales, in-model
+        augmentation parameters) through ONE pinned staging buffer and one asynchronous copy:
+        pageable uploads would block the host until the stream drains, once per tensor.
+        Returns (drops, top_drop, aug4) as views of a persistent device buffer."""
+        sizes = []
+        if self.drop_block > 0:
+            sizes += [(n, f) for f in self.widths]
+        if self.drop_top > 0:
+            sizes.append((n, self.widths[-1]))
+        if augment:
+            sizes.append((n, 4))
+        if not sizes:
+            return None, None, None
+        st = self._stage.get((n, augment))
+        if st is None:
+            total = sum(a * b for a, b in sizes)
+            st = {"dev": torch.empty(total, dtype=torch.float32, device=self.device),
+                  "ring": [(torch.empty(total, dtype=torch.float32).pin_memory(),
+                            torch.cuda.Event()) for _ in range(3)], "i": 0, "used": 0}
+            self._stage[(n, augment)] = st
+
+        def views(flat):
+            out, off = [], 0
+            for a, b in sizes:
+                out.append(flat[off:off + a * b].view(a, b))
+                off += a * b
+            return out
+
+        host, ev = st["ring"][st["i"]]
+        if st["used"] >= len(st["ring"]):
+            ev.synchronize()  # the copy that last read this pinned slot has executed
+        st["i"] = (st["i"] + 1) % len(st["ring"])
+        st["used"] += 1
+        hv = views(host)
+        self._host_dropout(n, hv)
+        if augment:
+            hv[-1].copy_(torch.from_numpy(self._host_augmentation(n)))
+        st["dev"].copy_(host, non_blocking=True)
+        ev.record()
+        dv = views(st["dev"])
+        k = 0
+        drops = top = aug4 = None
+        if self.drop_block > 0:
+            drops = dv[:len(self.widths)]
+            k = len(self.widths)
+        if self.drop_top > 0:
+            top = dv[k]
+        if augment:
+            aug4 = dv[-1]
+        return drops, top, aug4
 
     def _input(self, x, training: bool, aug4: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Accepts uint8 [N,H,W,3] (host or device) or float32 [N,H,W,3] in [0,1] (the
@@ -331,8 +399,9 @@ class LeafCNN:
             if self.use_se:
                 dm = B(p + "dm", (n, f))
                 nn.se_bwd(ds, sv[p + "m"], sv[p + "z1"], s, P[p + "se.w1"], P[p + "se.w2"], dm,
-                          G[p + "se.w1"], G[p + "se.b1"], G[p + "se.w2"], G[p + "se.b2"])
-                add_nc = dm.mul_(1.0 / (h * w))
+                          G[p + "se.w1"], G[p + "se.b1"], G[p + "se.w2"], G[p + "se.b2"],
+                          dm_scale=1.0 / (h * w))
+                add_nc = dm
             # conv2 branch: dz2 = (dr*s + dm/HW) * [a2 > 0] -> BN2 backward -> dy2 (gB)
             nn.bn_bwd(gA, y2, st2, P[p + "bn2.gamma"], G[p + "bn2.gamma"], G[p + "bn2.beta"], True,
                       alpha_nc=s, add_nc=add_nc, out=gB)
@@ -364,16 +433,14 @@ class LeafCNN:
     # ------------------------------------------------------------ training
     def draw_dropout(self, n: int):
         """SpatialDropout2D keep-scales [N,C_i] per stage and Dropout keep-scales [N,F]."""
-        drops = None
+        host = []
         if self.drop_block > 0:
-            drops = []
-            for f in self.widths:
-                keep = (torch.rand((n, f), generator=self.gen) >= self.drop_block).float()
-                drops.append((keep / (1.0 - self.drop_block)).to(self.device))
-        top = None
+            host += [torch.empty((n, f)) for f in self.widths]
         if self.drop_top > 0:
-            keep = (torch.rand((n, self.widths[-1]), generator=self.gen) >= self.drop_top).float()
-            top = (keep / (1.0 - self.drop_top)).to(self.device)
+            host.append(torch.empty((n, self.widths[-1])))
+        self._host_dropout(n, host)
+        drops = [t.to(self.device) for t in host[:len(self.widths)]] if self.drop_block > 0 else None
+        top = host[-1].to(self.device) if self.drop_top > 0 else None
         return drops, top
 
     def train_step(self, x, y_true: torch.Tensor, lr: float, *, weight_decay: float = 1e-4,
@@ -386,8 +453,8 @@ class LeafCNN:
         tensors (no host sync)."""
         n = x.shape[0]
         self._global_n = global_n
-        drops, top = self.draw_dropout(n)
-        x0 = self._input(x, True)
+        drops, top, aug4 = self.draw_step_randoms(n, self.augment)
+        x0 = self._input(x, True, aug4)
         probs, loss = self.forward(x0, True, y_true, drops, top)
         self.backward()
         if grad_sync is not None:

@@ -215,13 +215,14 @@ def se_fwd(m, w1, b1, w2, b2, z1, s):
     return s
 
 
-def se_bwd(ds, m, z1, s, w1, w2, dm, dw1, db1, dw2, db2):
+def se_bwd(ds, m, z1, s, w1, w2, dm, dw1, db1, dw2, db2, dm_scale: float = 1.0):
     n, c = m.shape
     cr = w1.shape[1]
     ws = _workspace(_lib.load().lf_se_bwd_workspace(n, c, cr), m.device)
     _lib.call("lf_se_bwd_f32", ds.data_ptr(), m.data_ptr(), z1.data_ptr(), s.data_ptr(),
               w1.data_ptr(), w2.data_ptr(), dm.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
-              dw2.data_ptr(), db2.data_ptr(), n, c, cr, ws.data_ptr(), ws.numel(), _stream())
+              dw2.data_ptr(), db2.data_ptr(), n, c, cr, float(dm_scale), ws.data_ptr(), ws.numel(),
+              _stream())
     return dm
 
 
