@@ -78,7 +78,9 @@ class KernelTimer:
                 n, cin, h, w, cout, k = args[2:8]
                 kname = (WG_NAMES3 if k == 3 else WG_NAMES1)[lib.lf_conv2d_wgrad_variant(n, cin, h, w, cout, k)]
             flop = 2.0 * n * h * w * cin * cout * k * k
-            timer.records.append((kname, flop, e0, e1))
+            # operands once: both activation tensors + the weights / weight-gradient
+            nbytes = 4.0 * (n * h * w * (cin + cout) + cin * cout * k * k)
+            timer.records.append((kname, flop, e0, e1, nbytes))
             return rc
 
         self.lib_mod.call = call
@@ -86,13 +88,15 @@ class KernelTimer:
 
     def summary(self):
         torch.cuda.synchronize()
-        agg = defaultdict(lambda: [0.0, 0.0, 0])
-        for kname, flop, e0, e1 in self.records:
+        agg = defaultdict(lambda: [0.0, 0.0, 0, 0.0])
+        for kname, flop, e0, e1, nbytes in self.records:
             a = agg[kname]
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += flop
             a[2] += 1
-        return {k: {"seconds": v[0], "flop": v[1], "launches": v[2]} for k, v in agg.items()}
+            a[3] += nbytes
+        return {k: {"seconds": v[0], "flop": v[1], "launches": v[2], "bytes": v[3]}
+                for k, v in agg.items()}
 
 
 def cpu_baseline(seconds_budget: float = 25.0):
@@ -301,7 +305,8 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": dom_name,
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                         "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                          "launches_per_step": dom["launches"] / args.steps,
                          "avg_launch_ms": round(dom["seconds"] / dom["launches"] * 1e3, 4),
                          "algorithmic_gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3)},
