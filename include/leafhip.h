@@ -200,7 +200,8 @@ int lf_conv2d_wgrad_reduce_f32(void* workspace, float* dw, int n, int cin, int h
  * keras RandomFlip("horizontal") -> RandomRotation (bilinear, fill_mode="reflect") ->
  * RandomContrast on the [0,1] image, then Normalization (x-mean)/denom.  aug4[n] =
  * {flip 0/1, cos, sin, contrast factor} (device, drawn by the host RNG); mean3/denom3 are
- * HOST pointers (or both null); means_ws is a device scratch of n*3 floats.
+ * HOST pointers (or both null); means_ws is a device scratch of n*24 floats
+ * (8 partial channel sums per image).
  * Stochastic layers: statistical parity with keras, exact parity with oracle/cnn_ref.py. */
 int lf_input_stage_f32(const uint8_t* in, float* out, int n, int h, int w, const float* aug4,
                        const float* mean3, const float* denom3, float* means_ws,
@@ -280,12 +281,14 @@ int lf_mul_f32(const float* a, const float* b, float* out, size_t count, lf_stre
 /* Flat buffers; tensor t occupies [offsets[t], offsets[t+1]).  Per tensor: g' = g + 2*l2[t]*w
  * (kernel_regularizer gradient), clip_by_norm(g', clipnorm) per tensor (0 = off), decoupled
  * decay w -= lr*wd*w, Adam with bias correction at `step` (1-based), then
- * ema = copy ? w : decay*ema + (1-decay)*w (ema may be null).  norms_ws: ntensors floats. */
+ * ema = copy ? w : decay*ema + (1-decay)*w (ema may be null).  norms_out: ntensors floats (the
+ * pre-clip gradient norms, for logging); workspace: lf_adamw_workspace(ntensors) bytes. */
+size_t lf_adamw_workspace(int ntensors);
 int lf_adamw_step_f32(float* param, const float* grad, float* m, float* v, float* ema,
                       const long long* offsets, const float* l2, int ntensors, long long max_count,
                       float lr, float beta1, float beta2, float eps, float weight_decay,
                       float clipnorm, long long step, float ema_decay, int ema_copy,
-                      float* norms_ws, lf_stream_t stream);
+                      float* norms_out, void* workspace, size_t ws_bytes, lf_stream_t stream);
 int lf_ema_update_f32(float* ema, const float* w, size_t count, float decay, int copy,
                       lf_stream_t stream);
 

@@ -65,12 +65,14 @@ SIGNATURES = {
     "lf_head_fwd_f32": [P, P, P, P, P, P, c_int, c_int, c_int, P],
     "lf_head_bwd_f32": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     "lf_mul_f32": [P, P, P, c_size_t, P],
+    "lf_adamw_workspace": [c_int],
     "lf_adamw_step_f32": [P, P, P, P, P, P, P, c_int, C.c_longlong, c_float, c_float, c_float,
-                          c_float, c_float, c_float, C.c_longlong, c_float, c_int, P, P],
+                          c_float, c_float, c_float, C.c_longlong, c_float, c_int, P, P, c_size_t, P],
     "lf_ema_update_f32": [P, P, c_size_t, c_float, c_int, P],
 }
 _RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t,
-             "lf_bn_workspace": c_size_t, "lf_se_bwd_workspace": c_size_t}
+             "lf_bn_workspace": c_size_t, "lf_se_bwd_workspace": c_size_t,
+             "lf_adamw_workspace": c_size_t}
 
 
 class LeafHipError(RuntimeError):

@@ -78,16 +78,18 @@ __device__ __forceinline__ void sample_aug(const uint8_t* __restrict__ src, int 
     }
 }
 
-// per-image channel means of the flipped+rotated image (RandomContrast's mean); grid = n
+// per-image channel sums of the flipped+rotated image (RandomContrast's mean), in kMeanSplit
+// interleaved slices per image: grid = (kMeanSplit, n); input_aug_kernel adds the slices in order
+constexpr int kMeanSplit = 8;
 __global__ __launch_bounds__(kBlock) void aug_means_kernel(const uint8_t* __restrict__ in,
                                                            const float* __restrict__ aug,
                                                            float* __restrict__ means, int h, int w) {
     __shared__ float red[12];
-    const int n = blockIdx.x;
+    const int n = blockIdx.y;
     const uint8_t* src = in + (size_t)n * h * w * 3;
     const float flip = aug[4 * n], cs = aug[4 * n + 1], sn = aug[4 * n + 2];
     float acc[3] = {0.f, 0.f, 0.f};
-    for (int p = threadIdx.x; p < h * w; p += kBlock) {
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < h * w; p += kMeanSplit * kBlock) {
         float rgb[3];
         sample_aug(src, h, w, p / w, p % w, flip, cs, sn, rgb);
         acc[0] += rgb[0];
@@ -96,10 +98,10 @@ __global__ __launch_bounds__(kBlock) void aug_means_kernel(const uint8_t* __rest
     }
     block_sum<3>(acc, red);
     if (threadIdx.x == 0) {
-        const float inv = 1.0f / (float)(h * w);
-        means[3 * n] = acc[0] * inv;
-        means[3 * n + 1] = acc[1] * inv;
-        means[3 * n + 2] = acc[2] * inv;
+        float* dst = means + ((size_t)n * kMeanSplit + blockIdx.x) * 3;
+        dst[0] = acc[0];
+        dst[1] = acc[1];
+        dst[2] = acc[2];
     }
 }
 
@@ -114,7 +116,19 @@ __global__ __launch_bounds__(kBlock) void input_aug_kernel(const uint8_t* __rest
     const uint8_t* src = in + (size_t)n * hw * 3;
     float* dst = out + (size_t)n * hw * 3;
     const float flip = aug[4 * n], cs = aug[4 * n + 1], sn = aug[4 * n + 2], ct = aug[4 * n + 3];
-    const float mu[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+    float mu[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < kMeanSplit; ++k) {
+        const float* part = means + ((size_t)n * kMeanSplit + k) * 3;
+        mu[0] += part[0];
+        mu[1] += part[1];
+        mu[2] += part[2];
+    }
+    {
+        const float inv = 1.0f / (float)hw;
+        mu[0] *= inv;
+        mu[1] *= inv;
+        mu[2] *= inv;
+    }
     const float nm[3] = {m0, m1, m2}, nd[3] = {d0, d1, d2};
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < (int)hw; p += gridDim.x * kBlock) {
         float rgb[3];
@@ -454,22 +468,39 @@ __global__ __launch_bounds__(kBlock) void se_bwd_sample_kernel(
 }
 
 // out[i][j] = sum_n a[n][i] * b[n][j]  (i < ra, j < rb); i == ra row holds sum_n b[n][j] (bias)
+// One workgroup = 64 outputs x 4 batch slices (one wave each); slices combined in fixed order.
 __global__ __launch_bounds__(kBlock) void outer_sum_kernel(const float* __restrict__ a,
                                                            const float* __restrict__ b,
                                                            float* __restrict__ out,
                                                            float* __restrict__ bias_out, int n,
                                                            int ra, int rb) {
+    static_assert(kBlock == 256, "outer_sum_kernel: 4 waves");
+    __shared__ float part[4][64];
     const int total = (ra + 1) * rb;
-    for (int t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    const int per = (n + 3) / 4;
+    const int k0 = slice * per, k1 = min(n, k0 + per);
+    float acc = 0.f;
+    if (t < total) {
         const int i = t / rb, j = t - i * rb;
-        float acc = 0.f;
         if (i < ra) {
-            for (int k = 0; k < n; ++k) acc = fmaf(a[(size_t)k * ra + i], b[(size_t)k * rb + j], acc);
-            out[(size_t)i * rb + j] = acc;
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) acc = fmaf(a[(size_t)k * ra + i], b[(size_t)k * rb + j], acc);
         } else {
-            for (int k = 0; k < n; ++k) acc += b[(size_t)k * rb + j];
-            bias_out[j] = acc;
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) acc += b[(size_t)k * rb + j];
         }
+    }
+    part[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && t < total) {
+        const float r = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        const int i = t / rb, j = t - i * rb;
+        if (i < ra)
+            out[(size_t)i * rb + j] = r;
+        else
+            bias_out[j] = r;
     }
 }
 
@@ -677,17 +708,22 @@ __global__ __launch_bounds__(kBlock) void mul_kernel(const float* __restrict__ a
 // bias-corrected Adam, EMA of the updated weights.  Flat buffers + a segment table.
 // ---------------------------------------------------------------------------
 // norms: one workgroup per tensor: sum over (g + 2*l2*w)^2
-__global__ __launch_bounds__(1024) void adam_norm_kernel(const float* __restrict__ p,
-                                                         const float* __restrict__ g,
-                                                         const long long* __restrict__ offs,
-                                                         const float* __restrict__ l2,
-                                                         float* __restrict__ norms) {
-    __shared__ double red[16];
-    const int t = blockIdx.x;
+// squared gradient norm of tensor t in kNormSplit contiguous slices: grid = (kNormSplit, ntensors)
+constexpr int kNormSplit = 32;
+__global__ __launch_bounds__(kBlock) void adam_norm_kernel(const float* __restrict__ p,
+                                                           const float* __restrict__ g,
+                                                           const long long* __restrict__ offs,
+                                                           const float* __restrict__ l2,
+                                                           double* __restrict__ partial) {
+    __shared__ double red[kBlock / 64];
+    const int t = blockIdx.y;
     const long long b = offs[t], e = offs[t + 1];
+    const long long per = (e - b + kNormSplit - 1) / kNormSplit;
+    const long long s0 = b + per * blockIdx.x, s1 = s0 + per < e ? s0 + per : e;
     const float l2c = 2.f * l2[t];
     double acc = 0.0;
-    for (long long i = b + threadIdx.x; i < e; i += 1024) {
+#pragma unroll 4
+    for (long long i = s0 + threadIdx.x; i < s1; i += kBlock) {
         const float gv = fmaf(l2c, p[i], g[i]);
         acc += (double)gv * gv;
     }
@@ -697,8 +733,8 @@ __global__ __launch_bounds__(1024) void adam_norm_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         double s = 0.0;
-        for (int k = 0; k < 16; ++k) s += red[k];
-        norms[t] = (float)sqrt(s);
+        for (int k = 0; k < kBlock / 64; ++k) s += red[k];
+        partial[(size_t)t * kNormSplit + blockIdx.x] = s;
     }
 }
 
@@ -710,7 +746,8 @@ struct AdamArgs {
     float* ema;  // may be null
     const long long* offs;
     const float* l2;
-    const float* norms;
+    const double* norm_partial;
+    float* norms;
     float lr, beta1, beta2, eps, wd, clipnorm, alpha, ema_decay;
     int ema_copy;
 };
@@ -720,7 +757,11 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(AdamArgs a) {
     const long long b = a.offs[t], e = a.offs[t + 1];
     const float l2c = 2.f * a.l2[t];
     // keras clip_by_norm: g * clip / max(norm, clip)
-    const float cf = a.clipnorm > 0.f ? a.clipnorm / fmaxf(a.norms[t], a.clipnorm) : 1.f;
+    double sq = 0.0;
+    for (int k = 0; k < kNormSplit; ++k) sq += a.norm_partial[(size_t)t * kNormSplit + k];
+    const float norm = (float)sqrt(sq);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.norms[t] = norm;
+    const float cf = a.clipnorm > 0.f ? a.clipnorm / fmaxf(norm, a.clipnorm) : 1.f;
     for (long long i = b + (long long)blockIdx.x * kBlock + threadIdx.x; i < e;
          i += (long long)gridDim.x * kBlock) {
         float w = a.p[i];
@@ -768,7 +809,7 @@ int lf_input_stage_f32(const uint8_t* in, float* out, int n, int h, int w, const
             d[c] = denom3[c];
         }
     hipStream_t s = lf::as_stream(stream);
-    aug_means_kernel<<<n, kBlock, 0, s>>>(in, aug4, means_ws, h, w);
+    aug_means_kernel<<<dim3(kMeanSplit, n), kBlock, 0, s>>>(in, aug4, means_ws, h, w);
     input_aug_kernel<<<dim3(plane_grid(h * w), n), kBlock, 0, s>>>(in, out, aug4, means_ws, h, w,
                                                                    m[0], m[1], m[2], d[0], d[1], d[2]);
     return lf::check_launch("lf_input_stage");
@@ -893,9 +934,9 @@ int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float*
     se_bwd_sample_kernel<<<n, kBlock, (size_t)(c + cr) * sizeof(float), st>>>(ds, s, z1, w1, w2, dpre2,
                                                                               dpre1, dm, c, cr, dm_scale);
     // dw1[c][cr] = sum_n m[n][c] dpre1[n][cr]; dw2[cr][c] = sum_n z1[n][cr] dpre2[n][c]
-    outer_sum_kernel<<<lf::stream_grid((size_t)(c + 1) * cr, kBlock), kBlock, 0, st>>>(m, dpre1, dw1, db1,
+    outer_sum_kernel<<<(unsigned)(((size_t)(c + 1) * cr + 63) / 64), kBlock, 0, st>>>(m, dpre1, dw1, db1,
                                                                                     n, c, cr);
-    outer_sum_kernel<<<lf::stream_grid((size_t)(cr + 1) * c, kBlock), kBlock, 0, st>>>(z1, dpre2, dw2,
+    outer_sum_kernel<<<(unsigned)(((size_t)(cr + 1) * c + 63) / 64), kBlock, 0, st>>>(z1, dpre2, dw2,
                                                                                     db2, n, cr, c);
     return lf::check_launch("lf_se_bwd");
 }
@@ -947,7 +988,7 @@ int lf_head_bwd_f32(const float* feat, const float* w, const float* probs, const
     hipStream_t st = lf::as_stream(stream);
     head_bwd_kernel<<<n, 64, (size_t)c * sizeof(float), st>>>(probs, ytrue, w, dlogits, dfeat, f, c, inv_n);
     // dW[f][c] = sum_n feat[n][f] dlogits[n][c]; db[c] = sum_n dlogits[n][c]
-    outer_sum_kernel<<<lf::stream_grid((size_t)(f + 1) * c, kBlock), kBlock, 0, st>>>(feat, dlogits, dw, db,
+    outer_sum_kernel<<<(unsigned)(((size_t)(f + 1) * c + 63) / 64), kBlock, 0, st>>>(feat, dlogits, dw, db,
                                                                                    n, f, c);
     return lf::check_launch("lf_head_bwd");
 }
@@ -959,19 +1000,30 @@ int lf_mul_f32(const float* a, const float* b, float* out, size_t count, lf_stre
     return lf::check_launch("lf_mul");
 }
 
+size_t lf_adamw_workspace(int ntensors) {
+    return ntensors > 0 ? (size_t)ntensors * kNormSplit * sizeof(double) : 0;
+}
+
 int lf_adamw_step_f32(float* param, const float* grad, float* m, float* v, float* ema,
                       const long long* offsets, const float* l2, int ntensors, long long max_count,
                       float lr, float beta1, float beta2, float eps, float weight_decay,
                       float clipnorm, long long step, float ema_decay, int ema_copy,
-                      float* norms_ws, lf_stream_t stream) {
-    LF_REQUIRE(param && grad && m && v && offsets && l2 && norms_ws, "lf_adamw_step: null buffer");
+                      float* norms_out, void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(param && grad && m && v && offsets && l2 && norms_out && workspace,
+               "lf_adamw_step: null buffer");
+    if (ws_bytes < lf_adamw_workspace(ntensors)) {
+        lf::set_error("lf_adamw_step: workspace %zu < %zu", ws_bytes, lf_adamw_workspace(ntensors));
+        return LF_ERR_WORKSPACE;
+    }
     LF_REQUIRE(ntensors > 0 && ntensors <= 65535 && max_count > 0 && step >= 1,
                "lf_adamw_step: bad ntensors=%d max_count=%lld step=%lld", ntensors, max_count, step);
     hipStream_t st = lf::as_stream(stream);
-    adam_norm_kernel<<<ntensors, 1024, 0, st>>>(param, grad, offsets, l2, norms_ws);
+    double* partial = static_cast<double*>(workspace);
+    adam_norm_kernel<<<dim3(kNormSplit, ntensors), kBlock, 0, st>>>(param, grad, offsets, l2, partial);
     AdamArgs a;
     a.p = param; a.g = grad; a.m = m; a.v = v; a.ema = ema; a.offs = offsets; a.l2 = l2;
-    a.norms = norms_ws;
+    a.norm_partial = partial;
+    a.norms = norms_out;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.clipnorm = clipnorm;
     const double b1p = pow((double)beta1, (double)step), b2p = pow((double)beta2, (double)step);

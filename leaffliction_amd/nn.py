@@ -110,7 +110,7 @@ def input_stage(x_u8: torch.Tensor, aug4: torch.Tensor, mean=None, denom=None,
         raise ValueError("input_stage: x must be [N,H,W,3] and aug [N,4]")
     if out is None:
         out = torch.empty((n, 3, h, w), dtype=_F32, device=x_u8.device)
-    ws = torch.empty((n, 3), dtype=_F32, device=x_u8.device)
+    ws = torch.empty((n, 24), dtype=_F32, device=x_u8.device)
     m = d = None
     if mean is not None:
         m = (_lib.c_float * 3)(*[float(v) for v in mean])
@@ -276,10 +276,12 @@ def adamw_step(param, grad, m, v, ema, offsets, l2, max_count, lr, step, beta1=0
     nt = offsets.numel() - 1
     if norms is None:
         norms = torch.empty(nt, dtype=_F32, device=param.device)
+    ws = _workspace(_lib.load().lf_adamw_workspace(nt), param.device)
     _lib.call("lf_adamw_step_f32", param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
               _ptr(ema), offsets.data_ptr(), l2.data_ptr(), nt, int(max_count), float(lr),
               float(beta1), float(beta2), float(eps), float(weight_decay), float(clipnorm),
-              int(step), float(ema_decay), 1 if ema_copy else 0, norms.data_ptr(), _stream())
+              int(step), float(ema_decay), 1 if ema_copy else 0, norms.data_ptr(), ws.data_ptr(),
+              ws.numel(), _stream())
     return norms
 
 
