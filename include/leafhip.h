@@ -178,6 +178,18 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
 int lf_conv2d_variant(int h, int wd, int cout);
 int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout, int ksize);
 
+/* Conv2D followed by BatchNormalization in training mode (cnn.py:28-33,40-45): the same
+ * convolution, and in its epilogue the per-tile sums of (y - pivot[co]) and (y - pivot[co])^2 for
+ * every output channel -> tile_part[co][tile][2] (tile < lf_conv2d_stats_tiles(...)).  pivot
+ * (device, [cout], may be null) only conditions the sum of squares; pass the layer's moving
+ * mean.  lf_bn_train_stats_tiles_f32 (below) turns the tile sums into the batch statistics, so
+ * the activation is not read again. */
+long long lf_conv2d_stats_tiles(int n, int h, int w, int cout);
+int lf_conv2d_stats_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd,
+                        int cout, int ksize, const float* in_scale, const float* in_shift,
+                        int in_relu, const float* pivot, float* tile_part, size_t tile_part_bytes,
+                        lf_stream_t stream);
+
 /* w [Cin][k*k][Cout] -> wt [Cout][k*k (flipped)][Cin]: the weights with which
  * lf_conv2d_f32(dy, wt, dx, n, cout, h, w, cin, k, ...) is the input gradient. */
 int lf_conv2d_dgrad_weights_f32(const float* w, float* wt, int cin, int ksize, int cout,
@@ -219,6 +231,13 @@ int lf_bn_train_stats_f32(const float* y, int n, int c, int hw, const float* gam
                           const float* beta, float* moving_mean, float* moving_var, float momentum,
                           float eps, float* mean, float* invstd, float* scale, float* shift,
                           void* workspace, size_t ws_bytes, lf_stream_t stream);
+/* Same outputs as lf_bn_train_stats_f32 from the tile sums of lf_conv2d_stats_f32 (taken about
+ * moving_mean, which must not have changed in between); tiles = lf_conv2d_stats_tiles(...). */
+int lf_bn_train_stats_tiles_f32(const float* tile_part, long long tiles, int n, int c, int hw,
+                                const float* gamma, const float* beta, float* moving_mean,
+                                float* moving_var, float momentum, float eps, float* mean,
+                                float* invstd, float* scale, float* shift, void* workspace,
+                                size_t ws_bytes, lf_stream_t stream);
 /* Inference scale/shift from the moving statistics. */
 int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
                                 const float* moving_mean, const float* moving_var, float eps,

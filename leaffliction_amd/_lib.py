@@ -42,6 +42,8 @@ SIGNATURES = {
     "lf_conv2d_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P],
     "lf_conv2d_variant": [c_int, c_int, c_int],
     "lf_conv2d_wgrad_variant": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "lf_conv2d_stats_tiles": [c_int, c_int, c_int, c_int],
+    "lf_conv2d_stats_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_size_t, P],
     "lf_conv2d_dgrad_weights_f32": [P, P, c_int, c_int, c_int, P],
     "lf_conv2d_wgrad_workspace": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_wgrad_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,
@@ -52,6 +54,7 @@ SIGNATURES = {
     "lf_bn_workspace": [c_int],
     "lf_bn_train_stats_f32": [P, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P,
                               P, c_size_t, P],
+    "lf_bn_train_stats_tiles_f32": [P, C.c_longlong, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P],
     "lf_bn_infer_scale_shift_f32": [c_int, P, P, P, P, c_float, P, P, P],
     "lf_bn_bwd_f32": [P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P, c_size_t,
                       P],
@@ -72,7 +75,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t,
              "lf_bn_workspace": c_size_t, "lf_se_bwd_workspace": c_size_t,
-             "lf_adamw_workspace": c_size_t}
+             "lf_adamw_workspace": c_size_t, "lf_conv2d_stats_tiles": C.c_longlong}
 
 
 class LeafHipError(RuntimeError):

@@ -53,7 +53,28 @@ struct ConvArgs {
     int in_relu;
     int accumulate;  // y += conv(...) instead of y = conv(...)
     int vec_ok;      // W % 4 == 0, Cout % 4 == 0, 16-byte aligned bases
+    // optional BatchNorm statistics of the output, gathered in the epilogue: per (channel, tile)
+    // sum and sum of squares of (y - pivot[co]) -> stat_part[(co * stat_tiles + tile) * 2 + {0,1}]
+    float* stat_part;
+    const float* stat_pivot;  // may be null (pivot 0)
+    long long stat_tiles;     // n * tiles_x * tiles_y
 };
+
+// sum over the 32 lanes of each wave half (DPP); the total lands in lanes 16-31 / 48-63
+__device__ __forceinline__ float dpp_add(float v, float moved) { return v + moved; }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float half_sum32(float v) {
+    v += dpp_move<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_move<0x140, 0xf>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_move<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    return v;
+}
 
 // ---------------------------------------------------------------------------
 // forward / dgrad
@@ -307,11 +328,13 @@ void conv_mfma_kernel(ConvArgs p) {
 
     // epilogue: D[row = co][col = pixel]; row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* yout = p.y + (size_t)n * p.cout * hw;
+    bool pix_ok[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int f = (wave_px * NB + nb) * 32 + j;
         const int oy = ty0 + f / TW, ox = tx0 + f % TW;
-        if (oy >= p.h || ox >= p.wd) continue;
+        pix_ok[nb] = oy < p.h && ox < p.wd;
+        if (!pix_ok[nb]) continue;
         const size_t pix = (size_t)oy * p.wd + ox;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
@@ -324,6 +347,47 @@ void conv_mfma_kernel(ConvArgs p) {
                     *dst = p.accumulate ? *dst + acc[m][nb][r] : acc[m][nb][r];
                 }
             }
+        }
+    }
+    if (p.stat_part != nullptr) {  // uniform: BatchNorm statistics of this output tile
+        __syncthreads();           // every wave is done with the staging LDS
+        float* red = lds;          // [WPX][CT][2]
+        static_assert(WPX * CT * 2 <= PATCH + WSZ, "stat scratch must fit the staging LDS");
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = (wave_co * MB + m) * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2);
+                const int co = co0 + cl;
+                const float pv = (p.stat_pivot != nullptr && co < p.cout) ? p.stat_pivot[co] : 0.f;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float d = pix_ok[nb] ? acc[m][nb][r] - pv : 0.f;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                }
+                s1 = half_sum32(s1);
+                s2 = half_sum32(s2);
+                if (j == 31) {
+                    red[(wave_px * CT + cl) * 2] = s1;
+                    red[(wave_px * CT + cl) * 2 + 1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        const long long tg = (long long)n * (p.tiles_x * p.tiles_y) + tile;
+        for (int c = tid; c < CT; c += kThreads) {
+            if (co0 + c >= p.cout) continue;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int wp = 0; wp < WPX; ++wp) {
+                a += red[(wp * CT + c) * 2];
+                b += red[(wp * CT + c) * 2 + 1];
+            }
+            float* dst = p.stat_part + ((size_t)(co0 + c) * (size_t)p.stat_tiles + (size_t)tg) * 2;
+            dst[0] = a;
+            dst[1] = b;
         }
     }
 }
@@ -1170,18 +1234,19 @@ int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout, int ksize) 
     return plan_wgrad(n, cin, cout, h, wd, ksize).variant;
 }
 
-int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
-                  int ksize, const float* in_scale, const float* in_shift, int in_relu,
-                  int accumulate, lf_stream_t stream) {
-    LF_REQUIRE(x && w && y, "lf_conv2d: null buffer");
+static int conv2d_launch(const char* who, const float* x, const float* w, float* y, int n, int cin,
+                         int h, int wd, int cout, int ksize, const float* in_scale,
+                         const float* in_shift, int in_relu, int accumulate, float* stat_part,
+                         const float* stat_pivot, lf_stream_t stream) {
+    LF_REQUIRE(x && w && y, "%s: null buffer", who);
     LF_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && wd > 0,
-               "lf_conv2d: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, wd);
-    LF_REQUIRE(ksize == 3 || ksize == 1, "lf_conv2d: ksize must be 1 or 3 (got %d)", ksize);
+               "%s: bad dims n=%d cin=%d cout=%d h=%d w=%d", who, n, cin, cout, h, wd);
+    LF_REQUIRE(ksize == 3 || ksize == 1, "%s: ksize must be 1 or 3 (got %d)", who, ksize);
     LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr),
-               "lf_conv2d: in_scale/in_shift must both be set");
-    LF_REQUIRE(n <= 65535, "lf_conv2d: batch too large for grid.z");
+               "%s: in_scale/in_shift must both be set", who);
+    LF_REQUIRE(n <= 65535, "%s: batch too large for grid.z", who);
     LF_REQUIRE((size_t)cin * h * wd < (1ull << 30) && (size_t)cin * ksize * ksize * cout < (1ull << 30),
-               "lf_conv2d: per-image tensor too large for 32-bit offsets");
+               "%s: per-image tensor too large for 32-bit offsets", who);
     const int best = lf_conv2d_variant(h, wd, cout);
     const FwdVariant& v = kFwdVariants[best];
     ConvArgs a;
@@ -1192,11 +1257,42 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
     a.in_relu = in_relu;
     a.accumulate = accumulate;
     a.vec_ok = (wd % 4 == 0) && (cout % 4 == 0) && aligned16(x) && aligned16(w);
+    a.stat_part = stat_part;
+    a.stat_pivot = stat_pivot;
+    a.stat_tiles = (long long)n * a.tiles_x * a.tiles_y;
     dim3 grid(a.tiles_x * a.tiles_y, (cout + v.ct - 1) / v.ct, n);
     hipStream_t s = lf::as_stream(stream);
     const int rc = ksize == 3 ? launch_fwd<9>(best, a, grid, s) : launch_fwd<1>(best, a, grid, s);
     if (rc != LF_OK) return rc;
-    return lf::check_launch("lf_conv2d");
+    return lf::check_launch(who);
+}
+
+int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
+                  int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                  int accumulate, lf_stream_t stream) {
+    return conv2d_launch("lf_conv2d", x, w, y, n, cin, h, wd, cout, ksize, in_scale, in_shift, in_relu,
+                         accumulate, nullptr, nullptr, stream);
+}
+
+long long lf_conv2d_stats_tiles(int n, int h, int wd, int cout) {
+    if (n <= 0 || h <= 0 || wd <= 0 || cout <= 0) return 0;
+    const FwdVariant& v = kFwdVariants[lf_conv2d_variant(h, wd, cout)];
+    return (long long)n * ((wd + v.tw - 1) / v.tw) * ((h + v.th - 1) / v.th);
+}
+
+int lf_conv2d_stats_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd,
+                        int cout, int ksize, const float* in_scale, const float* in_shift,
+                        int in_relu, const float* pivot, float* tile_part, size_t tile_part_bytes,
+                        lf_stream_t stream) {
+    LF_REQUIRE(tile_part, "lf_conv2d_stats: null tile_part");
+    const long long tiles = lf_conv2d_stats_tiles(n, h, wd, cout);
+    if (tile_part_bytes < (size_t)tiles * (size_t)(cout > 0 ? cout : 0) * 2 * sizeof(float)) {
+        lf::set_error("lf_conv2d_stats: tile_part %zu bytes < %lld tiles x %d channels x 8",
+                      tile_part_bytes, tiles, cout);
+        return LF_ERR_WORKSPACE;
+    }
+    return conv2d_launch("lf_conv2d_stats", x, w, y, n, cin, h, wd, cout, ksize, in_scale, in_shift,
+                         in_relu, 0, tile_part, pivot, stream);
 }
 
 int lf_conv2d_dgrad_weights_f32(const float* w, float* wt, int cin, int ksize, int cout,

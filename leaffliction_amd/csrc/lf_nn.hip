@@ -206,8 +206,32 @@ __global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restric
 
 // One thread per channel: combine partials in double, produce mean / invstd / scale / shift and
 // update the moving statistics (keras BatchNormalization: biased variance, momentum 0.99).
-__global__ void bn_finalize_kernel(const float* __restrict__ y, const float* __restrict__ part,
-                                   int c, int hw, double count, const float* __restrict__ gamma,
+// grid = (kBnSplit, C): workgroup (s, c) adds slice s of channel c's per-tile partial sums
+// (written by the convolution epilogue, lf_conv2d_stats_f32) in a fixed order.
+__global__ __launch_bounds__(kBlock) void bn_tile_reduce_kernel(const float* __restrict__ tile_part,
+                                                                long long tiles,
+                                                                float* __restrict__ part) {
+    __shared__ float red[8];
+    const int ch = blockIdx.y, s = blockIdx.x;
+    const long long per = (tiles + kBnSplit - 1) / kBnSplit;
+    const long long t0 = per * s, t1 = t0 + per < tiles ? t0 + per : tiles;
+    const float2* src = reinterpret_cast<const float2*>(tile_part) + (size_t)ch * (size_t)tiles;
+    float acc[2] = {0.f, 0.f};
+    for (long long t = t0 + threadIdx.x; t < t1; t += kBlock) {
+        const float2 v = src[t];
+        acc[0] += v.x;
+        acc[1] += v.y;
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        part[((size_t)ch * kBnSplit + s) * 2] = acc[0];
+        part[((size_t)ch * kBnSplit + s) * 2 + 1] = acc[1];
+    }
+}
+
+// `pivot_src[ch * pivot_stride]` is the value the partial sums were taken about (null = 0).
+__global__ void bn_finalize_kernel(const float* __restrict__ pivot_src, int pivot_stride,
+                                   const float* __restrict__ part, int c, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ mmean,
                                    float* __restrict__ mvar, float momentum, float eps,
                                    float* __restrict__ mean_o, float* __restrict__ invstd_o,
@@ -219,7 +243,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ y, const float* __r
         s += part[((size_t)ch * kBnSplit + k) * 2];
         q += part[((size_t)ch * kBnSplit + k) * 2 + 1];
     }
-    const double pivot = y[(size_t)ch * hw];
+    const double pivot = pivot_src != nullptr ? (double)pivot_src[(size_t)ch * pivot_stride] : 0.0;
     const double dm = s / count;
     double var = q / count - dm * dm;
     if (var < 0.0) var = 0.0;
@@ -848,10 +872,34 @@ int lf_bn_train_stats_f32(const float* y, int n, int c, int hw, const float* gam
     hipStream_t s = lf::as_stream(stream);
     float* part = static_cast<float*>(workspace);
     bn_stats_kernel<<<dim3(kBnSplit, c), kBlock, 0, s>>>(y, n, c, hw, part);
-    bn_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(y, part, c, hw, (double)n * hw, gamma, beta,
+    bn_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(y, hw, part, c, (double)n * hw, gamma, beta,
                                                    moving_mean, moving_var, momentum, eps, mean,
                                                    invstd, scale, shift);
     return lf::check_launch("lf_bn_train_stats");
+}
+
+int lf_bn_train_stats_tiles_f32(const float* tile_part, long long tiles, int n, int c, int hw,
+                                const float* gamma, const float* beta, float* moving_mean,
+                                float* moving_var, float momentum, float eps, float* mean,
+                                float* invstd, float* scale, float* shift, void* workspace,
+                                size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(tile_part && gamma && beta && moving_mean && moving_var && mean && invstd && scale &&
+                   shift && workspace,
+               "lf_bn_train_stats_tiles: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && hw > 0 && c <= 65535 && tiles > 0,
+               "lf_bn_train_stats_tiles: bad dims n=%d c=%d hw=%d tiles=%lld", n, c, hw, tiles);
+    if (ws_bytes < lf_bn_workspace(c)) {
+        lf::set_error("lf_bn_train_stats_tiles: workspace %zu < %zu", ws_bytes, lf_bn_workspace(c));
+        return LF_ERR_WORKSPACE;
+    }
+    hipStream_t s = lf::as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    bn_tile_reduce_kernel<<<dim3(kBnSplit, c), kBlock, 0, s>>>(tile_part, tiles, part);
+    // the tile sums were taken about moving_mean as it still is here (updated by this kernel)
+    bn_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(moving_mean, 1, part, c, (double)n * hw, gamma,
+                                                   beta, moving_mean, moving_var, momentum, eps,
+                                                   mean, invstd, scale, shift);
+    return lf::check_launch("lf_bn_train_stats_tiles");
 }
 
 int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,

@@ -306,6 +306,19 @@ class LeafCNN:
                                     self.s[name + ".mean"], self.s[name + ".var"], st, BN_EPS)
         return st
 
+    def _conv_bn(self, x, wname: str, ksize: int, bn: str, pro, out: torch.Tensor, training: bool):
+        """Conv2D -> BatchNormalization: returns (y, stats[4,C]).  In training the batch
+        statistics come out of the convolution's epilogue (no second pass over y)."""
+        P = self.p
+        if training:
+            st = self.stats[bn]
+            nn.conv2d_bn_stats(x, P[wname], ksize, P[bn + ".gamma"], P[bn + ".beta"],
+                               self.s[bn + ".mean"], self.s[bn + ".var"], st, pro[0], pro[1], pro[2],
+                               out=out, momentum=BN_MOMENTUM, eps=BN_EPS)
+            return out, st
+        y = nn.conv2d(x, P[wname], ksize, pro[0], pro[1], pro[2], out=out)
+        return y, self._bn(bn, y, False)
+
     def forward(self, x0: torch.Tensor, training: bool, y_true: Optional[torch.Tensor] = None,
                 drops: Optional[List[torch.Tensor]] = None,
                 top_drop: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
@@ -316,18 +329,18 @@ class LeafCNN:
         sv: Dict[str, Any] = {"x0": x0, "n": n}
         # Activations a = relu(BN(y)) are never materialised: every consumer (the next conv,
         # wgrad, GAP, the residual tail, BN backward) applies scale/shift(+ReLU) while it reads y.
-        y = nn.conv2d(x0, P["stem.w"], 3, out=B("stem.y", (n, self.widths[0], h, w)))
-        st = self._bn("stem.bn", y, training)
+        y, st = self._conv_bn(x0, "stem.w", 3, "stem.bn", (None, None, False),
+                              B("stem.y", (n, self.widths[0], h, w)), training)
         sv["stem.y"] = y
         xin, xin_st = y, st  # block input = relu(xin*xin_st[2]+xin_st[3]) (None = already final)
         cin = self.widths[0]
         for i, f in enumerate(self.widths):
             p = f"s{i}."
             pro = (xin_st[2], xin_st[3], True) if xin_st is not None else (None, None, False)
-            y1 = nn.conv2d(xin, P[p + "c1.w"], 3, pro[0], pro[1], pro[2], out=B(p + "y1", (n, f, h, w)))
-            st1 = self._bn(p + "bn1", y1, training)
-            y2 = nn.conv2d(y1, P[p + "c2.w"], 3, st1[2], st1[3], True, out=B(p + "y2", y1.shape))
-            st2 = self._bn(p + "bn2", y2, training)
+            y1, st1 = self._conv_bn(xin, p + "c1.w", 3, p + "bn1", pro, B(p + "y1", (n, f, h, w)),
+                                    training)
+            y2, st2 = self._conv_bn(y1, p + "c2.w", 3, p + "bn2", (st1[2], st1[3], True),
+                                    B(p + "y2", y1.shape), training)
             s = None
             if self.use_se:
                 m = nn.gap(y2, out=B(p + "m", (n, f)), scale=st2[2], shift=st2[3], relu=True)
@@ -336,9 +349,8 @@ class LeafCNN:
                               B(p + "s", (n, f)))
                 sv[p + "m"], sv[p + "z1"] = m, z1
             if cin != f:
-                yp = nn.conv2d(xin, P[p + "proj.w"], 1, pro[0], pro[1], pro[2],
-                               out=B(p + "yp", y1.shape))
-                stp = self._bn(p + "bnp", yp, training)
+                yp, stp = self._conv_bn(xin, p + "proj.w", 1, p + "bnp", pro, B(p + "yp", y1.shape),
+                                        training)
                 sc, scs, scb, scr = yp, stp[2], stp[3], False
                 sv[p + "yp"] = yp
             else:

@@ -12,9 +12,9 @@ _F32 = torch.float32
 _ws_cache = {}
 
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (the C ABI never allocates)."""
-    key = str(device)
+def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    """Grow-only scratch buffer per device and slot (the C ABI never allocates)."""
+    key = (str(device), slot)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -55,6 +55,51 @@ def conv2d(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, in_scale=None, in_s
     _lib.call("lf_conv2d_f32", x.data_ptr(), w_iko.data_ptr(), out.data_ptr(), n, cin, h, w, cout,
               ksize, _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, 1 if accumulate else 0,
               _stream())
+    return out
+
+
+def conv2d_bn_stats(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, gamma, beta, mmean, mvar,
+                    stats: torch.Tensor, in_scale=None, in_shift=None, in_relu: bool = False,
+                    out: Optional[torch.Tensor] = None, momentum: float = 0.99,
+                    eps: float = 1e-3) -> torch.Tensor:
+    """Conv2D + training-mode BatchNormalization statistics: y = conv(x'), and `stats` [4,C]
+    (mean, invstd, scale, shift) + the moving statistics are produced from per-tile sums the
+    convolution gathers in its epilogue, so y is not read again."""
+    _chk(x, _F32, "conv2d_bn_stats.x", 4)
+    _chk(w_iko, _F32, "conv2d_bn_stats.w", 3)
+    n, cin, h, w = x.shape
+    if w_iko.shape[0] != cin or w_iko.shape[1] != ksize * ksize:
+        raise ValueError(f"conv2d_bn_stats.w: expected [{cin},{ksize * ksize},Cout]")
+    cout = w_iko.shape[2]
+    for t, nm in ((in_scale, "in_scale"), (in_shift, "in_shift")):
+        if t is not None:
+            _chk(t, _F32, f"conv2d_bn_stats.{nm}", 1)
+            if t.shape[0] != cin:
+                raise ValueError(f"conv2d_bn_stats.{nm}: expected [{cin}]")
+    for t in (gamma, beta, mmean, mvar):
+        _chk(t, _F32, "conv2d_bn_stats.param", 1)
+        if t.shape[0] != cout:
+            raise ValueError("conv2d_bn_stats: per-channel vectors must be [Cout]")
+    _chk(stats, _F32, "conv2d_bn_stats.stats", 2)
+    if tuple(stats.shape) != (4, cout):
+        raise ValueError("conv2d_bn_stats.stats: expected [4,Cout]")
+    if out is None:
+        out = torch.empty((n, cout, h, w), dtype=_F32, device=x.device)
+    else:
+        _chk(out, _F32, "conv2d_bn_stats.out", 4)
+        if tuple(out.shape) != (n, cout, h, w):
+            raise ValueError("conv2d_bn_stats.out: shape mismatch")
+    lib = _lib.load()
+    tiles = lib.lf_conv2d_stats_tiles(n, h, w, cout)
+    tp = _workspace(tiles * cout * 8, x.device, slot=1)
+    _lib.call("lf_conv2d_stats_f32", x.data_ptr(), w_iko.data_ptr(), out.data_ptr(), n, cin, h, w,
+              cout, ksize, _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, mmean.data_ptr(),
+              tp.data_ptr(), tp.numel(), _stream())
+    ws = _workspace(lib.lf_bn_workspace(cout), x.device)
+    _lib.call("lf_bn_train_stats_tiles_f32", tp.data_ptr(), tiles, n, cout, h * w, gamma.data_ptr(),
+              beta.data_ptr(), mmean.data_ptr(), mvar.data_ptr(), float(momentum), float(eps),
+              stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+              ws.data_ptr(), ws.numel(), _stream())
     return out
 
 

@@ -93,3 +93,42 @@ def test_conv_known_answers(cuda):
     a = torch.randn(4, 32, 32, 32, generator=g).to(cuda)
     d = torch.randn(4, 32, 32, 32, generator=g).to(cuda)
     assert torch.equal(nn.conv2d_wgrad(a, d, 3), nn.conv2d_wgrad(a, d, 3))
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k", SHAPES)
+def test_conv_bn_stats_epilogue(cuda, n, cin, cout, h, w, k):
+    """Conv2D + training BatchNormalization statistics gathered in the conv epilogue: same y
+    (bit-identical to the plain conv), batch mean / biased variance, scale / shift and moving
+    statistics vs torch fp32 (mean 1e-5, variance 1e-4 relative: fp32 tile sums about the
+    moving-mean pivot, combined in double)."""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(7 + n * 1000 + cin * 10 + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g) + 0.5
+    wt = torch.randn(cin, k * k, cout, generator=g) / (cin * k * k) ** 0.5
+    gamma = torch.rand(cout, generator=g) + 0.5
+    beta = torch.randn(cout, generator=g)
+    mmean0 = torch.randn(cout, generator=g) * 0.3
+    mvar0 = torch.rand(cout, generator=g) + 0.5
+    y_ref = F.conv2d(x, iko_to_oihw(wt, k), padding=k // 2)
+    mean_ref = y_ref.mean((0, 2, 3))
+    var_ref = y_ref.var((0, 2, 3), unbiased=False)
+    xd, wd = x.to(cuda), wt.to(cuda)
+    mm, mv = mmean0.to(cuda), mvar0.to(cuda)
+    stats = torch.zeros(4, cout, device=cuda)
+    y = nn.conv2d_bn_stats(xd, wd, k, gamma.to(cuda), beta.to(cuda), mm, mv, stats,
+                           momentum=0.99, eps=1e-3)
+    assert torch.equal(y, nn.conv2d(xd, wd, k))
+    st = stats.cpu()
+    scale = y_ref.abs().max().item()
+    assert (st[0] - mean_ref).abs().max().item() <= 1e-5 * scale
+    assert ((st[1] - 1.0 / torch.sqrt(var_ref + 1e-3)).abs() * torch.sqrt(var_ref + 1e-3)).max().item() <= 1e-4
+    sc_ref = gamma / torch.sqrt(var_ref + 1e-3)
+    assert torch.allclose(st[2], sc_ref, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(st[3], beta - mean_ref * sc_ref, rtol=1e-4, atol=1e-4 * scale)
+    assert torch.allclose(mm.cpu(), mmean0 * 0.99 + mean_ref * 0.01, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(mv.cpu(), mvar0 * 0.99 + var_ref * 0.01, rtol=1e-5, atol=1e-6)
+    # and against the two-pass path (plain conv, then the statistics kernel)
+    mm2, mv2 = mmean0.to(cuda), mvar0.to(cuda)
+    stats2 = torch.zeros(4, cout, device=cuda)
+    nn.bn_train_stats(y, gamma.to(cuda), beta.to(cuda), mm2, mv2, stats2, 0.99, 1e-3)
+    assert torch.allclose(stats, stats2, rtol=1e-4, atol=1e-5 * scale)
