@@ -246,17 +246,22 @@ int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
  * (both optional), zeroed where the forward's ReLU was inactive when relu != 0 — the mask is
  * recomputed as y*scale[c]+shift[c] > 0 from the pre-BN tensor, so the activation is never
  * stored; dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma = sum dz*xhat,
- * dbeta = sum dz. */
+ * dbeta = sum dz.  plane_g / plane_m (optional, [n][c][2], relu case only): when the producer
+ * of g already left per-plane sums {sum g*mask, sum g*mask*y} (lf_block_tail_bwd_f32) and the
+ * forward left {sum mask, sum mask*y} (lf_gap_f32; needed with add_nc), the two channel sums
+ * come from those and g / y are read once (for dy) instead of twice. */
 int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* y,
                   const float* mean, const float* invstd, const float* scale, const float* shift,
-                  int relu, const float* gamma, float* dy, float* dgamma, float* dbeta, int n, int c,
-                  int hw, void* workspace, size_t ws_bytes, lf_stream_t stream);
+                  int relu, const float* gamma, float* dy, float* dgamma, float* dbeta,
+                  const float* plane_g, const float* plane_m, int n, int c, int hw, void* workspace,
+                  size_t ws_bytes, lf_stream_t stream);
 
 /* ---- pooling / broadcast ---- */
 /* out[p] = mean over hw of act(x[p][:]*scale[c]+shift[c]), c = p % C (GlobalAveragePooling2D,
- * cnn.py:13,98; scale/shift null = plain mean; relu applies with the prologue). */
+ * cnn.py:13,98; scale/shift null = plain mean; relu applies with the prologue).  mask_sums
+ * (optional, [planes][2]) receives {count of x*scale+shift > 0, sum of x over those}. */
 int lf_gap_f32(const float* x, float* out, int planes, int hw, int c, const float* scale,
-               const float* shift, int relu, lf_stream_t stream);
+               const float* shift, int relu, float* mask_sums, lf_stream_t stream);
 /* out[p][:] = v[p]*scale (GAP backward). */
 int lf_bcast_planes_f32(const float* v, float* out, int planes, int hw, float scale,
                         lf_stream_t stream);
@@ -276,16 +281,21 @@ int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float*
 /* ---- residual tail (cnn.py:47-48,94-96): Add -> ReLU -> SpatialDropout2D -> MaxPool2D(2) ---- */
 /* r = relu(sc' + a*s[n][c]) with a = relu(y*a_scale[c]+a_shift[c]) (BN2+ReLU fused; a = y when
  * a_scale is null) and sc' = act(sc*sc_scale[c]+sc_shift[c]) (projection BN, or BN+ReLU of the
- * producer when sc_relu) or sc;  p = drop[n][c] * maxpool2x2(r) (drop = 0 or 1/(1-rate)). */
+ * producer when sc_relu) or sc;  p = drop[n][c] * maxpool2x2(r) (drop = 0 or 1/(1-rate)).
+ * r itself is not stored: route [n][c][h/2][w/2] (one byte per pooled value) records where the
+ * value came from (bits 0-1: first maximum in scan order) and whether it was > 0 (bit 2). */
 int lf_block_tail_fwd_f32(const float* y, const float* a_scale, const float* a_shift,
                           const float* s, const float* sc, const float* sc_scale,
-                          const float* sc_shift, int sc_relu, const float* drop, float* r, float* p,
-                          int n, int c, int h, int w, lf_stream_t stream);
-/* dr = gradient wrt (sc' + a*s): dp*drop routed to the first maximum of each window where
- * r > 0; ds[n][c] = sum_hw dr*a (SE gate gradient; y/ds optional together). */
-int lf_block_tail_bwd_f32(const float* dp, const float* r, const float* y, const float* a_scale,
-                          const float* a_shift, const float* drop, float* dr, float* ds, int n,
-                          int c, int h, int w, lf_stream_t stream);
+                          const float* sc_shift, int sc_relu, const float* drop, uint8_t* route,
+                          float* p, int n, int c, int h, int w, lf_stream_t stream);
+/* dr = gradient wrt (sc' + a*s): dp*drop routed to the recorded position of each window whose
+ * maximum was > 0; ds[n][c] = sum_hw dr*a (SE gate gradient); plane_sums [n][c][2] =
+ * {sum dr*[a>0], sum dr*[a>0]*y} for lf_bn_bwd_f32 (y goes with ds / plane_sums; plane_sums
+ * needs a_scale). */
+int lf_block_tail_bwd_f32(const float* dp, const uint8_t* route, const float* y,
+                          const float* a_scale, const float* a_shift, const float* drop, float* dr,
+                          float* ds, float* plane_sums, int n, int c, int h, int w,
+                          lf_stream_t stream);
 
 /* ---- head (cnn.py:98-101; train/utils.py:30-35) ---- */
 /* probs = softmax(feat w + b), w [f][c]; loss[n] = -sum_j ytrue[n][j] log(clip(probs)). */

@@ -56,15 +56,15 @@ SIGNATURES = {
                               P, c_size_t, P],
     "lf_bn_train_stats_tiles_f32": [P, C.c_longlong, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P],
     "lf_bn_infer_scale_shift_f32": [c_int, P, P, P, P, c_float, P, P, P],
-    "lf_bn_bwd_f32": [P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P, c_size_t,
-                      P],
-    "lf_gap_f32": [P, P, c_int, c_int, c_int, P, P, c_int, P],
+    "lf_bn_bwd_f32": [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P,
+                      c_size_t, P],
+    "lf_gap_f32": [P, P, c_int, c_int, c_int, P, P, c_int, P, P],
     "lf_bcast_planes_f32": [P, P, c_int, c_int, c_float, P],
     "lf_se_fwd_f32": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
     "lf_se_bwd_workspace": [c_int, c_int, c_int],
     "lf_se_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P, c_size_t, P],
     "lf_block_tail_fwd_f32": [P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P],
-    "lf_block_tail_bwd_f32": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "lf_block_tail_bwd_f32": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "lf_head_fwd_f32": [P, P, P, P, P, P, c_int, c_int, c_int, P],
     "lf_head_bwd_f32": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     "lf_mul_f32": [P, P, P, c_size_t, P],

@@ -386,38 +386,48 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(BnBwdArgs a,
 // ---------------------------------------------------------------------------
 // global average pool per plane, and its broadcast backward
 // ---------------------------------------------------------------------------
-// out[plane] = mean_hw act(x*scale[c]+shift[c]) (scale null = plain mean)
+// out[plane] = mean_hw act(x*scale[c]+shift[c]) (scale null = plain mean); with mask_sums also
+// {count of x*scale+shift > 0, sum of x over those} per plane (BatchNorm backward needs them)
 __global__ __launch_bounds__(kBlock) void gap_kernel(const float* __restrict__ x,
                                                      float* __restrict__ out, int hw, int c,
                                                      const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, int relu) {
-    __shared__ float red[4];
+                                                     const float* __restrict__ shift, int relu,
+                                                     float* __restrict__ mask_sums) {
+    __shared__ float red[12];
     const size_t base = (size_t)blockIdx.x * hw;
     const bool pro = scale != nullptr;
     const float sc = pro ? scale[blockIdx.x % c] : 1.f, sh = pro ? shift[blockIdx.x % c] : 0.f;
-    float acc[1] = {0.f};
+    float acc[3] = {0.f, 0.f, 0.f};
+    auto one = [&](float xv) {
+        float v = xv;
+        if (pro) {
+            v = fmaf(xv, sc, sh);
+            if (v > 0.f) {
+                acc[1] += 1.f;
+                acc[2] += xv;
+            }
+            if (relu) v = fmaxf(v, 0.f);
+        }
+        return v;
+    };
     if ((hw & 3) == 0) {
         const float4* x4 = reinterpret_cast<const float4*>(x + base);
         for (int i = threadIdx.x; i < hw / 4; i += kBlock) {
-            float4 v = x4[i];
-            if (pro) {
-                v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            }
-            acc[0] += (v.x + v.y) + (v.z + v.w);
+            const float4 v = x4[i];
+            const float a = one(v.x), b = one(v.y), cc = one(v.z), d = one(v.w);
+            acc[0] += (a + b) + (cc + d);
         }
     } else {
-        for (int i = threadIdx.x; i < hw; i += kBlock) {
-            float v = x[base + i];
-            if (pro) {
-                v = fmaf(v, sc, sh);
-                if (relu) v = fmaxf(v, 0.f);
-            }
-            acc[0] += v;
+        for (int i = threadIdx.x; i < hw; i += kBlock) acc[0] += one(x[base + i]);
+    }
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = acc[0] / (float)hw;
+        if (mask_sums != nullptr) {
+            mask_sums[2 * (size_t)blockIdx.x] = acc[1];
+            mask_sums[2 * (size_t)blockIdx.x + 1] = acc[2];
         }
     }
-    block_sum<1>(acc, red);
-    if (threadIdx.x == 0) out[blockIdx.x] = acc[0] / (float)hw;
 }
 
 __global__ __launch_bounds__(kBlock) void bcast_planes_kernel(const float* __restrict__ v,
@@ -558,7 +568,19 @@ __device__ __forceinline__ float tail_r(const TailArgs& t, float yv, float scv, 
     return fmaxf(sh + a * sv, 0.f);
 }
 
-__global__ __launch_bounds__(kBlock) void tail_fwd_kernel(TailArgs t, float* __restrict__ r,
+// window code: bits 0-1 = position of the first maximum in scan order (0,0),(0,1),(1,0),(1,1);
+// bit 2 = that maximum is > 0 (the gradient of the block's final ReLU)
+__device__ __forceinline__ unsigned tail_code(float r00, float r01, float r10, float r11, float& best) {
+    best = r00;
+    unsigned bi = 0;
+    if (r01 > best) { best = r01; bi = 1; }
+    if (r10 > best) { best = r10; bi = 2; }
+    if (r11 > best) { best = r11; bi = 3; }
+    return bi | (best > 0.f ? 4u : 0u);
+}
+
+// The residual r is not stored: backward only needs where each pooled value came from.
+__global__ __launch_bounds__(kBlock) void tail_fwd_kernel(TailArgs t, uint8_t* __restrict__ route,
                                                           float* __restrict__ p) {
     const int plane = blockIdx.x, ch = plane % t.c;
     const float sv = t.s ? t.s[plane] : 1.f;
@@ -572,86 +594,106 @@ __global__ __launch_bounds__(kBlock) void tail_fwd_kernel(TailArgs t, float* __r
         const int pw2 = pw / 2;
         for (int q = blockIdx.y * kBlock + threadIdx.x; q < ph * pw2; q += gridDim.y * kBlock) {
             const int py = q / pw2, px2 = q - py * pw2;
-            float m0 = 0.f, m1 = 0.f;  // r >= 0
+            float4 rv[2];
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy) {
                 const size_t o = base + (size_t)(2 * py + dy) * w + 4 * px2;
                 const float4 yv = *reinterpret_cast<const float4*>(t.y + o);
                 const float4 sv4 = *reinterpret_cast<const float4*>(t.sc + o);
-                float4 rv;
-                rv.x = tail_r(t, yv.x, sv4.x, as, ab, sv, ks, kb);
-                rv.y = tail_r(t, yv.y, sv4.y, as, ab, sv, ks, kb);
-                rv.z = tail_r(t, yv.z, sv4.z, as, ab, sv, ks, kb);
-                rv.w = tail_r(t, yv.w, sv4.w, as, ab, sv, ks, kb);
-                *reinterpret_cast<float4*>(r + o) = rv;
-                m0 = fmaxf(m0, fmaxf(rv.x, rv.y));
-                m1 = fmaxf(m1, fmaxf(rv.z, rv.w));
+                rv[dy].x = tail_r(t, yv.x, sv4.x, as, ab, sv, ks, kb);
+                rv[dy].y = tail_r(t, yv.y, sv4.y, as, ab, sv, ks, kb);
+                rv[dy].z = tail_r(t, yv.z, sv4.z, as, ab, sv, ks, kb);
+                rv[dy].w = tail_r(t, yv.w, sv4.w, as, ab, sv, ks, kb);
             }
-            *reinterpret_cast<float2*>(p + pbase + (size_t)py * pw + 2 * px2) = make_float2(m0 * dv, m1 * dv);
+            float m0, m1;
+            const unsigned c0 = tail_code(rv[0].x, rv[0].y, rv[1].x, rv[1].y, m0);
+            const unsigned c1 = tail_code(rv[0].z, rv[0].w, rv[1].z, rv[1].w, m1);
+            const size_t po = pbase + (size_t)py * pw + 2 * px2;  // even: pw is even here
+            *reinterpret_cast<uint16_t*>(route + po) = (uint16_t)(c0 | (c1 << 8));
+            *reinterpret_cast<float2*>(p + po) = make_float2(m0 * dv, m1 * dv);
         }
     } else {
         for (int q = blockIdx.y * kBlock + threadIdx.x; q < ph * pw; q += gridDim.y * kBlock) {
             const int py = q / pw, px = q - py * pw;
-            float mx = 0.f;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const size_t o = base + (size_t)(2 * py + dy) * w + 2 * px;
-                const float r0 = tail_r(t, t.y[o], t.sc[o], as, ab, sv, ks, kb);
-                const float r1 = tail_r(t, t.y[o + 1], t.sc[o + 1], as, ab, sv, ks, kb);
-                r[o] = r0;
-                r[o + 1] = r1;
-                mx = fmaxf(mx, fmaxf(r0, r1));
-            }
+            const size_t o0 = base + (size_t)(2 * py) * w + 2 * px, o1 = o0 + w;
+            const float r00 = tail_r(t, t.y[o0], t.sc[o0], as, ab, sv, ks, kb);
+            const float r01 = tail_r(t, t.y[o0 + 1], t.sc[o0 + 1], as, ab, sv, ks, kb);
+            const float r10 = tail_r(t, t.y[o1], t.sc[o1], as, ab, sv, ks, kb);
+            const float r11 = tail_r(t, t.y[o1 + 1], t.sc[o1 + 1], as, ab, sv, ks, kb);
+            float mx;
+            route[pbase + q] = (uint8_t)tail_code(r00, r01, r10, r11, mx);
             p[pbase + q] = mx * dv;
-        }
-    }
-    // leftover row / column when h or w is odd (not pooled, but r must be complete)
-    if ((h & 1) || (w & 1)) {
-        for (int q = blockIdx.y * kBlock + threadIdx.x; q < h * w; q += gridDim.y * kBlock) {
-            const int y = q / w, x = q - y * w;
-            if (y >= 2 * ph || x >= 2 * pw)
-                r[base + q] = tail_r(t, t.y[base + q], t.sc[base + q], as, ab, sv, ks, kb);
         }
     }
 }
 
-// dr = dp*drop routed to the first max of each 2x2 window where r > 0;
-// ds[n,c] = sum dr*a with a = relu(y*a_scale+a_shift) (or y)
+// dr = dp*drop routed to the recorded position of each 2x2 window when its maximum was > 0.
+// Per plane: ds = sum dr*a with a = relu(y*a_scale+a_shift) (or y), and (a_scale given)
+// plane_sums = {sum dr*[a>0], sum dr*[a>0]*y}: BatchNorm-2's backward sums without a second pass.
 __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(const float* __restrict__ dp,
-                                                          const float* __restrict__ r,
+                                                          const uint8_t* __restrict__ route,
                                                           const float* __restrict__ y,
                                                           const float* __restrict__ a_scale,
                                                           const float* __restrict__ a_shift,
                                                           const float* __restrict__ drop,
                                                           float* __restrict__ dr,
-                                                          float* __restrict__ ds, int c, int h,
-                                                          int w) {
-    __shared__ float red[4];
+                                                          float* __restrict__ ds,
+                                                          float* __restrict__ plane_sums, int c,
+                                                          int h, int w) {
+    __shared__ float red[12];
     const int plane = blockIdx.x, ch = plane % c;
     const float dv = drop ? drop[plane] : 1.f;
     const float as = a_scale ? a_scale[ch] : 1.f, ab = a_scale ? a_shift[ch] : 0.f;
     const int ph = h / 2, pw = w / 2;
     const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
-    float acc[1] = {0.f};
-    for (int t = threadIdx.x; t < ph * pw; t += kBlock) {
-        const int py = t / pw, px = t - py * pw;
-        const size_t o0 = base + (size_t)(2 * py) * w + 2 * px, o1 = o0 + w;
-        const float2 r0 = *reinterpret_cast<const float2*>(r + o0);
-        const float2 r1 = *reinterpret_cast<const float2*>(r + o1);
-        const float g = dp[pbase + t] * dv;
-        // argmax in window scan order (first maximum wins); relu'(r) = r > 0
-        float best = r0.x;
-        int bi = 0;
-        if (r0.y > best) { best = r0.y; bi = 1; }
-        if (r1.x > best) { best = r1.x; bi = 2; }
-        if (r1.y > best) { best = r1.y; bi = 3; }
-        const float gg = best > 0.f ? g : 0.f;
-        *reinterpret_cast<float2*>(dr + o0) = make_float2(bi == 0 ? gg : 0.f, bi == 1 ? gg : 0.f);
-        *reinterpret_cast<float2*>(dr + o1) = make_float2(bi == 2 ? gg : 0.f, bi == 3 ? gg : 0.f);
-        if (ds != nullptr && gg != 0.f) {
-            float av = y[bi < 2 ? o0 + bi : o1 + (bi - 2)];
-            if (a_scale) av = fmaxf(fmaf(av, as, ab), 0.f);
+    const bool sums = ds != nullptr || plane_sums != nullptr;
+    float acc[3] = {0.f, 0.f, 0.f};
+    auto tally = [&](float gg, size_t pos) {
+        if (sums && gg != 0.f) {
+            const float yv = y[pos];
+            float av = yv;
+            if (a_scale) {
+                av = fmaf(yv, as, ab);
+                if (av > 0.f) {
+                    acc[1] += gg;
+                    acc[2] += gg * yv;
+                } else {
+                    av = 0.f;
+                }
+            }
             acc[0] += gg * av;
+        }
+    };
+    if ((w & 3) == 0) {
+        const int pw2 = pw / 2;
+        for (int q = threadIdx.x; q < ph * pw2; q += kBlock) {
+            const int py = q / pw2, px2 = q - py * pw2;
+            const size_t po = pbase + (size_t)py * pw + 2 * px2;
+            const unsigned codes = *reinterpret_cast<const uint16_t*>(route + po);
+            const float2 g2 = *reinterpret_cast<const float2*>(dp + po);
+            const unsigned c0 = codes & 0xff, c1 = codes >> 8;
+            const float g0 = (c0 & 4u) ? g2.x * dv : 0.f, g1 = (c1 & 4u) ? g2.y * dv : 0.f;
+            const unsigned b0 = c0 & 3u, b1 = c1 & 3u;
+            const size_t o0 = base + (size_t)(2 * py) * w + 4 * px2, o1 = o0 + w;
+            *reinterpret_cast<float4*>(dr + o0) = make_float4(b0 == 0 ? g0 : 0.f, b0 == 1 ? g0 : 0.f,
+                                                              b1 == 0 ? g1 : 0.f, b1 == 1 ? g1 : 0.f);
+            *reinterpret_cast<float4*>(dr + o1) = make_float4(b0 == 2 ? g0 : 0.f, b0 == 3 ? g0 : 0.f,
+                                                              b1 == 2 ? g1 : 0.f, b1 == 3 ? g1 : 0.f);
+            tally(g0, (b0 < 2 ? o0 : o1) + (b0 & 1u));
+            tally(g1, (b1 < 2 ? o0 : o1) + 2 + (b1 & 1u));
+        }
+    } else {
+        for (int t = threadIdx.x; t < ph * pw; t += kBlock) {
+            const int py = t / pw, px = t - py * pw;
+            const size_t o0 = base + (size_t)(2 * py) * w + 2 * px, o1 = o0 + w;
+            const unsigned code = route[pbase + t];
+            const float gg = (code & 4u) ? dp[pbase + t] * dv : 0.f;
+            const unsigned bi = code & 3u;
+            dr[o0] = bi == 0 ? gg : 0.f;
+            dr[o0 + 1] = bi == 1 ? gg : 0.f;
+            dr[o1] = bi == 2 ? gg : 0.f;
+            dr[o1 + 1] = bi == 3 ? gg : 0.f;
+            tally(gg, (bi < 2 ? o0 : o1) + (bi & 1u));
         }
     }
     if ((h & 1) || (w & 1)) {
@@ -660,9 +702,61 @@ __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(const float* __restric
             if (yy >= 2 * ph || x >= 2 * pw) dr[base + t] = 0.f;
         }
     }
-    if (ds != nullptr) {
-        block_sum<1>(acc, red);
-        if (threadIdx.x == 0) ds[plane] = acc[0];
+    if (sums) {
+        block_sum<3>(acc, red);
+        if (threadIdx.x == 0) {
+            if (ds != nullptr) ds[plane] = acc[0];
+            if (plane_sums != nullptr) {
+                plane_sums[2 * (size_t)plane] = acc[1];
+                plane_sums[2 * (size_t)plane + 1] = acc[2];
+            }
+        }
+    }
+}
+
+// BatchNorm backward sums from per-plane sums (no pass over the activation): with
+// dz = (g*alpha + add) * [y*scale+shift > 0],
+//   sum dz       = sum_n alpha*G0 + add*M0          G = tail_bwd plane sums {sum g*mask, sum g*mask*y}
+//   sum dz*xhat  = invstd * sum_n alpha*(G1 - mean*G0) + add*(M1 - mean*M0)   M = gap mask sums
+// one workgroup per channel, fixed-order double accumulation.
+__global__ __launch_bounds__(kBlock) void bn_bwd_planes_kernel(const float* __restrict__ plane_g,
+                                                               const float* __restrict__ plane_m,
+                                                               const float* __restrict__ alpha,
+                                                               const float* __restrict__ addnc,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, int n,
+                                                               int c, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    __shared__ double red[2][kBlock / 64];
+    const int ch = blockIdx.x;
+    const double mu = mean[ch];
+    double s0 = 0.0, s1 = 0.0;
+    for (int img = threadIdx.x; img < n; img += kBlock) {
+        const size_t pl = (size_t)img * c + ch;
+        const double al = alpha ? alpha[pl] : 1.0, ad = addnc ? addnc[pl] : 0.0;
+        const double g0 = plane_g[2 * pl], g1 = plane_g[2 * pl + 1];
+        const double m0 = plane_m ? plane_m[2 * pl] : 0.0, m1 = plane_m ? plane_m[2 * pl + 1] : 0.0;
+        s0 += al * g0 + ad * m0;
+        s1 += al * (g1 - mu * g0) + ad * (m1 - mu * m0);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        s1 += __shfl_down(s1, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s0;
+        red[1][threadIdx.x >> 6] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) {
+            a += red[0][k];
+            b += red[1][k];
+        }
+        dbeta[ch] = (float)a;
+        dgamma[ch] = (float)(b * (double)invstd[ch]);
     }
 }
 
@@ -914,10 +1008,15 @@ int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
 
 int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* y,
                   const float* mean, const float* invstd, const float* scale, const float* shift,
-                  int relu, const float* gamma, float* dy, float* dgamma, float* dbeta, int n, int c,
-                  int hw, void* workspace, size_t ws_bytes, lf_stream_t stream) {
+                  int relu, const float* gamma, float* dy, float* dgamma, float* dbeta,
+                  const float* plane_g, const float* plane_m, int n, int c, int hw, void* workspace,
+                  size_t ws_bytes, lf_stream_t stream) {
     LF_REQUIRE(g && y && mean && invstd && scale && shift && gamma && dy && dgamma && dbeta && workspace,
                "lf_bn_bwd: null buffer");
+    LF_REQUIRE(plane_g != nullptr || plane_m == nullptr, "lf_bn_bwd: plane_m needs plane_g");
+    LF_REQUIRE(plane_g == nullptr || relu != 0, "lf_bn_bwd: plane sums describe the ReLU-masked case");
+    LF_REQUIRE(plane_g == nullptr || add_nc == nullptr || plane_m != nullptr,
+               "lf_bn_bwd: add_nc with plane sums needs plane_m");
     LF_REQUIRE(n > 0 && c > 0 && hw > 0 && c <= 65535 && (long long)n * c < (1LL << 31),
                "lf_bn_bwd: bad dims n=%d c=%d hw=%d", n, c, hw);
     if (ws_bytes < lf_bn_workspace(c)) {
@@ -927,19 +1026,26 @@ int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, co
     BnBwdArgs a{g, alpha_nc, add_nc, y, mean, invstd, scale, shift, relu, n, c, hw};
     hipStream_t s = lf::as_stream(stream);
     float* part = static_cast<float*>(workspace);
-    bn_bwd_reduce_kernel<<<dim3(kBnSplit, c), kBlock, 0, s>>>(a, part);
-    bn_bwd_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(part, c, dgamma, dbeta);
+    if (plane_g != nullptr) {
+        bn_bwd_planes_kernel<<<c, kBlock, 0, s>>>(plane_g, plane_m, alpha_nc, add_nc, mean, invstd, n, c,
+                                                  dgamma, dbeta);
+    } else {
+        bn_bwd_reduce_kernel<<<dim3(kBnSplit, c), kBlock, 0, s>>>(a, part);
+        bn_bwd_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(part, c, dgamma, dbeta);
+    }
     bn_bwd_apply_kernel<<<dim3(n * c, plane_grid((hw & 3) ? hw : hw / 4)), kBlock, 0, s>>>(
         a, gamma, dgamma, dbeta, 1.0f / ((float)n * (float)hw), dy);
     return lf::check_launch("lf_bn_bwd");
 }
 
 int lf_gap_f32(const float* x, float* out, int planes, int hw, int c, const float* scale,
-               const float* shift, int relu, lf_stream_t stream) {
+               const float* shift, int relu, float* mask_sums, lf_stream_t stream) {
     LF_REQUIRE(x && out, "lf_gap: null buffer");
+    LF_REQUIRE(mask_sums == nullptr || scale != nullptr, "lf_gap: mask_sums needs scale/shift");
     LF_REQUIRE(planes > 0 && hw > 0 && c > 0, "lf_gap: bad dims planes=%d hw=%d c=%d", planes, hw, c);
     LF_REQUIRE((scale == nullptr) == (shift == nullptr), "lf_gap: scale/shift must both be set");
-    gap_kernel<<<planes, kBlock, 0, lf::as_stream(stream)>>>(x, out, hw, c, scale, shift, relu);
+    gap_kernel<<<planes, kBlock, 0, lf::as_stream(stream)>>>(x, out, hw, c, scale, shift, relu,
+                                                             mask_sums);
     return lf::check_launch("lf_gap");
 }
 
@@ -991,9 +1097,9 @@ int lf_se_bwd_f32(const float* ds, const float* m, const float* z1, const float*
 
 int lf_block_tail_fwd_f32(const float* y, const float* a_scale, const float* a_shift,
                           const float* s, const float* sc, const float* sc_scale,
-                          const float* sc_shift, int sc_relu, const float* drop, float* r, float* p,
-                          int n, int c, int h, int w, lf_stream_t stream) {
-    LF_REQUIRE(y && sc && r && p, "lf_block_tail_fwd: null buffer");
+                          const float* sc_shift, int sc_relu, const float* drop, uint8_t* route,
+                          float* p, int n, int c, int h, int w, lf_stream_t stream) {
+    LF_REQUIRE(y && sc && route && p, "lf_block_tail_fwd: null buffer");
     LF_REQUIRE(n > 0 && c > 0 && h > 1 && w > 1 && (long long)n * c < (1LL << 31),
                "lf_block_tail_fwd: bad dims n=%d c=%d h=%d w=%d", n, c, h, w);
     LF_REQUIRE((w & 1) == 0, "lf_block_tail_fwd: width must be even");
@@ -1001,20 +1107,24 @@ int lf_block_tail_fwd_f32(const float* y, const float* a_scale, const float* a_s
     LF_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "lf_block_tail_fwd: a_scale/a_shift");
     TailArgs t{y, a_scale, a_shift, s, sc, sc_scale, sc_shift, drop, sc_relu, c, h, w};
     const int items = (w & 3) == 0 ? (h / 2) * (w / 4) : (h / 2) * (w / 2);
-    tail_fwd_kernel<<<dim3(n * c, plane_grid(items)), kBlock, 0, lf::as_stream(stream)>>>(t, r, p);
+    tail_fwd_kernel<<<dim3(n * c, plane_grid(items)), kBlock, 0, lf::as_stream(stream)>>>(t, route, p);
     return lf::check_launch("lf_block_tail_fwd");
 }
 
-int lf_block_tail_bwd_f32(const float* dp, const float* r, const float* y, const float* a_scale,
-                          const float* a_shift, const float* drop, float* dr, float* ds, int n,
-                          int c, int h, int w, lf_stream_t stream) {
-    LF_REQUIRE(dp && r && dr, "lf_block_tail_bwd: null buffer");
+int lf_block_tail_bwd_f32(const float* dp, const uint8_t* route, const float* y,
+                          const float* a_scale, const float* a_shift, const float* drop, float* dr,
+                          float* ds, float* plane_sums, int n, int c, int h, int w,
+                          lf_stream_t stream) {
+    LF_REQUIRE(dp && route && dr, "lf_block_tail_bwd: null buffer");
+    LF_REQUIRE(plane_sums == nullptr || (y != nullptr && a_scale != nullptr),
+               "lf_block_tail_bwd: plane_sums needs y and a_scale/a_shift");
     LF_REQUIRE(n > 0 && c > 0 && h > 1 && w > 1, "lf_block_tail_bwd: bad dims n=%d c=%d h=%d w=%d", n, c, h, w);
     LF_REQUIRE((w & 1) == 0, "lf_block_tail_bwd: width must be even (float2 rows)");
-    LF_REQUIRE((y == nullptr) == (ds == nullptr), "lf_block_tail_bwd: y and ds go together");
+    LF_REQUIRE((y == nullptr) == (ds == nullptr && plane_sums == nullptr),
+               "lf_block_tail_bwd: y goes with ds / plane_sums");
     LF_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "lf_block_tail_bwd: a_scale/a_shift");
-    tail_bwd_kernel<<<n * c, kBlock, 0, lf::as_stream(stream)>>>(dp, r, y, a_scale, a_shift, drop, dr, ds,
-                                                                c, h, w);
+    tail_bwd_kernel<<<n * c, kBlock, 0, lf::as_stream(stream)>>>(dp, route, y, a_scale, a_shift, drop, dr,
+                                                                ds, plane_sums, c, h, w);
     return lf::check_launch("lf_block_tail_bwd");
 }
 

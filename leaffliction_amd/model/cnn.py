@@ -174,11 +174,11 @@ class LeafCNN:
             self.s[n_ + ".var"].fill_(1.0)
 
     # ------------------------------------------------------------- buffers
-    def _buf(self, n: int, key: str, shape) -> torch.Tensor:
+    def _buf(self, n: int, key: str, shape, dtype=torch.float32) -> torch.Tensor:
         d = self._bufs.setdefault(n, {})
         t = d.get(key)
-        if t is None or tuple(t.shape) != tuple(shape):
-            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
             d[key] = t
         return t
 
@@ -343,7 +343,11 @@ class LeafCNN:
                                     B(p + "y2", y1.shape), training)
             s = None
             if self.use_se:
-                m = nn.gap(y2, out=B(p + "m", (n, f)), scale=st2[2], shift=st2[3], relu=True)
+                # the squeeze pass also leaves BN2's ReLU-mask sums for the backward pass
+                msum = B(p + "msum", (n, f, 2)) if training else None
+                m = nn.gap(y2, out=B(p + "m", (n, f)), scale=st2[2], shift=st2[3], relu=True,
+                           mask_sums=msum)
+                sv[p + "msum"] = msum
                 z1 = B(p + "z1", (n, f // 8))
                 s = nn.se_fwd(m, P[p + "se.w1"], P[p + "se.b1"], P[p + "se.w2"], P[p + "se.b2"], z1,
                               B(p + "s", (n, f)))
@@ -356,11 +360,11 @@ class LeafCNN:
             else:
                 sc, scs, scb, scr = xin, pro[0], pro[1], pro[2]
             drop = drops[i] if (training and drops is not None) else None
-            r = B(p + "r", y1.shape)
             pooled = B(p + "p", (n, f, h // 2, w // 2))
-            nn.block_tail_fwd(y2, st2[2], st2[3], s, sc, scs, scb, scr, drop, r, pooled)
+            route = self._buf(n, p + "route", pooled.shape, torch.uint8)
+            nn.block_tail_fwd(y2, st2[2], st2[3], s, sc, scs, scb, scr, drop, route, pooled)
             sv.update({p + "xin": xin, p + "xin_st": xin_st, p + "y1": y1, p + "y2": y2, p + "s": s,
-                       p + "r": r, p + "drop": drop, p + "hw": (h, w)})
+                       p + "route": route, p + "drop": drop, p + "hw": (h, w)})
             xin, xin_st, cin, h, w = pooled, None, f, h // 2, w // 2
         a = xin
         g = nn.gap(a, out=B("g", (n, self.widths[-1])))
@@ -399,14 +403,15 @@ class LeafCNN:
             h, w = sv[p + "hw"]
             xin, xin_st, y1, y2 = (sv[p + k] for k in ("xin", "xin_st", "y1", "y2"))
             pro = (xin_st[2], xin_st[3], True) if xin_st is not None else (None, None, False)
-            s, r, drop = sv[p + "s"], sv[p + "r"], sv[p + "drop"]
+            s, route, drop = sv[p + "s"], sv[p + "route"], sv[p + "drop"]
             st1, st2 = self.stats[p + "bn1"], self.stats[p + "bn2"]
             gA = B(p + "gA", y1.shape)
             gB = B(p + "gB", y1.shape)
             gC = B(p + "gC", y1.shape)
             ds = B(p + "ds", (n, f)) if self.use_se else None
-            nn.block_tail_bwd(dp, r, y2 if self.use_se else None, st2[2] if self.use_se else None,
-                              st2[3] if self.use_se else None, drop, gA, ds)
+            # dr (into gA), the SE gate gradient, and BN2's per-plane backward sums in one pass
+            psum = B(p + "psum", (n, f, 2))
+            nn.block_tail_bwd(dp, route, y2, st2[2], st2[3], drop, gA, ds, psum)
             add_nc = None
             if self.use_se:
                 dm = B(p + "dm", (n, f))
@@ -416,7 +421,8 @@ class LeafCNN:
                 add_nc = dm
             # conv2 branch: dz2 = (dr*s + dm/HW) * [a2 > 0] -> BN2 backward -> dy2 (gB)
             nn.bn_bwd(gA, y2, st2, P[p + "bn2.gamma"], G[p + "bn2.gamma"], G[p + "bn2.beta"], True,
-                      alpha_nc=s, add_nc=add_nc, out=gB)
+                      alpha_nc=s, add_nc=add_nc, out=gB, plane_g=psum,
+                      plane_m=sv[p + "msum"] if self.use_se else None)
             nn.conv2d_wgrad(y1, gB, 3, st1[2], st1[3], True, out=G[p + "c2.w"])
             nn.conv2d(gB, self._dgrad_w(p + "c2.w", 3), 3, out=gC)          # da1
             nn.bn_bwd(gC, y1, st1, P[p + "bn1.gamma"], G[p + "bn1.gamma"], G[p + "bn1.beta"], True,

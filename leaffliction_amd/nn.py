@@ -206,13 +206,21 @@ def bn_infer_scale_shift(gamma, beta, mmean, mvar, stats, eps=1e-3):
     return stats
 
 
-def bn_bwd(g, y, stats, gamma, dgamma, dbeta, relu: bool, alpha_nc=None, add_nc=None, out=None):
-    """BatchNorm backward; the ReLU mask (relu=True) is recomputed from y and stats[2:4]."""
+def bn_bwd(g, y, stats, gamma, dgamma, dbeta, relu: bool, alpha_nc=None, add_nc=None, out=None,
+           plane_g=None, plane_m=None):
+    """BatchNorm backward; the ReLU mask (relu=True) is recomputed from y and stats[2:4].
+    plane_g ([N,C,2] from block_tail_bwd) / plane_m ([N,C,2] from gap) replace the reduction
+    pass over g and y."""
     _chk(g, _F32, "bn_bwd.g", 4)
     _chk(y, _F32, "bn_bwd.y", 4)
     if g.shape != y.shape:
         raise ValueError("bn_bwd: g and y must share a shape")
     n, c, h, w = y.shape
+    for t in (plane_g, plane_m):
+        if t is not None:
+            _chk(t, _F32, "bn_bwd.plane sums", 3)
+            if tuple(t.shape) != (n, c, 2):
+                raise ValueError("bn_bwd: plane sums must be [N,C,2]")
     for t in (alpha_nc, add_nc):
         if t is not None:
             _chk(t, _F32, "bn_bwd.alpha/add", 2)
@@ -224,18 +232,24 @@ def bn_bwd(g, y, stats, gamma, dgamma, dbeta, relu: bool, alpha_nc=None, add_nc=
     _lib.call("lf_bn_bwd_f32", g.data_ptr(), _ptr(alpha_nc), _ptr(add_nc), y.data_ptr(),
               stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
               1 if relu else 0, gamma.data_ptr(), out.data_ptr(), dgamma.data_ptr(),
-              dbeta.data_ptr(), n, c, h * w, ws.data_ptr(), ws.numel(), _stream())
+              dbeta.data_ptr(), _ptr(plane_g), _ptr(plane_m), n, c, h * w, ws.data_ptr(), ws.numel(),
+              _stream())
     return out
 
 
-def gap(x, out=None, scale=None, shift=None, relu: bool = False):
-    """[N,C,H,W] -> [N,C] mean of act(x*scale[c]+shift[c]) (plain mean without scale)."""
+def gap(x, out=None, scale=None, shift=None, relu: bool = False, mask_sums=None):
+    """[N,C,H,W] -> [N,C] mean of act(x*scale[c]+shift[c]) (plain mean without scale).
+    mask_sums [N,C,2] (optional) receives {count of x*scale+shift > 0, sum of x over those}."""
     _chk(x, _F32, "gap.x", 4)
     n, c, h, w = x.shape
     if out is None:
         out = torch.empty((n, c), dtype=_F32, device=x.device)
+    if mask_sums is not None:
+        _chk(mask_sums, _F32, "gap.mask_sums", 3)
+        if tuple(mask_sums.shape) != (n, c, 2):
+            raise ValueError("gap.mask_sums: expected [N,C,2]")
     _lib.call("lf_gap_f32", x.data_ptr(), out.data_ptr(), n * c, h * w, c, _ptr(scale), _ptr(shift),
-              1 if relu else 0, _stream())
+              1 if relu else 0, _ptr(mask_sums), _stream())
     return out
 
 
@@ -271,24 +285,30 @@ def se_bwd(ds, m, z1, s, w1, w2, dm, dw1, db1, dw2, db2, dm_scale: float = 1.0):
     return dm
 
 
-def block_tail_fwd(y, a_scale, a_shift, s, sc, sc_scale, sc_shift, sc_relu, drop, r, p):
+def block_tail_fwd(y, a_scale, a_shift, s, sc, sc_scale, sc_shift, sc_relu, drop, route, p):
+    """Add -> ReLU -> SpatialDropout2D -> MaxPool2D(2); route: uint8 [N,C,H/2,W/2] (written)."""
     _chk(y, _F32, "block_tail_fwd.y", 4)
+    _chk(route, torch.uint8, "block_tail_fwd.route", 4)
     n, c, h, w = y.shape
-    if sc.shape != y.shape or r.shape != y.shape or tuple(p.shape) != (n, c, h // 2, w // 2):
+    if sc.shape != y.shape or tuple(p.shape) != (n, c, h // 2, w // 2) or route.shape != p.shape:
         raise ValueError("block_tail_fwd: shape mismatch")
     _lib.call("lf_block_tail_fwd_f32", y.data_ptr(), _ptr(a_scale), _ptr(a_shift), _ptr(s),
               sc.data_ptr(), _ptr(sc_scale), _ptr(sc_shift), 1 if sc_relu else 0, _ptr(drop),
-              r.data_ptr(), p.data_ptr(), n, c, h, w, _stream())
-    return r, p
+              route.data_ptr(), p.data_ptr(), n, c, h, w, _stream())
+    return route, p
 
 
-def block_tail_bwd(dp, r, y, a_scale, a_shift, drop, dr, ds):
-    _chk(r, _F32, "block_tail_bwd.r", 4)
-    n, c, h, w = r.shape
-    if tuple(dp.shape) != (n, c, h // 2, w // 2) or dr.shape != r.shape:
+def block_tail_bwd(dp, route, y, a_scale, a_shift, drop, dr, ds, plane_sums=None):
+    _chk(dr, _F32, "block_tail_bwd.dr", 4)
+    _chk(route, torch.uint8, "block_tail_bwd.route", 4)
+    n, c, h, w = dr.shape
+    if tuple(dp.shape) != (n, c, h // 2, w // 2) or route.shape != dp.shape:
         raise ValueError("block_tail_bwd: shape mismatch")
-    _lib.call("lf_block_tail_bwd_f32", dp.data_ptr(), r.data_ptr(), _ptr(y), _ptr(a_scale),
-              _ptr(a_shift), _ptr(drop), dr.data_ptr(), _ptr(ds), n, c, h, w, _stream())
+    if plane_sums is not None and tuple(plane_sums.shape) != (n, c, 2):
+        raise ValueError("block_tail_bwd.plane_sums: expected [N,C,2]")
+    _lib.call("lf_block_tail_bwd_f32", dp.data_ptr(), route.data_ptr(), _ptr(y), _ptr(a_scale),
+              _ptr(a_shift), _ptr(drop), dr.data_ptr(), _ptr(ds), _ptr(plane_sums), n, c, h, w,
+              _stream())
     return dr, ds
 
 
