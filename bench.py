@@ -64,7 +64,7 @@ class KernelTimer:
 
         def call(name, *args):
             if not timer.enabled or name not in ("lf_conv2d_f32", "lf_conv2d_stats_f32",
-                                                 "lf_conv2d_wgrad_f32"):
+                                                 "lf_conv2d_wgrad_f32", "lf_conv2d_wgrad_bn_f32"):
                 return timer._orig(name, *args)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -76,11 +76,13 @@ class KernelTimer:
                 n, cin, h, w, cout, k = args[3:9]
                 kname = FWD_NAMES[lib.lf_conv2d_variant(h, w, cout)].replace("T", str(k * k))
             else:
-                n, cin, h, w, cout, k = args[2:8]
+                n, cin, h, w, cout, k = args[8:14] if name == "lf_conv2d_wgrad_bn_f32" else args[2:8]
                 kname = (WG_NAMES3 if k == 3 else WG_NAMES1)[lib.lf_conv2d_wgrad_variant(n, cin, h, w, cout, k)]
             flop = 2.0 * n * h * w * cin * cout * k * k
             # operands once: both activation tensors + the weights / weight-gradient
             nbytes = 4.0 * (n * h * w * (cin + cout) + cin * cout * k * k)
+            if name == "lf_conv2d_wgrad_bn_f32":  # also reads the BN input and writes dy
+                nbytes += 8.0 * n * h * w * cout
             timer.records.append((kname, flop, e0, e1, nbytes))
             return rc
 

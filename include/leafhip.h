@@ -206,6 +206,17 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, 
                         void* workspace, size_t ws_bytes, lf_stream_t stream);
 int lf_conv2d_wgrad_reduce_f32(void* workspace, float* dw, int n, int cin, int h, int wd,
                                int cout, int ksize, float beta, lf_stream_t stream);
+/* Weight gradient whose dY operand is a BatchNormalization backward, formed on the fly:
+ * dY = coef2*dz + coef3*bn_y + coef4, dz = (g*alpha_nc+add_nc)*[bn_y*coef0+coef1 > 0 or !bn_relu]
+ * (coef from lf_bn_bwd_sums_f32), also written to dy_out [n][cout][h][w] for the input-gradient
+ * convolution that follows.  3x3, shapes for which lf_conv2d_wgrad_bn_supported() != 0; same
+ * workspace and reduce step as lf_conv2d_wgrad_f32. */
+int lf_conv2d_wgrad_bn_supported(int n, int cin, int h, int w, int cout, int ksize);
+int lf_conv2d_wgrad_bn_f32(const float* x, const float* g, const float* bn_y,
+                           const float* alpha_nc, const float* add_nc, const float* coef,
+                           int bn_relu, float* dy_out, int n, int cin, int h, int w, int cout,
+                           int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                           void* workspace, size_t ws_bytes, lf_stream_t stream);
 
 /* ---- input stage ----------------------------------------------------------- */
 /* u8 HWC -> f32 NCHW with the model's train-time augmentation fused (cnn.py:74-86):
@@ -255,6 +266,16 @@ int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, co
                   int relu, const float* gamma, float* dy, float* dgamma, float* dbeta,
                   const float* plane_g, const float* plane_m, int n, int c, int hw, void* workspace,
                   size_t ws_bytes, lf_stream_t stream);
+
+/* The two channel sums of lf_bn_bwd_f32 without the apply pass: dgamma, dbeta and coef [5][c] =
+ * {scale, shift, P, Q, R} such that dy = P*dz + Q*y + R with dz = (g*alpha+add)*[y*scale+shift>0
+ * or !relu].  lf_conv2d_wgrad_bn_f32 forms dy from g and y with these while it computes the
+ * weight gradient, so the standalone apply pass (2 reads + 1 write) disappears. */
+int lf_bn_bwd_sums_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* y,
+                       const float* mean, const float* invstd, const float* scale,
+                       const float* shift, int relu, const float* gamma, float* dgamma, float* dbeta,
+                       float* coef, const float* plane_g, const float* plane_m, int n, int c, int hw,
+                       void* workspace, size_t ws_bytes, lf_stream_t stream);
 
 /* ---- pooling / broadcast ---- */
 /* out[p] = mean over hw of act(x[p][:]*scale[c]+shift[c]), c = p % C (GlobalAveragePooling2D,

@@ -48,6 +48,9 @@ SIGNATURES = {
     "lf_conv2d_wgrad_workspace": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_wgrad_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,
                             c_size_t, P],
+    "lf_conv2d_wgrad_bn_supported": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "lf_conv2d_wgrad_bn_f32": [P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P,
+                               c_int, P, c_size_t, P],
     "lf_conv2d_wgrad_reduce_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P],
     "lf_input_stage_f32": [P, P, c_int, c_int, c_int, P, P, P, P, P],
     "lf_scale_shift_act_f32": [P, P, c_int, c_int, c_int, P, P, c_int, P],
@@ -55,6 +58,8 @@ SIGNATURES = {
     "lf_bn_train_stats_f32": [P, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P,
                               P, c_size_t, P],
     "lf_bn_train_stats_tiles_f32": [P, C.c_longlong, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P],
+    "lf_bn_bwd_sums_f32": [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P,
+                           c_size_t, P],
     "lf_bn_infer_scale_shift_f32": [c_int, P, P, P, P, c_float, P, P, P],
     "lf_bn_bwd_f32": [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P,
                       c_size_t, P],

@@ -409,7 +409,24 @@ struct WgradArgs {
     int tiles_x, tiles_y, items, items_per_split;
     int in_relu;
     int vec_ok;
+    // optional: dY is the BatchNorm backward of `dy` (= upstream g), formed while staging
+    //   dz = (g*alpha[n][co] + add[n][co]) * [bn_y*coef0[co] + coef1[co] > 0 or !bn_relu]
+    //   dY = coef2[co]*dz + coef3[co]*bn_y + coef4[co]
+    // and written to dy_out by the ci-block-0 workgroups (each element exactly once)
+    const float* bn_y;     // null = plain dY
+    const float* bn_alpha;
+    const float* bn_add;
+    const float* bn_coef;  // [5][Cout]
+    float* dy_out;
+    int bn_relu;
 };
+
+__device__ __forceinline__ float bn_dy1(float g, float y, float al, float ad, float c0, float c1,
+                                        float c2, float c3, float c4, int relu) {
+    float dz = fmaf(g, al, ad);
+    if (relu && !(fmaf(y, c0, c1) > 0.f)) dz = 0.f;
+    return fmaf(c2, dz, fmaf(c3, y, c4));
+}
 
 template <int TAPS, int TW, int TH, int WCI, int WCO, int KSPL>
 __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kernel(WgradArgs p) {
@@ -781,9 +798,18 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
     const int tiles = p.tiles_x * p.tiles_y;
 
     if (p.vec_ok) {  // every tile is full in x (host guarantees W % TW == 0 for this path)
-        float4 xv[XPT], dv[DPT];
-        float xh[HPT];
-        unsigned xok = 0;
+        float4 xv[XPT], dv[DPT], yv[DPT];
+        float xh[HPT], dal[DPT], dad[DPT];
+        unsigned xok = 0, dok = 0;
+        const bool bn = p.bn_y != nullptr;
+        // BatchNorm-backward coefficients of this workgroup's CO_T channels
+        __shared__ float lbn[5 * CO_T];
+        if (bn) {
+            for (int e = tid; e < 5 * CO_T; e += NT) {
+                const int kk = e / CO_T, gc = co0 + (e - kk * CO_T);
+                lbn[e] = gc < p.cout ? p.bn_coef[(size_t)kk * p.cout + gc] : 0.f;
+            }
+        }
         // producer BatchNorm scale/shift of this workgroup's CI_T channels, staged once in LDS
         __shared__ float lsc[kMaxProC / 2];
         if (pro) {
@@ -838,8 +864,38 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                                                          (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
                 dv[i] = v;
             }
+            if (bn) {
+                const float* yin = p.bn_y + (size_t)n * p.cout * hw;
+                dok = 0;
+#pragma unroll
+                for (int i = 0; i < DPT; ++i) {
+                    const int e = tid + i * NT;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                    const int py = rem / TW4, slot = rem - py * TW4;
+                    const int gc = co0 + c, gy = ty0 + py;
+                    if (e < NDI && gc < p.cout && gy < p.h) {
+                        v = *reinterpret_cast<const float4*>(yin + (unsigned)gc * uhw +
+                                                             (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                        dok |= 1u << i;
+                    }
+                    yv[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < DPT; ++i) {
+                    const int e = tid + i * NT;
+                    const int gc = co0 + e / (TH * TW4);
+                    float al = 1.f, ad = 0.f;
+                    if (p.bn_alpha != nullptr && e < NDI && gc < p.cout) {
+                        al = p.bn_alpha[(size_t)n * p.cout + gc];
+                        ad = p.bn_add != nullptr ? p.bn_add[(size_t)n * p.cout + gc] : 0.f;
+                    }
+                    dal[i] = al;
+                    dad[i] = ad;
+                }
+            }
         };
-        auto store_item = [&]() {
+        auto store_item = [&](int item) {
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
                 const int e = tid + i * NT;
@@ -873,23 +929,39 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                     lx[c * PP + py * PW + (side ? PW - 1 : 0)] = v;
                 }
             }
+            const int sn = item / tiles, st = item - sn * tiles;
+            const int stx0 = (st % p.tiles_x) * TW, sty0 = (st / p.tiles_x) * TH;
 #pragma unroll
             for (int i = 0; i < DPT; ++i) {
                 const int e = tid + i * NT;
                 if (e < NDI) {
                     const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                    float4 v = dv[i];
+                    if (bn && (dok >> i & 1u)) {
+                        const float c0 = lbn[c], c1 = lbn[CO_T + c], c2 = lbn[2 * CO_T + c],
+                                    c3 = lbn[3 * CO_T + c], c4 = lbn[4 * CO_T + c];
+                        v.x = bn_dy1(v.x, yv[i].x, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
+                        v.y = bn_dy1(v.y, yv[i].y, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
+                        v.z = bn_dy1(v.z, yv[i].z, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
+                        v.w = bn_dy1(v.w, yv[i].w, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
+                        if (blockIdx.y == 0) {
+                            const int py = rem / TW4, slot = rem - py * TW4;
+                            *reinterpret_cast<float4*>(p.dy_out + ((size_t)sn * p.cout + co0 + c) * hw +
+                                                       (size_t)(sty0 + py) * p.wd + stx0 + 4 * slot) = v;
+                        }
+                    }
                     float* dst = ld + c * DP + rem * 4;
-                    dst[0] = dv[i].x;
-                    dst[1] = dv[i].y;
-                    dst[2] = dv[i].z;
-                    dst[3] = dv[i].w;
+                    dst[0] = v.x;
+                    dst[1] = v.y;
+                    dst[2] = v.z;
+                    dst[3] = v.w;
                 }
             }
         };
         if (first < last) load_item(first);
         for (int item = first; item < last; ++item) {
             __syncthreads();
-            store_item();
+            store_item(item);
             __syncthreads();
             if (item + 1 < last) load_item(item + 1);  // in flight during the MFMAs
             compute_item();
@@ -1216,6 +1288,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15)
 
 extern "C" {
 
+int lf_conv2d_wgrad_bn_supported(int n, int cin, int h, int wd, int cout, int ksize);
+
 int lf_conv2d_variant(int h, int wd, int cout) {
     int best = 0;
     long long bw = -1;
@@ -1313,20 +1387,22 @@ size_t lf_conv2d_wgrad_workspace(int n, int cin, int h, int wd, int cout, int ks
     return ((size_t)pl.splits + groups) * count * sizeof(float);
 }
 
-int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, int wd, int cout,
-                        int ksize, const float* in_scale, const float* in_shift, int in_relu,
-                        void* workspace, size_t ws_bytes, lf_stream_t stream) {
-    LF_REQUIRE(x && dy && workspace, "lf_conv2d_wgrad: null buffer");
+static int wgrad_launch(const char* who, const float* x, const float* dy, int n, int cin, int h,
+                        int wd, int cout, int ksize, const float* in_scale, const float* in_shift,
+                        int in_relu, const float* bn_y, const float* bn_alpha, const float* bn_add,
+                        const float* bn_coef, int bn_relu, float* dy_out, void* workspace,
+                        size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(x && dy && workspace, "%s: null buffer", who);
     LF_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && wd > 0,
-               "lf_conv2d_wgrad: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, wd);
-    LF_REQUIRE(ksize == 3 || ksize == 1, "lf_conv2d_wgrad: ksize must be 1 or 3 (got %d)", ksize);
+               "%s: bad dims n=%d cin=%d cout=%d h=%d w=%d", who, n, cin, cout, h, wd);
+    LF_REQUIRE(ksize == 3 || ksize == 1, "%s: ksize must be 1 or 3 (got %d)", who, ksize);
     LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr),
-               "lf_conv2d_wgrad: in_scale/in_shift must both be set");
+               "%s: in_scale/in_shift must both be set", who);
     LF_REQUIRE((size_t)cin * h * wd < (1ull << 30) && (size_t)cout * h * wd < (1ull << 30),
-               "lf_conv2d_wgrad: per-image tensor too large for 32-bit offsets");
+               "%s: per-image tensor too large for 32-bit offsets", who);
     const WgPlan pl = plan_wgrad(n, cin, cout, h, wd, ksize);
     if (ws_bytes < lf_conv2d_wgrad_workspace(n, cin, h, wd, cout, ksize)) {
-        lf::set_error("lf_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes,
+        lf::set_error("%s: workspace %zu < %zu bytes", who, ws_bytes,
                       lf_conv2d_wgrad_workspace(n, cin, h, wd, cout, ksize));
         return LF_ERR_WORKSPACE;
     }
@@ -1338,6 +1414,16 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, 
     a.items_per_split = pl.items_per_split;
     a.in_relu = in_relu;
     a.vec_ok = (wd % pl.tw == 0) && (wd % 4 == 0) && aligned16(x) && aligned16(dy);
+    a.bn_y = bn_y; a.bn_alpha = bn_alpha; a.bn_add = bn_add; a.bn_coef = bn_coef;
+    a.dy_out = dy_out; a.bn_relu = bn_relu;
+    if (bn_y != nullptr) {
+        LF_REQUIRE(bn_coef && dy_out, "%s: bn_coef / dy_out missing", who);
+        LF_REQUIRE(bn_add == nullptr || bn_alpha != nullptr, "%s: bn_add needs bn_alpha", who);
+        LF_REQUIRE(lf_conv2d_wgrad_bn_supported(n, cin, h, wd, cout, ksize) && a.vec_ok &&
+                       aligned16(bn_y) && aligned16(dy_out),
+                   "%s: shape/alignment not supported by the fused BatchNorm-backward path "
+                   "(ask lf_conv2d_wgrad_bn_supported first)", who);
+    }
     dim3 grid(pl.splits, pl.gy, pl.gz);
     hipStream_t s = lf::as_stream(stream);
     int rc = LF_OK;
@@ -1346,7 +1432,32 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, 
     else
         rc = launch_wgrad(ksize, pl.variant, a, grid, s);
     if (rc != LF_OK) return rc;
-    return lf::check_launch("lf_conv2d_wgrad");
+    return lf::check_launch(who);
+}
+
+int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, int wd, int cout,
+                        int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                        void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    return wgrad_launch("lf_conv2d_wgrad", x, dy, n, cin, h, wd, cout, ksize, in_scale, in_shift,
+                        in_relu, nullptr, nullptr, nullptr, nullptr, 0, nullptr, workspace, ws_bytes,
+                        stream);
+}
+
+int lf_conv2d_wgrad_bn_supported(int n, int cin, int h, int wd, int cout, int ksize) {
+    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || wd <= 0 || ksize != 3) return 0;
+    const WgPlan pl = plan_wgrad(n, cin, cout, h, wd, ksize);
+    return pl.variant != kWgSmallCin && (wd % pl.tw == 0) && (wd % 4 == 0);
+}
+
+int lf_conv2d_wgrad_bn_f32(const float* x, const float* g, const float* bn_y,
+                           const float* alpha_nc, const float* add_nc, const float* coef,
+                           int bn_relu, float* dy_out, int n, int cin, int h, int wd, int cout,
+                           int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                           void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(bn_y, "lf_conv2d_wgrad_bn: null bn_y");
+    return wgrad_launch("lf_conv2d_wgrad_bn", x, g, n, cin, h, wd, cout, ksize, in_scale, in_shift,
+                        in_relu, bn_y, alpha_nc, add_nc, coef, bn_relu, dy_out, workspace, ws_bytes,
+                        stream);
 }
 
 int lf_conv2d_wgrad_reduce_f32(void* workspace, float* dw, int n, int cin, int h, int wd, int cout,

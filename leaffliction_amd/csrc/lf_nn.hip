@@ -348,6 +348,24 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int c,
     dgamma[ch] = (float)q;
 }
 
+// dy = coef2*dz + coef3*y + coef4 with dz masked by y*coef0+coef1 > 0: the apply step as five
+// per-channel coefficients, for consumers that form dy while they read g and y
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ invstd,
+                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                   const float* __restrict__ dbeta, float inv_count, int c,
+                                   float* __restrict__ coef) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const float k = gamma[ch] * invstd[ch];
+    const float mdz = dbeta[ch] * inv_count, mdzx = dgamma[ch] * inv_count;
+    coef[ch] = scale[ch];
+    coef[c + ch] = shift[ch];
+    coef[2 * c + ch] = k;
+    coef[3 * c + ch] = -k * invstd[ch] * mdzx;
+    coef[4 * c + ch] = k * (mean[ch] * invstd[ch] * mdzx - mdz);
+}
+
 __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(BnBwdArgs a,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ dgamma,
@@ -1036,6 +1054,39 @@ int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, co
     bn_bwd_apply_kernel<<<dim3(n * c, plane_grid((hw & 3) ? hw : hw / 4)), kBlock, 0, s>>>(
         a, gamma, dgamma, dbeta, 1.0f / ((float)n * (float)hw), dy);
     return lf::check_launch("lf_bn_bwd");
+}
+
+int lf_bn_bwd_sums_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* y,
+                       const float* mean, const float* invstd, const float* scale,
+                       const float* shift, int relu, const float* gamma, float* dgamma, float* dbeta,
+                       float* coef, const float* plane_g, const float* plane_m, int n, int c, int hw,
+                       void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(mean && invstd && scale && shift && gamma && dgamma && dbeta && coef && workspace,
+               "lf_bn_bwd_sums: null buffer");
+    LF_REQUIRE(plane_g != nullptr || (g != nullptr && y != nullptr), "lf_bn_bwd_sums: g / y missing");
+    LF_REQUIRE(n > 0 && c > 0 && hw > 0 && c <= 65535 && (long long)n * c < (1LL << 31),
+               "lf_bn_bwd_sums: bad dims n=%d c=%d hw=%d", n, c, hw);
+    LF_REQUIRE(plane_g != nullptr || plane_m == nullptr, "lf_bn_bwd_sums: plane_m needs plane_g");
+    LF_REQUIRE(plane_g == nullptr || relu != 0, "lf_bn_bwd_sums: plane sums describe the ReLU-masked case");
+    LF_REQUIRE(plane_g == nullptr || add_nc == nullptr || plane_m != nullptr,
+               "lf_bn_bwd_sums: add_nc with plane sums needs plane_m");
+    if (ws_bytes < lf_bn_workspace(c)) {
+        lf::set_error("lf_bn_bwd_sums: workspace %zu < %zu", ws_bytes, lf_bn_workspace(c));
+        return LF_ERR_WORKSPACE;
+    }
+    hipStream_t s = lf::as_stream(stream);
+    if (plane_g != nullptr) {
+        bn_bwd_planes_kernel<<<c, kBlock, 0, s>>>(plane_g, plane_m, alpha_nc, add_nc, mean, invstd, n, c,
+                                                  dgamma, dbeta);
+    } else {
+        BnBwdArgs a{g, alpha_nc, add_nc, y, mean, invstd, scale, shift, relu, n, c, hw};
+        float* part = static_cast<float*>(workspace);
+        bn_bwd_reduce_kernel<<<dim3(kBnSplit, c), kBlock, 0, s>>>(a, part);
+        bn_bwd_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(part, c, dgamma, dbeta);
+    }
+    bn_bwd_coef_kernel<<<(c + 63) / 64, 64, 0, s>>>(mean, invstd, scale, shift, gamma, dgamma, dbeta,
+                                                   1.0f / ((float)n * (float)hw), c, coef);
+    return lf::check_launch("lf_bn_bwd_sums");
 }
 
 int lf_gap_f32(const float* x, float* out, int planes, int hw, int c, const float* scale,

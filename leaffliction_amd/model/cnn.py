@@ -419,15 +419,16 @@ class LeafCNN:
                           G[p + "se.w1"], G[p + "se.b1"], G[p + "se.w2"], G[p + "se.b2"],
                           dm_scale=1.0 / (h * w))
                 add_nc = dm
-            # conv2 branch: dz2 = (dr*s + dm/HW) * [a2 > 0] -> BN2 backward -> dy2 (gB)
-            nn.bn_bwd(gA, y2, st2, P[p + "bn2.gamma"], G[p + "bn2.gamma"], G[p + "bn2.beta"], True,
-                      alpha_nc=s, add_nc=add_nc, out=gB, plane_g=psum,
-                      plane_m=sv[p + "msum"] if self.use_se else None)
-            nn.conv2d_wgrad(y1, gB, 3, st1[2], st1[3], True, out=G[p + "c2.w"])
+            # conv2 branch: dz2 = (dr*s + dm/HW) * [a2 > 0];
+            # BN2 backward + conv2 weight gradient: dy2 is formed inside the wgrad kernel (-> gB)
+            nn.bn_bwd_wgrad(y1, gA, y2, st2, P[p + "bn2.gamma"], G[p + "bn2.gamma"],
+                            G[p + "bn2.beta"], True, 3, G[p + "c2.w"], gB, st1[2], st1[3], True,
+                            alpha_nc=s, add_nc=add_nc, plane_g=psum,
+                            plane_m=sv[p + "msum"] if self.use_se else None)
             nn.conv2d(gB, self._dgrad_w(p + "c2.w", 3), 3, out=gC)          # da1
-            nn.bn_bwd(gC, y1, st1, P[p + "bn1.gamma"], G[p + "bn1.gamma"], G[p + "bn1.beta"], True,
-                      out=gB)                                                 # dy1
-            nn.conv2d_wgrad(xin, gB, 3, pro[0], pro[1], pro[2], out=G[p + "c1.w"])
+            # BN1 backward + conv1 weight gradient (dy1 -> gB)
+            nn.bn_bwd_wgrad(xin, gC, y1, st1, P[p + "bn1.gamma"], G[p + "bn1.gamma"],
+                            G[p + "bn1.beta"], True, 3, G[p + "c1.w"], gB, pro[0], pro[1], pro[2])
             if cin != f:
                 stp = self.stats[p + "bnp"]
                 nn.bn_bwd(gA, sv[p + "yp"], stp, P[p + "bnp.gamma"], G[p + "bnp.gamma"],

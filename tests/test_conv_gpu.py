@@ -132,3 +132,59 @@ def test_conv_bn_stats_epilogue(cuda, n, cin, cout, h, w, k):
     stats2 = torch.zeros(4, cout, device=cuda)
     nn.bn_train_stats(y, gamma.to(cuda), beta.to(cuda), mm2, mv2, stats2, 0.99, 1e-3)
     assert torch.allclose(stats, stats2, rtol=1e-4, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,with_se", [(3, 32, 32, 32, 32, True),    # fused, CI_T == Cin
+                                                    (2, 64, 64, 32, 32, False),   # two ci blocks
+                                                    (2, 32, 64, 56, 56, True),    # 28-wide tiles
+                                                    (2, 16, 24, 20, 12, True)])   # unsupported -> fallback
+def test_bn_backward_inside_wgrad(cuda, n, cin, cout, h, w, with_se):
+    """BatchNorm backward formed inside the weight-gradient kernel (dy written on the side) vs
+    the standalone BN-backward kernel followed by the plain wgrad, and vs torch autograd."""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(99 + n + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    y = torch.randn(n, cout, h, w, generator=g) * 1.5 + 0.3          # BN input
+    up = torch.randn(n, cout, h, w, generator=g)                      # upstream gradient
+    gamma = torch.rand(cout, generator=g) + 0.5
+    beta = torch.randn(cout, generator=g) * 0.2
+    alpha = torch.rand(n, cout, generator=g) + 0.5 if with_se else None
+    add = torch.randn(n, cout, generator=g) * 0.01 if with_se else None
+    in_sc, in_sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+
+    # torch reference: a = relu(BN(y)); L = sum(a * (up*alpha) ) + sum(a * add) -> dL/dy, then wgrad
+    yr = y.clone().requires_grad_(True)
+    mean = yr.mean((0, 2, 3), keepdim=True)
+    var = yr.var((0, 2, 3), unbiased=False, keepdim=True)
+    a = torch.relu((yr - mean) / torch.sqrt(var + 1e-3) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+    coeff = up * (alpha.view(n, cout, 1, 1) if with_se else 1.0) + (add.view(n, cout, 1, 1) if with_se else 0.0)
+    (a * coeff).sum().backward()
+    dy_ref = yr.grad
+    xp = torch.relu(x * in_sc.view(1, -1, 1, 1) + in_sh.view(1, -1, 1, 1))
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(xp, wr, padding=1).backward(dy_ref)
+    dw_ref = wr.grad.reshape(cout, cin, 9).permute(1, 2, 0)
+
+    d = lambda t: None if t is None else t.to(cuda)  # noqa: E731
+    stats = torch.zeros(4, cout, device=cuda)
+    mm, mv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
+    nn.bn_train_stats(d(y), d(gamma), d(beta), mm, mv, stats, 0.99, 1e-3)
+    outs = []
+    for fused in (True, False):
+        dgamma, dbeta = torch.zeros(cout, device=cuda), torch.zeros(cout, device=cuda)
+        dw = torch.zeros(cin, 9, cout, device=cuda)
+        dy = torch.zeros(n, cout, h, w, device=cuda)
+        if fused:
+            nn.bn_bwd_wgrad(d(x), d(up), d(y), stats, d(gamma), dgamma, dbeta, True, 3, dw, dy,
+                            d(in_sc), d(in_sh), True, alpha_nc=d(alpha), add_nc=d(add))
+        else:
+            nn.bn_bwd(d(up), d(y), stats, d(gamma), dgamma, dbeta, True, alpha_nc=d(alpha),
+                      add_nc=d(add), out=dy)
+            nn.conv2d_wgrad(d(x), dy, 3, d(in_sc), d(in_sh), True, out=dw)
+        outs.append((dy.cpu(), dw.cpu(), dgamma.cpu(), dbeta.cpu()))
+    (dy_f, dw_f, dg_f, db_f), (dy_s, dw_s, dg_s, db_s) = outs
+    close(dy_f, dy_ref, tol=1e-4)
+    close(dy_f, dy_s, tol=2e-5)
+    close(dw_f, dw_ref, tol=5e-4)
+    close(dw_f, dw_s, tol=1e-4)
+    assert torch.allclose(dg_f, dg_s, rtol=1e-5, atol=1e-5) and torch.allclose(db_f, db_s, rtol=1e-5, atol=1e-5)
