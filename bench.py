@@ -63,7 +63,7 @@ class KernelTimer:
         timer = self
 
         def call(name, *args):
-            if not timer.enabled or name not in ("lf_conv2d_f32", "lf_conv2d_stats_f32",
+            if not timer.enabled or name not in ("lf_conv2d_f32", "lf_conv2d_stats_f32", "lf_conv2d_bnbwd_f32",
                                                  "lf_conv2d_wgrad_f32", "lf_conv2d_wgrad_bn_f32"):
                 return timer._orig(name, *args)
             e0 = torch.cuda.Event(enable_timing=True)
@@ -72,7 +72,7 @@ class KernelTimer:
             rc = timer._orig(name, *args)
             e1.record()
             lib = timer.lib_mod.load()
-            if name in ("lf_conv2d_f32", "lf_conv2d_stats_f32"):
+            if name in ("lf_conv2d_f32", "lf_conv2d_stats_f32", "lf_conv2d_bnbwd_f32"):
                 n, cin, h, w, cout, k = args[3:9]
                 kname = FWD_NAMES[lib.lf_conv2d_variant(h, w, cout)].replace("T", str(k * k))
             else:

@@ -190,6 +190,16 @@ int lf_conv2d_stats_f32(const float* x, const float* w, float* y, int n, int cin
                         int in_relu, const float* pivot, float* tile_part, size_t tile_part_bytes,
                         lf_stream_t stream);
 
+/* Input-gradient convolution whose output g feeds a BatchNormalization backward (mask_y = that
+ * BN's input, same shape as y): besides y (= conv, or y += conv with accumulate) the epilogue
+ * leaves per-tile {sum d, sum d*mask_y}, d = y*[mask_y*mask_scale[co]+mask_shift[co] > 0 or
+ * !mask_relu], in tile_part[co][tile][2] for lf_bn_bwd_sums_tiles_f32 — the BN backward's
+ * reduction pass over g and its input disappears. */
+int lf_conv2d_bnbwd_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd,
+                        int cout, int ksize, int accumulate, const float* mask_y,
+                        const float* mask_scale, const float* mask_shift, int mask_relu,
+                        float* tile_part, size_t tile_part_bytes, lf_stream_t stream);
+
 /* w [Cin][k*k][Cout] -> wt [Cout][k*k (flipped)][Cin]: the weights with which
  * lf_conv2d_f32(dy, wt, dx, n, cout, h, w, cin, k, ...) is the input gradient. */
 int lf_conv2d_dgrad_weights_f32(const float* w, float* wt, int cin, int ksize, int cout,
@@ -260,12 +270,13 @@ int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
  * dbeta = sum dz.  plane_g / plane_m (optional, [n][c][2], relu case only): when the producer
  * of g already left per-plane sums {sum g*mask, sum g*mask*y} (lf_block_tail_bwd_f32) and the
  * forward left {sum mask, sum mask*y} (lf_gap_f32; needed with add_nc), the two channel sums
- * come from those and g / y are read once (for dy) instead of twice. */
+ * come from those and g / y are read once (for dy) instead of twice.  have_sums != 0: dgamma /
+ * dbeta already hold the sums (lf_bn_bwd_sums_tiles_f32) and only the apply pass runs. */
 int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* y,
                   const float* mean, const float* invstd, const float* scale, const float* shift,
                   int relu, const float* gamma, float* dy, float* dgamma, float* dbeta,
-                  const float* plane_g, const float* plane_m, int n, int c, int hw, void* workspace,
-                  size_t ws_bytes, lf_stream_t stream);
+                  const float* plane_g, const float* plane_m, int have_sums, int n, int c, int hw,
+                  void* workspace, size_t ws_bytes, lf_stream_t stream);
 
 /* The two channel sums of lf_bn_bwd_f32 without the apply pass: dgamma, dbeta and coef [5][c] =
  * {scale, shift, P, Q, R} such that dy = P*dz + Q*y + R with dz = (g*alpha+add)*[y*scale+shift>0
@@ -276,6 +287,12 @@ int lf_bn_bwd_sums_f32(const float* g, const float* alpha_nc, const float* add_n
                        const float* shift, int relu, const float* gamma, float* dgamma, float* dbeta,
                        float* coef, const float* plane_g, const float* plane_m, int n, int c, int hw,
                        void* workspace, size_t ws_bytes, lf_stream_t stream);
+
+/* lf_bn_bwd_sums_f32 from the tile sums of lf_conv2d_bnbwd_f32 (no alpha/add). */
+int lf_bn_bwd_sums_tiles_f32(const float* tile_part, long long tiles, const float* mean,
+                             const float* invstd, const float* scale, const float* shift,
+                             const float* gamma, float* dgamma, float* dbeta, float* coef, int n,
+                             int c, int hw, void* workspace, size_t ws_bytes, lf_stream_t stream);
 
 /* ---- pooling / broadcast ---- */
 /* out[p] = mean over hw of act(x[p][:]*scale[c]+shift[c]), c = p % C (GlobalAveragePooling2D,

@@ -44,6 +44,8 @@ SIGNATURES = {
     "lf_conv2d_wgrad_variant": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_stats_tiles": [c_int, c_int, c_int, c_int],
     "lf_conv2d_stats_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_size_t, P],
+    "lf_conv2d_bnbwd_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P,
+                            c_size_t, P],
     "lf_conv2d_dgrad_weights_f32": [P, P, c_int, c_int, c_int, P],
     "lf_conv2d_wgrad_workspace": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_wgrad_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,
@@ -60,8 +62,10 @@ SIGNATURES = {
     "lf_bn_train_stats_tiles_f32": [P, C.c_longlong, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P],
     "lf_bn_bwd_sums_f32": [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P,
                            c_size_t, P],
+    "lf_bn_bwd_sums_tiles_f32": [P, C.c_longlong, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P,
+                                 c_size_t, P],
     "lf_bn_infer_scale_shift_f32": [c_int, P, P, P, P, c_float, P, P, P],
-    "lf_bn_bwd_f32": [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P,
+    "lf_bn_bwd_f32": [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P,
                       c_size_t, P],
     "lf_gap_f32": [P, P, c_int, c_int, c_int, P, P, c_int, P, P],
     "lf_bcast_planes_f32": [P, P, c_int, c_int, c_float, P],

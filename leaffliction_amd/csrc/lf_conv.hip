@@ -58,6 +58,13 @@ struct ConvArgs {
     float* stat_part;
     const float* stat_pivot;  // may be null (pivot 0)
     long long stat_tiles;     // n * tiles_x * tiles_y
+    // with stat_mask_y (same shape as y) the epilogue gathers BatchNorm-BACKWARD sums instead:
+    // d = y_out * [stat_mask_y*mask_scale[co]+mask_shift[co] > 0 or !mask_relu];
+    // stat_part gets {sum d, sum d*stat_mask_y}
+    const float* stat_mask_y;
+    const float* mask_scale;
+    const float* mask_shift;
+    int mask_relu;
 };
 
 // sum over the 32 lanes of each wave half (DPP); the total lands in lanes 16-31 / 48-63
@@ -326,46 +333,83 @@ void conv_mfma_kernel(ConvArgs p) {
         }
     }
 
-    // epilogue: D[row = co][col = pixel]; row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: D[row = co][col = pixel]; row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Processed in groups of RG accumulator rows: the group's read-modify-write operands
+    // (accumulate) and BatchNorm-backward mask values are loaded unconditionally from clamped
+    // addresses first, so RG*NB loads are in flight together, then stored / reduced.
+    constexpr int RG = TAPS == 1 ? (NB <= 2 ? 4 : 1) : (NB <= 2 ? 16 : 4);
     float* yout = p.y + (size_t)n * p.cout * hw;
+    const bool stats = p.stat_part != nullptr, masked = p.stat_mask_y != nullptr;
     bool pix_ok[NB];
+    unsigned pixc[NB];  // pixel offset, 0 when outside the image
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int f = (wave_px * NB + nb) * 32 + j;
         const int oy = ty0 + f / TW, ox = tx0 + f % TW;
         pix_ok[nb] = oy < p.h && ox < p.wd;
-        if (!pix_ok[nb]) continue;
-        const size_t pix = (size_t)oy * p.wd + ox;
+        pixc[nb] = pix_ok[nb] ? (unsigned)oy * (unsigned)p.wd + (unsigned)ox : 0u;
+    }
+    float* red = lds;  // [WPX][CT][2] statistics scratch
+    static_assert(WPX * CT * 2 <= PATCH + WSZ, "stat scratch must fit the staging LDS");
+    if (stats) __syncthreads();  // every wave is done with the staging LDS
+    const float* my = masked ? p.stat_mask_y + (size_t)n * p.cout * hw : nullptr;
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int cb = co0 + (wave_co * MB + m) * 32 + 4 * khalf;
+    for (int m = 0; m < MB; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cb + (r & 3) + 8 * (r >> 2);
-                if (co < p.cout) {
-                    float* dst = yout + (size_t)co * hw + pix;
-                    *dst = p.accumulate ? *dst + acc[m][nb][r] : acc[m][nb][r];
+        for (int rg = 0; rg < 16; rg += RG) {
+            float oldv[RG][NB], yv[RG][NB];
+            if (p.accumulate) {
+#pragma unroll
+                for (int rr = 0; rr < RG; ++rr) {
+                    const int r = rg + rr;
+                    const int co = co0 + (wave_co * MB + m) * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2);
+                    const float* src = yout + (size_t)min(co, p.cout - 1) * hw;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) oldv[rr][nb] = src[pixc[nb]];
                 }
             }
-        }
-    }
-    if (p.stat_part != nullptr) {  // uniform: BatchNorm statistics of this output tile
-        __syncthreads();           // every wave is done with the staging LDS
-        float* red = lds;          // [WPX][CT][2]
-        static_assert(WPX * CT * 2 <= PATCH + WSZ, "stat scratch must fit the staging LDS");
+            if (masked) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
+                for (int rr = 0; rr < RG; ++rr) {
+                    const int r = rg + rr;
+                    const int co = co0 + (wave_co * MB + m) * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2);
+                    const float* src = my + (size_t)min(co, p.cout - 1) * hw;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+                    for (int nb = 0; nb < NB; ++nb) yv[rr][nb] = src[pixc[nb]];
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr) {
+                const int r = rg + rr;
                 const int cl = (wave_co * MB + m) * 32 + 4 * khalf + (r & 3) + 8 * (r >> 2);
                 const int co = co0 + cl;
-                const float pv = (p.stat_pivot != nullptr && co < p.cout) ? p.stat_pivot[co] : 0.f;
-                float s1 = 0.f, s2 = 0.f;
+                const bool co_ok = co < p.cout;
+                float* dst = yout + (size_t)co * hw;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const float d = pix_ok[nb] ? acc[m][nb][r] - pv : 0.f;
-                    s1 += d;
-                    s2 = fmaf(d, d, s2);
+                    if (p.accumulate) acc[m][nb][r] += oldv[rr][nb];  // the statistics see the sum
+                    if (co_ok && pix_ok[nb]) dst[pixc[nb]] = acc[m][nb][r];
+                }
+                if (!stats) continue;
+                float s1 = 0.f, s2 = 0.f;
+                if (!masked) {  // forward statistics about the pivot
+                    const float pv = (p.stat_pivot != nullptr && co_ok) ? p.stat_pivot[co] : 0.f;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float d = pix_ok[nb] ? acc[m][nb][r] - pv : 0.f;
+                        s1 += d;
+                        s2 = fmaf(d, d, s2);
+                    }
+                } else {  // backward sums of the BatchNorm this gradient feeds
+                    const float msc = p.mask_scale[min(co, p.cout - 1)], msh = p.mask_shift[min(co, p.cout - 1)];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const bool on = co_ok && pix_ok[nb] &&
+                                        (!p.mask_relu || fmaf(yv[rr][nb], msc, msh) > 0.f);
+                        const float d = on ? acc[m][nb][r] : 0.f;
+                        s1 += d;
+                        s2 = fmaf(d, yv[rr][nb], s2);
+                    }
                 }
                 s1 = half_sum32(s1);
                 s2 = half_sum32(s2);
@@ -375,6 +419,8 @@ void conv_mfma_kernel(ConvArgs p) {
                 }
             }
         }
+    }
+    if (stats) {
         __syncthreads();
         const long long tg = (long long)n * (p.tiles_x * p.tiles_y) + tile;
         for (int c = tid; c < CT; c += kThreads) {
@@ -1311,7 +1357,8 @@ int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout, int ksize) 
 static int conv2d_launch(const char* who, const float* x, const float* w, float* y, int n, int cin,
                          int h, int wd, int cout, int ksize, const float* in_scale,
                          const float* in_shift, int in_relu, int accumulate, float* stat_part,
-                         const float* stat_pivot, lf_stream_t stream) {
+                         const float* stat_pivot, const float* stat_mask_y, const float* mask_scale,
+                         const float* mask_shift, int mask_relu, lf_stream_t stream) {
     LF_REQUIRE(x && w && y, "%s: null buffer", who);
     LF_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && wd > 0,
                "%s: bad dims n=%d cin=%d cout=%d h=%d w=%d", who, n, cin, cout, h, wd);
@@ -1333,6 +1380,8 @@ static int conv2d_launch(const char* who, const float* x, const float* w, float*
     a.vec_ok = (wd % 4 == 0) && (cout % 4 == 0) && aligned16(x) && aligned16(w);
     a.stat_part = stat_part;
     a.stat_pivot = stat_pivot;
+    a.stat_mask_y = stat_mask_y; a.mask_scale = mask_scale; a.mask_shift = mask_shift;
+    a.mask_relu = mask_relu;
     a.stat_tiles = (long long)n * a.tiles_x * a.tiles_y;
     dim3 grid(a.tiles_x * a.tiles_y, (cout + v.ct - 1) / v.ct, n);
     hipStream_t s = lf::as_stream(stream);
@@ -1345,7 +1394,7 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
                   int ksize, const float* in_scale, const float* in_shift, int in_relu,
                   int accumulate, lf_stream_t stream) {
     return conv2d_launch("lf_conv2d", x, w, y, n, cin, h, wd, cout, ksize, in_scale, in_shift, in_relu,
-                         accumulate, nullptr, nullptr, stream);
+                         accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 long long lf_conv2d_stats_tiles(int n, int h, int wd, int cout) {
@@ -1366,7 +1415,23 @@ int lf_conv2d_stats_f32(const float* x, const float* w, float* y, int n, int cin
         return LF_ERR_WORKSPACE;
     }
     return conv2d_launch("lf_conv2d_stats", x, w, y, n, cin, h, wd, cout, ksize, in_scale, in_shift,
-                         in_relu, 0, tile_part, pivot, stream);
+                         in_relu, 0, tile_part, pivot, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int lf_conv2d_bnbwd_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd,
+                        int cout, int ksize, int accumulate, const float* mask_y,
+                        const float* mask_scale, const float* mask_shift, int mask_relu,
+                        float* tile_part, size_t tile_part_bytes, lf_stream_t stream) {
+    LF_REQUIRE(tile_part && mask_y && mask_scale && mask_shift, "lf_conv2d_bnbwd: null buffer");
+    const long long tiles = lf_conv2d_stats_tiles(n, h, wd, cout);
+    if (tile_part_bytes < (size_t)tiles * (size_t)(cout > 0 ? cout : 0) * 2 * sizeof(float)) {
+        lf::set_error("lf_conv2d_bnbwd: tile_part %zu bytes < %lld tiles x %d channels x 8",
+                      tile_part_bytes, tiles, cout);
+        return LF_ERR_WORKSPACE;
+    }
+    return conv2d_launch("lf_conv2d_bnbwd", x, w, y, n, cin, h, wd, cout, ksize, nullptr, nullptr, 0,
+                         accumulate, tile_part, nullptr, mask_y, mask_scale, mask_shift, mask_relu,
+                         stream);
 }
 
 int lf_conv2d_dgrad_weights_f32(const float* w, float* wt, int cin, int ksize, int cout,

@@ -348,6 +348,23 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int c,
     dgamma[ch] = (float)q;
 }
 
+// dbeta = sum d, dgamma = invstd * (sum d*y - mean * sum d) from the kBnSplit partial pairs
+// {sum d, sum d*y} (convolution-epilogue tile sums, lf_conv2d_bnbwd_f32)
+__global__ void bn_bwd_tiles_finalize_kernel(const float* __restrict__ part, int c,
+                                             const float* __restrict__ mean,
+                                             const float* __restrict__ invstd,
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < kBnSplit; ++k) {
+        s += part[((size_t)ch * kBnSplit + k) * 2];
+        q += part[((size_t)ch * kBnSplit + k) * 2 + 1];
+    }
+    dbeta[ch] = (float)s;
+    dgamma[ch] = (float)((q - (double)mean[ch] * s) * (double)invstd[ch]);
+}
+
 // dy = coef2*dz + coef3*y + coef4 with dz masked by y*coef0+coef1 > 0: the apply step as five
 // per-channel coefficients, for consumers that form dy while they read g and y
 __global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -1027,10 +1044,11 @@ int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
 int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* y,
                   const float* mean, const float* invstd, const float* scale, const float* shift,
                   int relu, const float* gamma, float* dy, float* dgamma, float* dbeta,
-                  const float* plane_g, const float* plane_m, int n, int c, int hw, void* workspace,
-                  size_t ws_bytes, lf_stream_t stream) {
+                  const float* plane_g, const float* plane_m, int have_sums, int n, int c, int hw,
+                  void* workspace, size_t ws_bytes, lf_stream_t stream) {
     LF_REQUIRE(g && y && mean && invstd && scale && shift && gamma && dy && dgamma && dbeta && workspace,
                "lf_bn_bwd: null buffer");
+    LF_REQUIRE(!have_sums || plane_g == nullptr, "lf_bn_bwd: have_sums excludes plane sums");
     LF_REQUIRE(plane_g != nullptr || plane_m == nullptr, "lf_bn_bwd: plane_m needs plane_g");
     LF_REQUIRE(plane_g == nullptr || relu != 0, "lf_bn_bwd: plane sums describe the ReLU-masked case");
     LF_REQUIRE(plane_g == nullptr || add_nc == nullptr || plane_m != nullptr,
@@ -1044,7 +1062,9 @@ int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, co
     BnBwdArgs a{g, alpha_nc, add_nc, y, mean, invstd, scale, shift, relu, n, c, hw};
     hipStream_t s = lf::as_stream(stream);
     float* part = static_cast<float*>(workspace);
-    if (plane_g != nullptr) {
+    if (have_sums) {
+        // dgamma / dbeta already hold the two channel sums (lf_bn_bwd_sums*_f32)
+    } else if (plane_g != nullptr) {
         bn_bwd_planes_kernel<<<c, kBlock, 0, s>>>(plane_g, plane_m, alpha_nc, add_nc, mean, invstd, n, c,
                                                   dgamma, dbeta);
     } else {
@@ -1087,6 +1107,28 @@ int lf_bn_bwd_sums_f32(const float* g, const float* alpha_nc, const float* add_n
     bn_bwd_coef_kernel<<<(c + 63) / 64, 64, 0, s>>>(mean, invstd, scale, shift, gamma, dgamma, dbeta,
                                                    1.0f / ((float)n * (float)hw), c, coef);
     return lf::check_launch("lf_bn_bwd_sums");
+}
+
+int lf_bn_bwd_sums_tiles_f32(const float* tile_part, long long tiles, const float* mean,
+                             const float* invstd, const float* scale, const float* shift,
+                             const float* gamma, float* dgamma, float* dbeta, float* coef, int n,
+                             int c, int hw, void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(tile_part && mean && invstd && scale && shift && gamma && dgamma && dbeta && coef &&
+                   workspace,
+               "lf_bn_bwd_sums_tiles: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && hw > 0 && c <= 65535 && tiles > 0,
+               "lf_bn_bwd_sums_tiles: bad dims n=%d c=%d hw=%d tiles=%lld", n, c, hw, tiles);
+    if (ws_bytes < lf_bn_workspace(c)) {
+        lf::set_error("lf_bn_bwd_sums_tiles: workspace %zu < %zu", ws_bytes, lf_bn_workspace(c));
+        return LF_ERR_WORKSPACE;
+    }
+    hipStream_t s = lf::as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    bn_tile_reduce_kernel<<<dim3(kBnSplit, c), kBlock, 0, s>>>(tile_part, tiles, part);
+    bn_bwd_tiles_finalize_kernel<<<(c + 63) / 64, 64, 0, s>>>(part, c, mean, invstd, dgamma, dbeta);
+    bn_bwd_coef_kernel<<<(c + 63) / 64, 64, 0, s>>>(mean, invstd, scale, shift, gamma, dgamma, dbeta,
+                                                   1.0f / ((float)n * (float)hw), c, coef);
+    return lf::check_launch("lf_bn_bwd_sums_tiles");
 }
 
 int lf_gap_f32(const float* x, float* out, int planes, int hw, int c, const float* scale,

@@ -425,10 +425,12 @@ class LeafCNN:
                             G[p + "bn2.beta"], True, 3, G[p + "c2.w"], gB, st1[2], st1[3], True,
                             alpha_nc=s, add_nc=add_nc, plane_g=psum,
                             plane_m=sv[p + "msum"] if self.use_se else None)
-            nn.conv2d(gB, self._dgrad_w(p + "c2.w", 3), 3, out=gC)          # da1
+            # da1 (-> gC); its epilogue leaves BN1's backward sums
+            _, tsum = nn.conv2d_bnbwd(gB, self._dgrad_w(p + "c2.w", 3), 3, y1, st1, True, gC)
             # BN1 backward + conv1 weight gradient (dy1 -> gB)
             nn.bn_bwd_wgrad(xin, gC, y1, st1, P[p + "bn1.gamma"], G[p + "bn1.gamma"],
-                            G[p + "bn1.beta"], True, 3, G[p + "c1.w"], gB, pro[0], pro[1], pro[2])
+                            G[p + "bn1.beta"], True, 3, G[p + "c1.w"], gB, pro[0], pro[1], pro[2],
+                            tile_sums=tsum)
             if cin != f:
                 stp = self.stats[p + "bnp"]
                 nn.bn_bwd(gA, sv[p + "yp"], stp, P[p + "bnp.gamma"], G[p + "bnp.gamma"],
@@ -438,12 +440,17 @@ class LeafCNN:
                 nn.conv2d(gC, self._dgrad_w(p + "proj.w", 1), 1, out=dx)
             else:
                 dx = gA  # identity shortcut: dx starts as dr
-            nn.conv2d(gB, self._dgrad_w(p + "c1.w", 3), 3, out=dx, accumulate=True)
+            stem_sums = None
+            if i == 0:  # dx feeds the stem's BN backward: gather its sums in this epilogue
+                _, stem_sums = nn.conv2d_bnbwd(gB, self._dgrad_w(p + "c1.w", 3), 3, sv["stem.y"],
+                                               self.stats["stem.bn"], True, dx, accumulate=True)
+            else:
+                nn.conv2d(gB, self._dgrad_w(p + "c1.w", 3), 3, out=dx, accumulate=True)
             dp = dx
         # stem: dp is the gradient wrt relu(BN(stem.y))
         gS = self._buf(n, "stem.g", sv["stem.y"].shape)
         nn.bn_bwd(dp, sv["stem.y"], self.stats["stem.bn"], P["stem.bn.gamma"], G["stem.bn.gamma"],
-                  G["stem.bn.beta"], True, out=gS)
+                  G["stem.bn.beta"], True, out=gS, tile_sums=stem_sums)
         nn.conv2d_wgrad(sv["x0"], gS, 3, out=G["stem.w"])
 
     def _dgrad_w(self, name: str, k: int) -> torch.Tensor:

@@ -107,6 +107,30 @@ def conv2d_bn_stats(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, gamma, bet
     return out
 
 
+def conv2d_bnbwd(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, mask_y: torch.Tensor,
+                 stats: torch.Tensor, relu: bool, out: torch.Tensor, accumulate: bool = False):
+    """Input-gradient convolution out (+)= conv(x, w) whose result feeds the backward of the
+    BatchNormalization with input mask_y / statistics `stats`: the epilogue also leaves the
+    per-tile sums of that BN backward.  Returns (out, tile_sums) — pass tile_sums to
+    bn_bwd_wgrad."""
+    _chk(x, _F32, "conv2d_bnbwd.x", 4)
+    _chk(w_iko, _F32, "conv2d_bnbwd.w", 3)
+    _chk(mask_y, _F32, "conv2d_bnbwd.mask_y", 4)
+    _chk(out, _F32, "conv2d_bnbwd.out", 4)
+    n, cin, h, w = x.shape
+    if w_iko.shape[0] != cin or w_iko.shape[1] != ksize * ksize:
+        raise ValueError(f"conv2d_bnbwd.w: expected [{cin},{ksize * ksize},Cout]")
+    cout = w_iko.shape[2]
+    if tuple(out.shape) != (n, cout, h, w) or mask_y.shape != out.shape or tuple(stats.shape) != (4, cout):
+        raise ValueError("conv2d_bnbwd: shape mismatch")
+    tiles = _lib.load().lf_conv2d_stats_tiles(n, h, w, cout)
+    tp = _workspace(tiles * cout * 8, x.device, slot=1)
+    _lib.call("lf_conv2d_bnbwd_f32", x.data_ptr(), w_iko.data_ptr(), out.data_ptr(), n, cin, h, w,
+              cout, ksize, 1 if accumulate else 0, mask_y.data_ptr(), stats[2].data_ptr(),
+              stats[3].data_ptr(), 1 if relu else 0, tp.data_ptr(), tp.numel(), _stream())
+    return out, (tp, tiles)
+
+
 def conv2d_dgrad_weights(w_iko: torch.Tensor, ksize: int) -> torch.Tensor:
     """[Cin,k*k,Cout] -> [Cout,k*k(flipped),Cin]: conv2d(dy, wt) is the input gradient."""
     _chk(w_iko, _F32, "dgrad_weights.w", 3)
@@ -149,7 +173,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, in_scale=None, i
 def bn_bwd_wgrad(x: torch.Tensor, g: torch.Tensor, y_bn: torch.Tensor, stats: torch.Tensor, gamma,
                  dgamma, dbeta, relu: bool, ksize: int, dw_out: torch.Tensor, dy_out: torch.Tensor,
                  in_scale=None, in_shift=None, in_relu: bool = False, alpha_nc=None, add_nc=None,
-                 plane_g=None, plane_m=None) -> torch.Tensor:
+                 plane_g=None, plane_m=None, tile_sums=None) -> torch.Tensor:
     """BatchNormalization backward of g (BN input y_bn) followed by the weight gradient of the
     convolution that produced y_bn from x:  dy = BN'(g) is formed inside the wgrad kernel from
     g and y_bn (and written to dy_out for the input-gradient convolution); dgamma / dbeta /
@@ -169,7 +193,7 @@ def bn_bwd_wgrad(x: torch.Tensor, g: torch.Tensor, y_bn: torch.Tensor, stats: to
     lib = _lib.load()
     if _NO_FUSED_BN_WGRAD or not lib.lf_conv2d_wgrad_bn_supported(n, cin, h, w, cout, ksize):
         bn_bwd(g, y_bn, stats, gamma, dgamma, dbeta, relu, alpha_nc=alpha_nc, add_nc=add_nc,
-               out=dy_out, plane_g=plane_g, plane_m=plane_m)
+               out=dy_out, plane_g=plane_g, plane_m=plane_m, tile_sums=tile_sums)
         conv2d_wgrad(x, dy_out, ksize, in_scale, in_shift, in_relu, out=dw_out)
         return dy_out
     for t in (plane_g, plane_m):
@@ -180,11 +204,20 @@ def bn_bwd_wgrad(x: torch.Tensor, g: torch.Tensor, y_bn: torch.Tensor, stats: to
             raise ValueError("bn_bwd_wgrad: alpha/add must be [N,C]")
     coef = _workspace(5 * cout * 4, x.device, slot=2)
     ws = _workspace(lib.lf_bn_workspace(cout), x.device)
-    _lib.call("lf_bn_bwd_sums_f32", g.data_ptr(), _ptr(alpha_nc), _ptr(add_nc), y_bn.data_ptr(),
-              stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-              1 if relu else 0, gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-              coef.data_ptr(), _ptr(plane_g), _ptr(plane_m), n, cout, h * w, ws.data_ptr(),
-              ws.numel(), _stream())
+    if tile_sums is not None:
+        if alpha_nc is not None or add_nc is not None or plane_g is not None:
+            raise ValueError("bn_bwd_wgrad: tile_sums excludes alpha/add/plane sums")
+        tp, tiles = tile_sums
+        _lib.call("lf_bn_bwd_sums_tiles_f32", tp.data_ptr(), tiles, stats[0].data_ptr(),
+                  stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), gamma.data_ptr(),
+                  dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), n, cout, h * w,
+                  ws.data_ptr(), ws.numel(), _stream())
+    else:
+        _lib.call("lf_bn_bwd_sums_f32", g.data_ptr(), _ptr(alpha_nc), _ptr(add_nc), y_bn.data_ptr(),
+                  stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                  1 if relu else 0, gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                  coef.data_ptr(), _ptr(plane_g), _ptr(plane_m), n, cout, h * w, ws.data_ptr(),
+                  ws.numel(), _stream())
     ws = _workspace(lib.lf_conv2d_wgrad_workspace(n, cin, h, w, cout, ksize), x.device)
     _lib.call("lf_conv2d_wgrad_bn_f32", x.data_ptr(), g.data_ptr(), y_bn.data_ptr(), _ptr(alpha_nc),
               _ptr(add_nc), coef.data_ptr(), 1 if relu else 0, dy_out.data_ptr(), n, cin, h, w, cout,
@@ -260,10 +293,10 @@ def bn_infer_scale_shift(gamma, beta, mmean, mvar, stats, eps=1e-3):
 
 
 def bn_bwd(g, y, stats, gamma, dgamma, dbeta, relu: bool, alpha_nc=None, add_nc=None, out=None,
-           plane_g=None, plane_m=None):
+           plane_g=None, plane_m=None, tile_sums=None):
     """BatchNorm backward; the ReLU mask (relu=True) is recomputed from y and stats[2:4].
     plane_g ([N,C,2] from block_tail_bwd) / plane_m ([N,C,2] from gap) replace the reduction
-    pass over g and y."""
+    pass over g and y; so do tile_sums (from conv2d_bnbwd, which produced g)."""
     _chk(g, _F32, "bn_bwd.g", 4)
     _chk(y, _F32, "bn_bwd.y", 4)
     if g.shape != y.shape:
@@ -282,11 +315,22 @@ def bn_bwd(g, y, stats, gamma, dgamma, dbeta, relu: bool, alpha_nc=None, add_nc=
     if out is None:
         out = torch.empty_like(y)
     ws = _workspace(_lib.load().lf_bn_workspace(c), y.device)
+    have = 0
+    if tile_sums is not None:
+        if alpha_nc is not None or add_nc is not None or plane_g is not None:
+            raise ValueError("bn_bwd: tile_sums excludes alpha/add/plane sums")
+        tp, tiles = tile_sums
+        coef = _workspace(5 * c * 4, y.device, slot=2)
+        _lib.call("lf_bn_bwd_sums_tiles_f32", tp.data_ptr(), tiles, stats[0].data_ptr(),
+                  stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), gamma.data_ptr(),
+                  dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), n, c, h * w, ws.data_ptr(),
+                  ws.numel(), _stream())
+        have = 1
     _lib.call("lf_bn_bwd_f32", g.data_ptr(), _ptr(alpha_nc), _ptr(add_nc), y.data_ptr(),
               stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
               1 if relu else 0, gamma.data_ptr(), out.data_ptr(), dgamma.data_ptr(),
-              dbeta.data_ptr(), _ptr(plane_g), _ptr(plane_m), n, c, h * w, ws.data_ptr(), ws.numel(),
-              _stream())
+              dbeta.data_ptr(), _ptr(plane_g), _ptr(plane_m), have, n, c, h * w, ws.data_ptr(),
+              ws.numel(), _stream())
     return out
 
 

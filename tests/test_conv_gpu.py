@@ -188,3 +188,38 @@ def test_bn_backward_inside_wgrad(cuda, n, cin, cout, h, w, with_se):
     close(dw_f, dw_ref, tol=5e-4)
     close(dw_f, dw_s, tol=1e-4)
     assert torch.allclose(dg_f, dg_s, rtol=1e-5, atol=1e-5) and torch.allclose(db_f, db_s, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,acc", [(2, 32, 32, 64, 64, 3, False),
+                                                  (2, 64, 32, 32, 32, 3, True),
+                                                  (1, 256, 128, 28, 28, 3, False),   # masked 28-wide tiles
+                                                  (2, 16, 24, 20, 12, 3, True),      # ragged / scalar path
+                                                  (2, 5, 7, 9, 11, 3, False)])
+def test_conv_bn_backward_sums_epilogue(cuda, n, cin, cout, h, w, k, acc):
+    """Input-gradient conv whose epilogue gathers the next BN backward's channel sums: same
+    output as the plain conv, and dgamma / dbeta / dy equal to the two-pass BN backward."""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(5 + n + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g).to(cuda)
+    wt = (torch.randn(cin, k * k, cout, generator=g) / (cin * k * k) ** 0.5).to(cuda)
+    y_bn = (torch.randn(n, cout, h, w, generator=g) * 1.3 + 0.2).to(cuda)
+    base = torch.randn(n, cout, h, w, generator=g).to(cuda)
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(cuda)
+    beta = (torch.randn(cout, generator=g) * 0.2).to(cuda)
+    stats = torch.zeros(4, cout, device=cuda)
+    nn.bn_train_stats(y_bn, gamma, beta, torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda),
+                      stats, 0.99, 1e-3)
+    out_a = base.clone() if acc else torch.empty_like(base)
+    nn.conv2d(x, wt, k, out=out_a, accumulate=acc)
+    out_b = base.clone() if acc else torch.empty_like(base)
+    _, tsum = nn.conv2d_bnbwd(x, wt, k, y_bn, stats, True, out_b, accumulate=acc)
+    assert torch.equal(out_a, out_b)
+    res = []
+    for ts in (None, tsum):
+        dgamma, dbeta = torch.zeros(cout, device=cuda), torch.zeros(cout, device=cuda)
+        dy = nn.bn_bwd(out_a, y_bn, stats, gamma, dgamma, dbeta, True, tile_sums=ts)
+        res.append((dy.cpu(), dgamma.cpu(), dbeta.cpu()))
+    scale = max(res[0][1].abs().max().item(), res[0][2].abs().max().item())
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 2e-5 * scale
+    assert (res[0][2] - res[1][2]).abs().max().item() <= 2e-5 * scale
+    close(res[1][0], res[0][0], tol=2e-5)
