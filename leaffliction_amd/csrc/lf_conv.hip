@@ -33,6 +33,12 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
+// development-only ablations for timing studies (never set in the shipped build):
+// 1 = no epilogue stores, 2 = every workgroup reads image 0 (cache-resident input),
+// 4 = no LDS staging writes (MFMAs run on stale LDS)
+#ifndef LF_ABLATE
+#define LF_ABLATE 0
+#endif
 #ifndef LF_KC_SMALL
 #define LF_KC_SMALL 8
 #endif
@@ -123,7 +129,7 @@ void conv_mfma_kernel(ConvArgs p) {
     const int n = blockIdx.z;
     const size_t hw = (size_t)p.h * p.wd;
     const unsigned uhw = (unsigned)hw;
-    const float* xin = p.x + (size_t)n * p.cin * hw;
+    const float* xin = p.x + ((LF_ABLATE & 2) ? (size_t)0 : (size_t)n * p.cin * hw);
 
     // per-lane LDS read bases
     const int khalf = lane >> 5, j = lane & 31;
@@ -250,10 +256,12 @@ void conv_mfma_kernel(ConvArgs p) {
                         v.w = pro_apply(v.w, sc, sh, p.in_relu);
                     }
                     float* dst = lp + kc * PP + py * PW + HALO + 4 * slot;
-                    dst[0] = v.x;
-                    dst[1] = v.y;
-                    dst[2] = v.z;
-                    dst[3] = v.w;
+                    if (!(LF_ABLATE & 4) || v.x == 123.456f) {
+                        dst[0] = v.x;
+                        dst[1] = v.y;
+                        dst[2] = v.z;
+                        dst[3] = v.w;
+                    }
                 }
             }
 #pragma unroll
@@ -265,13 +273,13 @@ void conv_mfma_kernel(ConvArgs p) {
                     float v = ph[i];
                     if (pro && (okmask >> (16 + i) & 1u))
                         v = pro_apply(v, pro_sc(c0 + kc), pro_sh(c0 + kc), p.in_relu);
-                    lp[kc * PP + py * PW + (side ? PW - 1 : 0)] = v;
+                    if (!(LF_ABLATE & 4) || v == 123.456f) lp[kc * PP + py * PW + (side ? PW - 1 : 0)] = v;
                 }
             }
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 const int e = tid + i * kThreads;
-                if (e < NWI) reinterpret_cast<float4*>(lw)[e] = wv[i];  // lw[row*CT + col]
+                if (e < NWI && (!(LF_ABLATE & 4) || wv[i].x == 123.456f)) reinterpret_cast<float4*>(lw)[e] = wv[i];  // lw[row*CT + col]
             }
         };
         load_patch(0);
@@ -388,7 +396,8 @@ void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     if (p.accumulate) acc[m][nb][r] += oldv[rr][nb];  // the statistics see the sum
-                    if (co_ok && pix_ok[nb]) dst[pixc[nb]] = acc[m][nb][r];
+                    if (co_ok && pix_ok[nb] && (!(LF_ABLATE & 1) || acc[m][nb][r] == 123.456f))
+                        dst[pixc[nb]] = acc[m][nb][r];
                 }
                 if (!stats) continue;
                 float s1 = 0.f, s2 = 0.f;
