@@ -35,7 +35,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kThreads = 256;
 // development-only ablations for timing studies (never set in the shipped build):
 // 1 = no epilogue stores, 2 = every workgroup reads image 0 (cache-resident input),
-// 4 = no LDS staging writes (MFMAs run on stale LDS)
+// 4 = no LDS staging writes (MFMAs run on stale LDS); wgrad3: 8 = no staging at all after the
+// first item, 16 = no per-item barrier
 #ifndef LF_ABLATE
 #define LF_ABLATE 0
 #endif
@@ -793,6 +794,15 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
 // (32*WCI ci) x (32*WCO co) weight block; wave (q, tr, k) accumulates the three taps of filter
 // row tr (48 accumulators) over its K-split share of each tile's rows.  With so few
 // accumulators the next item's tiles are prefetched into registers during the MFMAs.
+// floats of (dynamic) LDS: two staging buffers (X patch + dY tile each), or the K-split scratch
+template <int TW, int TH, int WCI, int WCO, int KSPL>
+constexpr int wgrad3_lds_floats() {
+    const int pp = ((TW + 2) * (TH + 2)) | 1, dp = (TW * TH) | 1;
+    const int buf = 32 * WCI * pp + 32 * WCO * dp;
+    const int red = KSPL > 1 ? 3 * 3 * 1024 : 0;
+    return 2 * buf > red ? 2 * buf : red;
+}
+
 template <int TW, int TH, int WCI, int WCO, int KSPL>
 __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(WgradArgs p) {
     constexpr int NT = 64 * 3 * WCI * WCO * KSPL;
@@ -802,16 +812,14 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
     constexpr int DP = (TW * TH) | 1;
     constexpr int CI_T = 32 * WCI, CO_T = 32 * WCO, NQ = WCI * WCO;
     constexpr int XSZ = CI_T * PP, DSZ = CO_T * DP;
-    constexpr int RED = KSPL > 1 ? 3 * 3 * 1024 : 0;  // one (ci,co) block's three row-waves
-    constexpr int LDSF = XSZ + DSZ > RED ? XSZ + DSZ : RED;
+    constexpr int BUF = XSZ + DSZ;  // one staging buffer; the kernel double-buffers
+    static_assert(wgrad3_lds_floats<TW, TH, WCI, WCO, KSPL>() >= 2 * BUF, "LDS sizing");
     constexpr int TW4 = TW / 4;
     constexpr int NXI = CI_T * PH * TW4, XPT = (NXI + NT - 1) / NT;      // interior float4 items
     constexpr int NHI = CI_T * PH * 2 * 1, HPT = (NHI + NT - 1) / NT;  // halo scalars
     constexpr int NDI = CO_T * TH * TW4, DPT = (NDI + NT - 1) / NT;
     constexpr int kMaxProC = 512;
-    __shared__ float lds[LDSF];
-    float* lx = lds;
-    float* ld = lds + XSZ;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tr = wid % 3, rest = wid / 3;
@@ -831,13 +839,18 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
     const int bbase = (w_co * 32 + j) * DP + khalf;
     const bool pro = p.in_scale != nullptr;
 
-    auto compute_item = [&]() {
+    // one half (part 0 / 1) of an item's pixel pairs from staging buffer `buf`
+    auto compute_part = [&](int part, int buf) {
         constexpr int ROWS = TH / KSPL;
+        constexpr int HALF = (TW / 4) * 2;  // even split point of the row
+        const float* lx = lds + buf * BUF;
+        const float* ld = lx + XSZ;
+        const int x0 = part ? HALF : 0, x1 = part ? TW : HALF;
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
             const int row = w_k * ROWS + rr;
 #pragma unroll 4
-            for (int xx = 0; xx < TW; xx += 2) {
+            for (int xx = x0; xx < x1; xx += 2) {
                 const float b = ld[bbase + row * TW + xx];
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
@@ -950,7 +963,9 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                 }
             }
         };
-        auto store_item = [&](int item) {
+        auto store_item = [&](int item, int buf) {
+            float* lx = lds + buf * BUF;
+            float* ld = lx + XSZ;
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
                 const int e = tid + i * NT;
@@ -1013,15 +1028,30 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                 }
             }
         };
-        if (first < last) load_item(first);
+        // double-buffered staging, one barrier per item: while an item's MFMAs run from one
+        // buffer the next item (loaded an iteration earlier) is written into the other, and
+        // the loads of the item after that are issued
+        int cur = 0;
+        if (first < last) {
+            load_item(first);
+            __syncthreads();  // lsc / lbn are staged
+            store_item(first, 0);
+            if (first + 1 < last) load_item(first + 1);
+        }
+        __syncthreads();
         for (int item = first; item < last; ++item) {
-            __syncthreads();
-            store_item(item);
-            __syncthreads();
-            if (item + 1 < last) load_item(item + 1);  // in flight during the MFMAs
-            compute_item();
+            compute_part(0, cur);
+            if (!(LF_ABLATE & 8) && item + 1 < last) {
+                store_item(item + 1, cur ^ 1);
+                if (item + 2 < last) load_item(item + 2);
+            }
+            compute_part(1, cur);
+            if (!(LF_ABLATE & 16)) __syncthreads();
+            cur ^= 1;
         }
     } else {
+        float* lx = lds;
+        float* ld = lds + XSZ;
         // scalar staging for ragged shapes
         for (int item = first; item < last; ++item) {
             const int n = item / tiles, t = item - n * tiles;
@@ -1050,7 +1080,8 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                 ld[c * DP + rem] = v;
             }
             __syncthreads();
-            compute_item();
+            compute_part(0, 0);
+            compute_part(1, 0);
         }
     }
 
@@ -1270,14 +1301,31 @@ constexpr WgVariant kWgVariants[] = {{32, 4, 32, 32, 4}, {16, 8, 32, 64, 2}, {16
                                      {28, 2, 64, 64, 1}, {32, 4, 32, 64, 2}};
 constexpr int kWgSmallCin = 5;  // variant id of wgrad_smallcin_kernel<32, 8>
 
+// wgrad3 uses more than the 64 KB of LDS a kernel gets by default: raise the limit once
+template <int TW, int TH, int WCI, int WCO, int KSPL>
+int launch_wgrad3(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    constexpr size_t bytes = (size_t)wgrad3_lds_floats<TW, TH, WCI, WCO, KSPL>() * sizeof(float);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<TW, TH, WCI, WCO, KSPL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            lf::set_error("lf_conv2d_wgrad: cannot reserve %zu bytes of LDS", bytes);
+            return LF_ERR_LAUNCH;
+        }
+        raised = true;
+    }
+    wgrad3_kernel<TW, TH, WCI, WCO, KSPL><<<grid, 64 * 3 * WCI * WCO * KSPL, bytes, s>>>(a);
+    return LF_OK;
+}
+
 int launch_wgrad(int ksize, int variant, const WgradArgs& a, dim3 grid, hipStream_t s) {
     if (ksize == 3) {
         switch (variant) {
-            case 0: wgrad3_kernel<32, 4, 1, 1, 4><<<grid, 768, 0, s>>>(a); break;
-            case 1: wgrad3_kernel<16, 8, 1, 2, 2><<<grid, 768, 0, s>>>(a); break;
-            case 2: wgrad3_kernel<16, 4, 2, 2, 1><<<grid, 768, 0, s>>>(a); break;
-            case 3: wgrad3_kernel<28, 2, 2, 2, 1><<<grid, 768, 0, s>>>(a); break;
-            case 4: wgrad3_kernel<32, 4, 1, 2, 2><<<grid, 768, 0, s>>>(a); break;
+            case 0: return launch_wgrad3<32, 4, 1, 1, 4>(a, grid, s);
+            case 1: return launch_wgrad3<16, 8, 1, 2, 2>(a, grid, s);
+            case 2: return launch_wgrad3<16, 4, 2, 2, 1>(a, grid, s);
+            case 3: return launch_wgrad3<28, 2, 2, 2, 1>(a, grid, s);
+            case 4: return launch_wgrad3<32, 4, 1, 2, 2>(a, grid, s);
             default: return LF_ERR_INVALID;
         }
     } else {
