@@ -839,27 +839,28 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
     const int bbase = (w_co * 32 + j) * DP + khalf;
     const bool pro = p.in_scale != nullptr;
 
-    // one half (part 0 / 1) of an item's pixel pairs from staging buffer `buf`
-    auto compute_part = [&](int part, int buf) {
-        constexpr int ROWS = TH / KSPL;
-        constexpr int HALF = (TW / 4) * 2;  // even split point of the row
+    // quarter q (0..3) of an item's pixel pairs from staging buffer `buf`
+    constexpr int ROWS = TH / KSPL, NK = ROWS * (TW / 2);
+    auto compute_quarter = [&](auto qc, int buf) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int K0 = NK * Q / 4, K1 = NK * (Q + 1) / 4;
         const float* lx = lds + buf * BUF;
         const float* ld = lx + XSZ;
-        const int x0 = part ? HALF : 0, x1 = part ? TW : HALF;
 #pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) {
-            const int row = w_k * ROWS + rr;
-#pragma unroll 4
-            for (int xx = x0; xx < x1; xx += 2) {
-                const float b = ld[bbase + row * TW + xx];
+        for (int kk = K0; kk < K1; ++kk) {
+            const int row = w_k * ROWS + kk / (TW / 2), xx = 2 * (kk % (TW / 2));
+            const float b = ld[bbase + row * TW + xx];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float a = lx[abase + row * PW + xx + dx];
-                    acc[dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[dx], 0, 0, 0);
-                }
+            for (int dx = 0; dx < 3; ++dx) {
+                const float a = lx[abase + row * PW + xx + dx];
+                acc[dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[dx], 0, 0, 0);
             }
         }
     };
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
+    using Q3 = std::integral_constant<int, 3>;
 
     const int first = blockIdx.x * p.items_per_split;
     const int last = min(first + p.items_per_split, p.items);
@@ -870,14 +871,6 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
         float xh[HPT], dal[DPT], dad[DPT];
         unsigned xok = 0, dok = 0;
         const bool bn = p.bn_y != nullptr;
-        // BatchNorm-backward coefficients of this workgroup's CO_T channels
-        __shared__ float lbn[5 * CO_T];
-        if (bn) {
-            for (int e = tid; e < 5 * CO_T; e += NT) {
-                const int kk = e / CO_T, gc = co0 + (e - kk * CO_T);
-                lbn[e] = gc < p.cout ? p.bn_coef[(size_t)kk * p.cout + gc] : 0.f;
-            }
-        }
         // producer BatchNorm scale/shift of this workgroup's CI_T channels, staged once in LDS
         __shared__ float lsc[kMaxProC / 2];
         if (pro) {
@@ -887,92 +880,111 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                 lsc[kMaxProC / 4 + c] = gc < p.cin ? p.in_shift[gc] : 0.f;
             }
         }
+        // BatchNorm-backward coefficients of this workgroup's CO_T channels
+        __shared__ float lbn[5 * CO_T];
+        if (bn) {
+            for (int e = tid; e < 5 * CO_T; e += NT) {
+                const int kk = e / CO_T, gc = co0 + (e - kk * CO_T);
+                lbn[e] = gc < p.cout ? p.bn_coef[(size_t)kk * p.cout + gc] : 0.f;
+            }
+        }
+        // Per-thread staging invariants, decoded once: an item only moves the tile origin.
+        //   *_g: element offset from the tile origin (image n, row ty0, column tx0) inside the
+        //        image's [C][H][W] block;  *_l: LDS float index | (patch row << 16) | (valid << 31)
+        int xg[XPT], hg[HPT], dg[DPT];
+        unsigned xl[XPT], hl[HPT], dl[DPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int e = tid + i * NT;
+            const int c = e / (PH * TW4), rem = e - c * (PH * TW4);
+            const int py = rem / TW4, slot = rem - py * TW4;
+            const bool ok = e < NXI && ci0 + c < p.cin;
+            xg[i] = ok ? c * (int)uhw + (py - 1) * p.wd + 4 * slot : 0;
+            xl[i] = (unsigned)(c * PP + py * PW + 1 + 4 * slot) | ((unsigned)py << 16) | (ok ? 1u << 31 : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < HPT; ++i) {
+            const int e = tid + i * NT;
+            const int c = e / (PH * 2), rem = e - c * (PH * 2);
+            const int py = rem >> 1, side = rem & 1;
+            const bool ok = e < NHI && ci0 + c < p.cin;
+            hg[i] = ok ? c * (int)uhw + (py - 1) * p.wd + (side ? TW : -1) : 0;
+            hl[i] = (unsigned)(c * PP + py * PW + (side ? PW - 1 : 0)) | ((unsigned)py << 16) |
+                    ((unsigned)side << 30) | (ok ? 1u << 31 : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) {
+            const int e = tid + i * NT;
+            const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+            const int py = rem / TW4, slot = rem - py * TW4;
+            const bool ok = e < NDI && co0 + c < p.cout;
+            dg[i] = ok ? c * (int)uhw + py * p.wd + 4 * slot : 0;
+            dl[i] = (unsigned)(c * DP + rem * 4) | ((unsigned)py << 16) | (ok ? 1u << 31 : 0u);
+        }
+        // Loads are unconditional: an element outside the image reads the tile origin instead
+        // (always mapped) and is zeroed when it is stored.
         auto load_item = [&](int item) {
             const int n = item / tiles, t = item - n * tiles;
             const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
-            const float* xin = p.x + (size_t)n * p.cin * hw;
-            const float* din = p.dy + (size_t)n * p.cout * hw;
+            const size_t torg = (size_t)ty0 * p.wd + tx0;
+            const size_t nl = (LF_ABLATE & 2) ? 0 : (size_t)n;
+            const float* xin = p.x + (nl * p.cin + ci0) * hw + torg;
+            const float* din = p.dy + (nl * p.cout + co0) * hw + torg;
             xok = 0;
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
-                const int e = tid + i * NT;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int c = e / (PH * TW4), rem = e - c * (PH * TW4);
-                const int py = rem / TW4, slot = rem - py * TW4;
-                const int gc = ci0 + c, gy = ty0 + py - 1;
-                if (e < NXI && gc < p.cin && gy >= 0 && gy < p.h) {
-                    v = *reinterpret_cast<const float4*>(xin + (unsigned)gc * uhw +
-                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
-                    xok |= 1u << i;
-                }
-                xv[i] = v;
+                const int gy = ty0 + (int)((xl[i] >> 16) & 0xffu) - 1;
+                const bool ok = (xl[i] >> 31) && gy >= 0 && gy < p.h;
+                xv[i] = *reinterpret_cast<const float4*>(xin + (ok ? xg[i] : 0));
+                xok |= (ok ? 1u : 0u) << i;
             }
 #pragma unroll
             for (int i = 0; i < HPT; ++i) {
-                const int e = tid + i * NT;
-                float v = 0.f;
-                const int c = e / (PH * 2), rem = e - c * (PH * 2);
-                const int py = rem >> 1, side = rem & 1;
-                const int gc = ci0 + c, gy = ty0 + py - 1, gx = side ? tx0 + TW : tx0 - 1;
-                if (e < NHI && gc < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd) {
-                    v = xin[(unsigned)gc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx];
-                    xok |= 1u << (16 + i);
-                }
-                xh[i] = v;
+                const int gy = ty0 + (int)((hl[i] >> 16) & 0xffu) - 1;
+                const bool side = (hl[i] >> 30) & 1u;
+                const bool ok = (hl[i] >> 31) && gy >= 0 && gy < p.h && (side ? tx0 + TW < p.wd : tx0 > 0);
+                xh[i] = xin[ok ? hg[i] : 0];
+                xok |= (ok ? 1u : 0u) << (16 + i);
             }
+            dok = 0;
 #pragma unroll
             for (int i = 0; i < DPT; ++i) {
-                const int e = tid + i * NT;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
-                const int py = rem / TW4, slot = rem - py * TW4;
-                const int gc = co0 + c, gy = ty0 + py;
-                if (e < NDI && gc < p.cout && gy < p.h)
-                    v = *reinterpret_cast<const float4*>(din + (unsigned)gc * uhw +
-                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
-                dv[i] = v;
+                const int gy = ty0 + (int)((dl[i] >> 16) & 0xffu);
+                const bool ok = (dl[i] >> 31) && gy < p.h;
+                dv[i] = *reinterpret_cast<const float4*>(din + (ok ? dg[i] : 0));
+                dok |= (ok ? 1u : 0u) << i;
             }
             if (bn) {
-                const float* yin = p.bn_y + (size_t)n * p.cout * hw;
-                dok = 0;
+                const float* yin = p.bn_y + ((size_t)n * p.cout + co0) * hw + torg;
 #pragma unroll
-                for (int i = 0; i < DPT; ++i) {
-                    const int e = tid + i * NT;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
-                    const int py = rem / TW4, slot = rem - py * TW4;
-                    const int gc = co0 + c, gy = ty0 + py;
-                    if (e < NDI && gc < p.cout && gy < p.h) {
-                        v = *reinterpret_cast<const float4*>(yin + (unsigned)gc * uhw +
-                                                             (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
-                        dok |= 1u << i;
-                    }
-                    yv[i] = v;
-                }
+                for (int i = 0; i < DPT; ++i)
+                    yv[i] = *reinterpret_cast<const float4*>(yin + ((dok >> i & 1u) ? dg[i] : 0));
+                if (p.bn_alpha != nullptr) {
 #pragma unroll
-                for (int i = 0; i < DPT; ++i) {
-                    const int e = tid + i * NT;
-                    const int gc = co0 + e / (TH * TW4);
-                    float al = 1.f, ad = 0.f;
-                    if (p.bn_alpha != nullptr && e < NDI && gc < p.cout) {
-                        al = p.bn_alpha[(size_t)n * p.cout + gc];
-                        ad = p.bn_add != nullptr ? p.bn_add[(size_t)n * p.cout + gc] : 0.f;
+                    for (int i = 0; i < DPT; ++i) {
+                        const int e = tid + i * NT;
+                        const int gc = min(co0 + e / (TH * TW4), p.cout - 1);
+                        dal[i] = p.bn_alpha[(size_t)n * p.cout + gc];
+                        dad[i] = p.bn_add != nullptr ? p.bn_add[(size_t)n * p.cout + gc] : 0.f;
                     }
-                    dal[i] = al;
-                    dad[i] = ad;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < DPT; ++i) {
+                        dal[i] = 1.f;
+                        dad[i] = 0.f;
+                    }
                 }
             }
         };
         auto store_item = [&](int item, int buf) {
             float* lx = lds + buf * BUF;
             float* ld = lx + XSZ;
+            constexpr float4 kZero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
-                const int e = tid + i * NT;
-                if (e < NXI) {
-                    const int c = e / (PH * TW4), rem = e - c * (PH * TW4);
-                    const int py = rem / TW4, slot = rem - py * TW4;
-                    float4 v = xv[i];
+                if (tid + i * NT < NXI) {
+                    const int c = (tid + i * NT) / (PH * TW4);
+                    float4 v = (xok >> i & 1u) ? xv[i] : kZero4;
                     if (pro && (xok >> i & 1u)) {
                         const float sc = lsc[c], sh = lsc[kMaxProC / 4 + c];
                         v.x = pro_apply(v.x, sc, sh, p.in_relu);
@@ -980,33 +992,33 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                         v.z = pro_apply(v.z, sc, sh, p.in_relu);
                         v.w = pro_apply(v.w, sc, sh, p.in_relu);
                     }
-                    float* dst = lx + c * PP + py * PW + 1 + 4 * slot;
-                    dst[0] = v.x;
-                    dst[1] = v.y;
-                    dst[2] = v.z;
-                    dst[3] = v.w;
+                    float* dst = lx + (xl[i] & 0xffffu);
+                    if (!(LF_ABLATE & 32) || v.x == 123.456f) {
+                        dst[0] = v.x;
+                        dst[1] = v.y;
+                        dst[2] = v.z;
+                        dst[3] = v.w;
+                    }
                 }
             }
 #pragma unroll
             for (int i = 0; i < HPT; ++i) {
-                const int e = tid + i * NT;
-                if (e < NHI) {
-                    const int c = e / (PH * 2), rem = e - c * (PH * 2);
-                    const int py = rem >> 1, side = rem & 1;
-                    float v = xh[i];
+                if (tid + i * NT < NHI) {
+                    const int c = (tid + i * NT) / (PH * 2);
+                    float v = (xok >> (16 + i) & 1u) ? xh[i] : 0.f;
                     if (pro && (xok >> (16 + i) & 1u))
                         v = pro_apply(v, lsc[c], lsc[kMaxProC / 4 + c], p.in_relu);
-                    lx[c * PP + py * PW + (side ? PW - 1 : 0)] = v;
+                    if (!(LF_ABLATE & 32) || v == 123.456f) lx[hl[i] & 0xffffu] = v;
                 }
             }
             const int sn = item / tiles, st = item - sn * tiles;
             const int stx0 = (st % p.tiles_x) * TW, sty0 = (st / p.tiles_x) * TH;
+            float* dyo = bn ? p.dy_out + ((size_t)sn * p.cout + co0) * hw + (size_t)sty0 * p.wd + stx0 : nullptr;
 #pragma unroll
             for (int i = 0; i < DPT; ++i) {
-                const int e = tid + i * NT;
-                if (e < NDI) {
-                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
-                    float4 v = dv[i];
+                if (tid + i * NT < NDI) {
+                    const int c = (tid + i * NT) / (TH * TW4);
+                    float4 v = (dok >> i & 1u) ? dv[i] : kZero4;
                     if (bn && (dok >> i & 1u)) {
                         const float c0 = lbn[c], c1 = lbn[CO_T + c], c2 = lbn[2 * CO_T + c],
                                     c3 = lbn[3 * CO_T + c], c4 = lbn[4 * CO_T + c];
@@ -1014,17 +1026,16 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                         v.y = bn_dy1(v.y, yv[i].y, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
                         v.z = bn_dy1(v.z, yv[i].z, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
                         v.w = bn_dy1(v.w, yv[i].w, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
-                        if (blockIdx.y == 0) {
-                            const int py = rem / TW4, slot = rem - py * TW4;
-                            *reinterpret_cast<float4*>(p.dy_out + ((size_t)sn * p.cout + co0 + c) * hw +
-                                                       (size_t)(sty0 + py) * p.wd + stx0 + 4 * slot) = v;
-                        }
+                        if (blockIdx.y == 0)
+                            *reinterpret_cast<float4*>(dyo + dg[i]) = v;
                     }
-                    float* dst = ld + c * DP + rem * 4;
-                    dst[0] = v.x;
-                    dst[1] = v.y;
-                    dst[2] = v.z;
-                    dst[3] = v.w;
+                    float* dst = ld + (dl[i] & 0xffffu);
+                    if (!(LF_ABLATE & 32) || v.x == 123.456f) {
+                        dst[0] = v.x;
+                        dst[1] = v.y;
+                        dst[2] = v.z;
+                        dst[3] = v.w;
+                    }
                 }
             }
         };
@@ -1032,20 +1043,32 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
         // buffer the next item (loaded an iteration earlier) is written into the other, and
         // the loads of the item after that are issued
         int cur = 0;
-        if (first < last) {
-            load_item(first);
+        const int count = last - first;
+        auto nth = [&](int idx) { return first + idx; };
+        if (count > 0) {
+            load_item(nth(0));
             __syncthreads();  // lsc / lbn are staged
-            store_item(first, 0);
-            if (first + 1 < last) load_item(first + 1);
+            store_item(nth(0), 0);
+            if (count > 1) load_item(nth(1));
         }
         __syncthreads();
-        for (int item = first; item < last; ++item) {
-            compute_part(0, cur);
-            if (!(LF_ABLATE & 8) && item + 1 < last) {
-                store_item(item + 1, cur ^ 1);
-                if (item + 2 < last) load_item(item + 2);
-            }
-            compute_part(1, cur);
+        // The waves sharing a SIMD (wid, wid+4, wid+8) move through their MFMAs in lock step,
+        // so each stages after a different quarter: while one writes LDS the other two keep
+        // the MFMA pipe busy.
+        const int stage_q = (wid >> 2) % 3;
+        for (int idx = 0; idx < count; ++idx) {
+            const bool more = !(LF_ABLATE & 8) && idx + 1 < count;
+            auto stage = [&]() {
+                store_item(nth(idx + 1), cur ^ 1);
+                if (!(LF_ABLATE & 64) && idx + 2 < count) load_item(nth(idx + 2));
+            };
+            compute_quarter(Q0{}, cur);
+            if (more && stage_q == 0) stage();
+            compute_quarter(Q1{}, cur);
+            if (more && stage_q == 1) stage();
+            compute_quarter(Q2{}, cur);
+            if (more && stage_q == 2) stage();
+            compute_quarter(Q3{}, cur);
             if (!(LF_ABLATE & 16)) __syncthreads();
             cur ^= 1;
         }
@@ -1080,8 +1103,10 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                 ld[c * DP + rem] = v;
             }
             __syncthreads();
-            compute_part(0, 0);
-            compute_part(1, 0);
+            compute_quarter(Q0{}, 0);
+            compute_quarter(Q1{}, 0);
+            compute_quarter(Q2{}, 0);
+            compute_quarter(Q3{}, 0);
         }
     }
 
