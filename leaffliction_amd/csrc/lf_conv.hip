@@ -49,6 +49,22 @@ __device__ __forceinline__ float pro_apply(float v, float sc, float sh, int relu
     return relu ? fmaxf(v, 0.f) : v;
 }
 
+// Raw buffer loads: SGPR resource (base, byte size) + a 32-bit byte offset per lane; an offset
+// at or beyond the size returns 0, which is how zero padding is fetched (no branches, no
+// 64-bit address arithmetic per lane).
+typedef float lf_f4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kBufOob = 0xffffffffu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const lf_f4 v = __builtin_bit_cast(lf_f4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
 struct ConvArgs {
     const float* x;
     const float* w;  // [Cin][TAPS][Cout]
@@ -889,9 +905,11 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             }
         }
         // Per-thread staging invariants, decoded once: an item only moves the tile origin.
-        //   *_g: element offset from the tile origin (image n, row ty0, column tx0) inside the
-        //        image's [C][H][W] block;  *_l: LDS float index | (patch row << 16) | (valid << 31)
-        int xg[XPT], hg[HPT], dg[DPT];
+        //   *_g: BYTE offset of the element from the patch origin (image n, channel block, row
+        //        ty0-1, column tx0-1 for X; row ty0, column tx0 for dY), kBufOob when the
+        //        thread's slot / channel does not exist;
+        //   *_l: LDS float index | (patch row << 16)
+        unsigned xg[XPT], hg[HPT], dg[DPT];
         unsigned xl[XPT], hl[HPT], dl[DPT];
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
@@ -899,8 +917,8 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             const int c = e / (PH * TW4), rem = e - c * (PH * TW4);
             const int py = rem / TW4, slot = rem - py * TW4;
             const bool ok = e < NXI && ci0 + c < p.cin;
-            xg[i] = ok ? c * (int)uhw + (py - 1) * p.wd + 4 * slot : 0;
-            xl[i] = (unsigned)(c * PP + py * PW + 1 + 4 * slot) | ((unsigned)py << 16) | (ok ? 1u << 31 : 0u);
+            xg[i] = ok ? 4u * ((unsigned)c * uhw + (unsigned)py * (unsigned)p.wd + 1u + 4u * (unsigned)slot) : kBufOob;
+            xl[i] = (unsigned)(c * PP + py * PW + 1 + 4 * slot) | ((unsigned)py << 16);
         }
 #pragma unroll
         for (int i = 0; i < HPT; ++i) {
@@ -908,9 +926,9 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             const int c = e / (PH * 2), rem = e - c * (PH * 2);
             const int py = rem >> 1, side = rem & 1;
             const bool ok = e < NHI && ci0 + c < p.cin;
-            hg[i] = ok ? c * (int)uhw + (py - 1) * p.wd + (side ? TW : -1) : 0;
+            hg[i] = ok ? 4u * ((unsigned)c * uhw + (unsigned)py * (unsigned)p.wd + (side ? TW + 1u : 0u)) : kBufOob;
             hl[i] = (unsigned)(c * PP + py * PW + (side ? PW - 1 : 0)) | ((unsigned)py << 16) |
-                    ((unsigned)side << 30) | (ok ? 1u << 31 : 0u);
+                    ((unsigned)side << 30);
         }
 #pragma unroll
         for (int i = 0; i < DPT; ++i) {
@@ -918,47 +936,50 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
             const int py = rem / TW4, slot = rem - py * TW4;
             const bool ok = e < NDI && co0 + c < p.cout;
-            dg[i] = ok ? c * (int)uhw + py * p.wd + 4 * slot : 0;
-            dl[i] = (unsigned)(c * DP + rem * 4) | ((unsigned)py << 16) | (ok ? 1u << 31 : 0u);
+            dg[i] = ok ? 4u * ((unsigned)c * uhw + (unsigned)py * (unsigned)p.wd + 4u * (unsigned)slot) : kBufOob;
+            dl[i] = (unsigned)(c * DP + rem * 4) | ((unsigned)py << 16);
         }
-        // Loads are unconditional: an element outside the image reads the tile origin instead
-        // (always mapped) and is zeroed when it is stored.
+        const unsigned xbytes = 4u * ((unsigned)min(CI_T, p.cin - ci0) * uhw + (unsigned)p.wd + 1u);
+        const unsigned dbytes = 4u * (unsigned)min(CO_T, p.cout - co0) * uhw;
         auto load_item = [&](int item) {
             const int n = item / tiles, t = item - n * tiles;
             const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
             const size_t torg = (size_t)ty0 * p.wd + tx0;
             const size_t nl = (LF_ABLATE & 2) ? 0 : (size_t)n;
-            const float* xin = p.x + (nl * p.cin + ci0) * hw + torg;
-            const float* din = p.dy + (nl * p.cout + co0) * hw + torg;
+            // patch origin = one row up, one column left of the tile (never dereferenced there:
+            // rows / columns outside the image get the out-of-range offset)
+            const __amdgpu_buffer_rsrc_t rx =
+                buf_rsrc(p.x + (nl * p.cin + ci0) * hw + torg - (size_t)p.wd - 1, xbytes);
+            const __amdgpu_buffer_rsrc_t rd = buf_rsrc(p.dy + (nl * p.cout + co0) * hw + torg, dbytes);
             xok = 0;
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
-                const int gy = ty0 + (int)((xl[i] >> 16) & 0xffu) - 1;
-                const bool ok = (xl[i] >> 31) && gy >= 0 && gy < p.h;
-                xv[i] = *reinterpret_cast<const float4*>(xin + (ok ? xg[i] : 0));
+                const unsigned gy = (unsigned)(ty0 + (int)((xl[i] >> 16) & 0xffu) - 1);
+                const bool ok = xg[i] != kBufOob && gy < (unsigned)p.h;
+                xv[i] = buf_load4(rx, ok ? xg[i] : kBufOob);
                 xok |= (ok ? 1u : 0u) << i;
             }
 #pragma unroll
             for (int i = 0; i < HPT; ++i) {
-                const int gy = ty0 + (int)((hl[i] >> 16) & 0xffu) - 1;
+                const unsigned gy = (unsigned)(ty0 + (int)((hl[i] >> 16) & 0xffu) - 1);
                 const bool side = (hl[i] >> 30) & 1u;
-                const bool ok = (hl[i] >> 31) && gy >= 0 && gy < p.h && (side ? tx0 + TW < p.wd : tx0 > 0);
-                xh[i] = xin[ok ? hg[i] : 0];
+                const bool ok = hg[i] != kBufOob && gy < (unsigned)p.h && (side ? tx0 + TW < p.wd : tx0 > 0);
+                xh[i] = buf_load1(rx, ok ? hg[i] : kBufOob);
                 xok |= (ok ? 1u : 0u) << (16 + i);
             }
             dok = 0;
 #pragma unroll
             for (int i = 0; i < DPT; ++i) {
-                const int gy = ty0 + (int)((dl[i] >> 16) & 0xffu);
-                const bool ok = (dl[i] >> 31) && gy < p.h;
-                dv[i] = *reinterpret_cast<const float4*>(din + (ok ? dg[i] : 0));
+                const unsigned gy = (unsigned)(ty0 + (int)((dl[i] >> 16) & 0xffu));
+                const bool ok = dg[i] != kBufOob && gy < (unsigned)p.h;
+                dv[i] = buf_load4(rd, ok ? dg[i] : kBufOob);
                 dok |= (ok ? 1u : 0u) << i;
             }
             if (bn) {
-                const float* yin = p.bn_y + ((size_t)n * p.cout + co0) * hw + torg;
+                const __amdgpu_buffer_rsrc_t ry =
+                    buf_rsrc(p.bn_y + ((size_t)n * p.cout + co0) * hw + torg, dbytes);
 #pragma unroll
-                for (int i = 0; i < DPT; ++i)
-                    yv[i] = *reinterpret_cast<const float4*>(yin + ((dok >> i & 1u) ? dg[i] : 0));
+                for (int i = 0; i < DPT; ++i) yv[i] = buf_load4(ry, (dok >> i & 1u) ? dg[i] : kBufOob);
                 if (p.bn_alpha != nullptr) {
 #pragma unroll
                     for (int i = 0; i < DPT; ++i) {
@@ -979,12 +1000,11 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
         auto store_item = [&](int item, int buf) {
             float* lx = lds + buf * BUF;
             float* ld = lx + XSZ;
-            constexpr float4 kZero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
                 if (tid + i * NT < NXI) {
                     const int c = (tid + i * NT) / (PH * TW4);
-                    float4 v = (xok >> i & 1u) ? xv[i] : kZero4;
+                    float4 v = xv[i];  // padding was fetched as zeros
                     if (pro && (xok >> i & 1u)) {
                         const float sc = lsc[c], sh = lsc[kMaxProC / 4 + c];
                         v.x = pro_apply(v.x, sc, sh, p.in_relu);
@@ -1005,7 +1025,7 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             for (int i = 0; i < HPT; ++i) {
                 if (tid + i * NT < NHI) {
                     const int c = (tid + i * NT) / (PH * 2);
-                    float v = (xok >> (16 + i) & 1u) ? xh[i] : 0.f;
+                    float v = xh[i];
                     if (pro && (xok >> (16 + i) & 1u))
                         v = pro_apply(v, lsc[c], lsc[kMaxProC / 4 + c], p.in_relu);
                     if (!(LF_ABLATE & 32) || v == 123.456f) lx[hl[i] & 0xffffu] = v;
@@ -1018,7 +1038,7 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             for (int i = 0; i < DPT; ++i) {
                 if (tid + i * NT < NDI) {
                     const int c = (tid + i * NT) / (TH * TW4);
-                    float4 v = (dok >> i & 1u) ? dv[i] : kZero4;
+                    float4 v = dv[i];
                     if (bn && (dok >> i & 1u)) {
                         const float c0 = lbn[c], c1 = lbn[CO_T + c], c2 = lbn[2 * CO_T + c],
                                     c3 = lbn[3 * CO_T + c], c4 = lbn[4 * CO_T + c];
@@ -1027,7 +1047,7 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                         v.z = bn_dy1(v.z, yv[i].z, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
                         v.w = bn_dy1(v.w, yv[i].w, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
                         if (blockIdx.y == 0)
-                            *reinterpret_cast<float4*>(dyo + dg[i]) = v;
+                            *reinterpret_cast<float4*>(dyo + (dg[i] >> 2)) = v;
                     }
                     float* dst = ld + (dl[i] & 0xffffu);
                     if (!(LF_ABLATE & 32) || v.x == 123.456f) {
