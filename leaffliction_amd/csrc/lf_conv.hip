@@ -211,48 +211,56 @@ void conv_mfma_kernel(ConvArgs p) {
                 lsc[kMaxProC + c] = p.in_shift[c];
             }
         }
+        // Per-thread staging invariants (the workgroup has one tile; a chunk only moves the
+        // channel base): byte offsets from the chunk's first channel plane / weight row with
+        // kBufOob for everything that must read as zero (rows and columns outside the image,
+        // slots beyond the item count, cout columns beyond the tensor); LDS index | kc << 16.
+        // Channels / weight rows beyond Cin fall outside the chunk's buffer size -> zeros.
+        unsigned pg[IPT], pl[IPT];
+        unsigned hg[HPT > 0 ? HPT : 1], hl[HPT > 0 ? HPT : 1];
+        unsigned wg[WPT];
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int e = tid + i * kThreads;
+            const int kc = e / (PH * TW4), rem = e - kc * (PH * TW4);
+            const int py = rem / TW4, slot = rem - py * TW4;
+            const int gy = ty0 + py - HALO;
+            const bool ok = e < NVI && gy >= 0 && gy < p.h;
+            pg[i] = ok ? 4u * ((unsigned)kc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)(tx0 + 4 * slot)) : kBufOob;
+            pl[i] = (unsigned)(kc * PP + py * PW + HALO + 4 * slot) | ((unsigned)kc << 16);
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < HPT; ++i) {
+            const int e = tid + i * kThreads;
+            const int kc = e / (PH * 2), rem = e - kc * (PH * 2);
+            const int py = rem >> 1, side = rem & 1;
+            const int gy = ty0 + py - HALO, gx = side ? tx0 + TW : tx0 - 1;
+            const bool ok = e < NHI && gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd;
+            hg[i] = ok ? 4u * ((unsigned)kc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx) : kBufOob;
+            hl[i] = (unsigned)(kc * PP + py * PW + (side ? PW - 1 : 0)) | ((unsigned)kc << 16);
+            okmask |= (ok ? 1u : 0u) << (16 + i);
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + i * kThreads;
+            const int row = e / CT4, col = (e - row * CT4) * 4;
+            wg[i] = (e < NWI && co0 + col < p.cout) ? 4u * ((unsigned)row * (unsigned)p.cout + (unsigned)(co0 + col)) : kBufOob;
+        }
         auto load_patch = [&](int c0) {
-            okmask = 0;
+            const __amdgpu_buffer_rsrc_t rx =
+                buf_rsrc(xin + (size_t)c0 * hw, 4u * (unsigned)min(kKC, p.cin - c0) * uhw);
 #pragma unroll
-            for (int i = 0; i < IPT; ++i) {
-                const int e = tid + i * kThreads;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int kc = e / (PH * TW4), rem = e - kc * (PH * TW4);
-                const int py = rem / TW4, slot = rem - py * TW4;
-                const int c = c0 + kc, gy = ty0 + py - HALO;
-                if (e < NVI && c < p.cin && gy >= 0 && gy < p.h) {
-                    v = *reinterpret_cast<const float4*>(xin + (unsigned)c * uhw +
-                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
-                    okmask |= 1u << i;
-                }
-                pv[i] = v;
-            }
+            for (int i = 0; i < IPT; ++i) pv[i] = buf_load4(rx, pg[i]);
 #pragma unroll
-            for (int i = 0; i < HPT; ++i) {
-                const int e = tid + i * kThreads;
-                float v = 0.f;
-                const int kc = e / (PH * 2), rem = e - kc * (PH * 2);
-                const int py = rem >> 1, side = rem & 1;
-                const int c = c0 + kc, gy = ty0 + py - HALO, gx = side ? tx0 + TW : tx0 - 1;
-                if (e < NHI && c < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd) {
-                    v = xin[(unsigned)c * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx];
-                    okmask |= 1u << (16 + i);
-                }
-                ph[i] = v;
-            }
+            for (int i = 0; i < HPT; ++i) ph[i] = buf_load1(rx, hg[i]);
         };
         auto load_weights = [&](int c0) {
-            const int wvalid = (p.cin - c0) * TAPS;
+            const __amdgpu_buffer_rsrc_t rw =
+                buf_rsrc(p.w + (size_t)c0 * TAPS * p.cout,
+                         4u * (unsigned)(min(kKC, p.cin - c0) * TAPS) * (unsigned)p.cout);
 #pragma unroll
-            for (int i = 0; i < WPT; ++i) {
-                const int e = tid + i * kThreads;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int row = e / CT4, col = (e - row * CT4) * 4;
-                if (e < NWI && row < wvalid && co0 + col < p.cout)
-                    v = *reinterpret_cast<const float4*>(
-                        p.w + ((unsigned)c0 * TAPS + row) * (unsigned)p.cout + (unsigned)(co0 + col));
-                wv[i] = v;
-            }
+            for (int i = 0; i < WPT; ++i) wv[i] = buf_load4(rw, wg[i]);
         };
         auto pro_sc = [&](int c) { return c < kMaxProC ? lsc[c] : p.in_scale[c]; };
         auto pro_sh = [&](int c) { return c < kMaxProC ? lsc[kMaxProC + c] : p.in_shift[c]; };
@@ -260,10 +268,8 @@ void conv_mfma_kernel(ConvArgs p) {
             if (!kPrefetchW) load_weights(c0);
 #pragma unroll
             for (int i = 0; i < IPT; ++i) {
-                const int e = tid + i * kThreads;
-                if (e < NVI) {
-                    const int kc = e / (PH * TW4), rem = e - kc * (PH * TW4);
-                    const int py = rem / TW4, slot = rem - py * TW4;
+                if (tid + i * kThreads < NVI) {
+                    const int kc = (int)(pl[i] >> 16);
                     float4 v = pv[i];
                     if (pro && (okmask >> i & 1u)) {
                         const float sc = pro_sc(c0 + kc), sh = pro_sh(c0 + kc);
@@ -272,7 +278,7 @@ void conv_mfma_kernel(ConvArgs p) {
                         v.z = pro_apply(v.z, sc, sh, p.in_relu);
                         v.w = pro_apply(v.w, sc, sh, p.in_relu);
                     }
-                    float* dst = lp + kc * PP + py * PW + HALO + 4 * slot;
+                    float* dst = lp + (pl[i] & 0xffffu);
                     if (!(LF_ABLATE & 4) || v.x == 123.456f) {
                         dst[0] = v.x;
                         dst[1] = v.y;
@@ -283,14 +289,12 @@ void conv_mfma_kernel(ConvArgs p) {
             }
 #pragma unroll
             for (int i = 0; i < HPT; ++i) {
-                const int e = tid + i * kThreads;
-                if (e < NHI) {
-                    const int kc = e / (PH * 2), rem = e - kc * (PH * 2);
-                    const int py = rem >> 1, side = rem & 1;
+                if (tid + i * kThreads < NHI) {
+                    const int kc = (int)(hl[i] >> 16);
                     float v = ph[i];
                     if (pro && (okmask >> (16 + i) & 1u))
                         v = pro_apply(v, pro_sc(c0 + kc), pro_sh(c0 + kc), p.in_relu);
-                    if (!(LF_ABLATE & 4) || v == 123.456f) lp[kc * PP + py * PW + (side ? PW - 1 : 0)] = v;
+                    if (!(LF_ABLATE & 4) || v == 123.456f) lp[hl[i] & 0xffffu] = v;
                 }
             }
 #pragma unroll
