@@ -218,8 +218,8 @@ int lf_conv2d_wgrad_reduce_f32(void* workspace, float* dw, int n, int cin, int h
                                int cout, int ksize, float beta, lf_stream_t stream);
 /* Weight gradient whose dY operand is a BatchNormalization backward, formed on the fly:
  * dY = coef2*dz + coef3*bn_y + coef4, dz = (g*alpha_nc+add_nc)*[bn_y*coef0+coef1 > 0 or !bn_relu]
- * (coef from lf_bn_bwd_sums_f32), also written to dy_out [n][cout][h][w] for the input-gradient
- * convolution that follows.  3x3, shapes for which lf_conv2d_wgrad_bn_supported() != 0; same
+ * (coef from lf_bn_bwd_sums_f32), also written to dy_out [n][cout][h][w] (may be null: the stem
+ * has no input gradient) for the input-gradient convolution that follows.  3x3 (the small-Cin stem kernel included), shapes for which lf_conv2d_wgrad_bn_supported() != 0; same
  * workspace and reduce step as lf_conv2d_wgrad_f32. */
 int lf_conv2d_wgrad_bn_supported(int n, int cin, int h, int w, int cout, int ksize);
 int lf_conv2d_wgrad_bn_f32(const float* x, const float* g, const float* bn_y,

@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                         v.y = bn_dy1(v.y, yv[i].y, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
                         v.z = bn_dy1(v.z, yv[i].z, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
                         v.w = bn_dy1(v.w, yv[i].w, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
-                        if (blockIdx.y == 0)
+                        if (blockIdx.y == 0 && p.dy_out != nullptr)
                             *reinterpret_cast<float4*>(dyo + (dg[i] >> 2)) = v;
                     }
                     float* dst = ld + (dl[i] & 0xffffu);
@@ -1201,6 +1201,14 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad_smallcin_kernel(WgradArgs p
     const int last = min(first + p.items_per_split, p.items);
     const int tiles = p.tiles_x * p.tiles_y;
     const bool pro = p.in_scale != nullptr;
+    const bool bn = p.bn_y != nullptr;  // dY = BatchNorm backward of p.dy, formed while staging
+    __shared__ float lbn[5 * 32];
+    if (bn) {
+        for (int e = tid; e < 5 * 32; e += kThreads) {
+            const int kk = e / 32, gc = co0 + (e - kk * 32);
+            lbn[e] = gc < p.cout ? p.bn_coef[(size_t)kk * p.cout + gc] : 0.f;
+        }
+    }
     constexpr int ROWS = TH / 4;
     for (int item = first; item < last; ++item) {
         const int n = item / tiles, t = item - n * tiles;
@@ -1227,9 +1235,24 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad_smallcin_kernel(WgradArgs p
                 const int py = rem / TW4, slot = rem - py * TW4;
                 const int gc = co0 + c, gy = ty0 + py;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gc < p.cout && gy < p.h)
-                    v = *reinterpret_cast<const float4*>(din + (unsigned)gc * uhw +
-                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                if (gc < p.cout && gy < p.h) {
+                    const size_t off = (size_t)gc * uhw + (size_t)gy * p.wd + tx0 + 4 * slot;
+                    v = *reinterpret_cast<const float4*>(din + off);
+                    if (bn) {
+                        const float4 yv = *reinterpret_cast<const float4*>(
+                            p.bn_y + (size_t)n * p.cout * hw + off);
+                        const float al = p.bn_alpha ? p.bn_alpha[(size_t)n * p.cout + gc] : 1.f;
+                        const float ad = p.bn_add ? p.bn_add[(size_t)n * p.cout + gc] : 0.f;
+                        const float c0 = lbn[c], c1 = lbn[32 + c], c2 = lbn[64 + c], c3 = lbn[96 + c],
+                                    c4 = lbn[128 + c];
+                        v.x = bn_dy1(v.x, yv.x, al, ad, c0, c1, c2, c3, c4, p.bn_relu);
+                        v.y = bn_dy1(v.y, yv.y, al, ad, c0, c1, c2, c3, c4, p.bn_relu);
+                        v.z = bn_dy1(v.z, yv.z, al, ad, c0, c1, c2, c3, c4, p.bn_relu);
+                        v.w = bn_dy1(v.w, yv.w, al, ad, c0, c1, c2, c3, c4, p.bn_relu);
+                        if (blockIdx.y == 0 && p.dy_out != nullptr)
+                            *reinterpret_cast<float4*>(p.dy_out + (size_t)n * p.cout * hw + off) = v;
+                    }
+                }
                 float* dst = ld + c * DP + rem * 4;
                 dst[0] = v.x;
                 dst[1] = v.y;
@@ -1588,10 +1611,10 @@ static int wgrad_launch(const char* who, const float* x, const float* dy, int n,
     a.bn_y = bn_y; a.bn_alpha = bn_alpha; a.bn_add = bn_add; a.bn_coef = bn_coef;
     a.dy_out = dy_out; a.bn_relu = bn_relu;
     if (bn_y != nullptr) {
-        LF_REQUIRE(bn_coef && dy_out, "%s: bn_coef / dy_out missing", who);
+        LF_REQUIRE(bn_coef, "%s: bn_coef missing", who);
         LF_REQUIRE(bn_add == nullptr || bn_alpha != nullptr, "%s: bn_add needs bn_alpha", who);
         LF_REQUIRE(lf_conv2d_wgrad_bn_supported(n, cin, h, wd, cout, ksize) && a.vec_ok &&
-                       aligned16(bn_y) && aligned16(dy_out),
+                       aligned16(bn_y) && (dy_out == nullptr || aligned16(dy_out)),
                    "%s: shape/alignment not supported by the fused BatchNorm-backward path "
                    "(ask lf_conv2d_wgrad_bn_supported first)", who);
     }
@@ -1617,7 +1640,7 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, 
 int lf_conv2d_wgrad_bn_supported(int n, int cin, int h, int wd, int cout, int ksize) {
     if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || wd <= 0 || ksize != 3) return 0;
     const WgPlan pl = plan_wgrad(n, cin, cout, h, wd, ksize);
-    return pl.variant != kWgSmallCin && (wd % pl.tw == 0) && (wd % 4 == 0);
+    return (wd % pl.tw == 0) && (wd % 4 == 0);
 }
 
 int lf_conv2d_wgrad_bn_f32(const float* x, const float* g, const float* bn_y,

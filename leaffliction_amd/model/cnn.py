@@ -448,10 +448,10 @@ class LeafCNN:
                 nn.conv2d(gB, self._dgrad_w(p + "c1.w", 3), 3, out=dx, accumulate=True)
             dp = dx
         # stem: dp is the gradient wrt relu(BN(stem.y))
-        gS = self._buf(n, "stem.g", sv["stem.y"].shape)
-        nn.bn_bwd(dp, sv["stem.y"], self.stats["stem.bn"], P["stem.bn.gamma"], G["stem.bn.gamma"],
-                  G["stem.bn.beta"], True, out=gS, tile_sums=stem_sums)
-        nn.conv2d_wgrad(sv["x0"], gS, 3, out=G["stem.w"])
+        # the stem has no input gradient: its BN backward exists only inside the wgrad kernel
+        nn.bn_bwd_wgrad(sv["x0"], dp, sv["stem.y"], self.stats["stem.bn"], P["stem.bn.gamma"],
+                        G["stem.bn.gamma"], G["stem.bn.beta"], True, 3, G["stem.w"], None,
+                        tile_sums=stem_sums)
 
     def _dgrad_w(self, name: str, k: int) -> torch.Tensor:
         return nn.conv2d_dgrad_weights(self.p[name], k)

@@ -176,25 +176,27 @@ def bn_bwd_wgrad(x: torch.Tensor, g: torch.Tensor, y_bn: torch.Tensor, stats: to
                  plane_g=None, plane_m=None, tile_sums=None) -> torch.Tensor:
     """BatchNormalization backward of g (BN input y_bn) followed by the weight gradient of the
     convolution that produced y_bn from x:  dy = BN'(g) is formed inside the wgrad kernel from
-    g and y_bn (and written to dy_out for the input-gradient convolution); dgamma / dbeta /
+    g and y_bn (and written to dy_out, when given, for the input-gradient convolution); dgamma / dbeta /
     dw_out are filled.  Falls back to the two-kernel route for shapes the fused kernel does not
     take (same results up to rounding)."""
     _chk(x, _F32, "bn_bwd_wgrad.x", 4)
     _chk(g, _F32, "bn_bwd_wgrad.g", 4)
     _chk(y_bn, _F32, "bn_bwd_wgrad.y", 4)
-    _chk(dy_out, _F32, "bn_bwd_wgrad.dy_out", 4)
+    if dy_out is not None:
+        _chk(dy_out, _F32, "bn_bwd_wgrad.dy_out", 4)
     _chk(dw_out, _F32, "bn_bwd_wgrad.dw_out", 3)
     n, cin, h, w = x.shape
     cout = g.shape[1]
-    if g.shape != y_bn.shape or dy_out.shape != g.shape or g.shape[0] != n or tuple(g.shape[2:]) != (h, w):
+    if g.shape != y_bn.shape or (dy_out is not None and dy_out.shape != g.shape) or g.shape[0] != n \
+            or tuple(g.shape[2:]) != (h, w):
         raise ValueError("bn_bwd_wgrad: shape mismatch")
     if tuple(dw_out.shape) != (cin, ksize * ksize, cout):
         raise ValueError("bn_bwd_wgrad.dw_out: shape mismatch")
     lib = _lib.load()
     if _NO_FUSED_BN_WGRAD or not lib.lf_conv2d_wgrad_bn_supported(n, cin, h, w, cout, ksize):
-        bn_bwd(g, y_bn, stats, gamma, dgamma, dbeta, relu, alpha_nc=alpha_nc, add_nc=add_nc,
-               out=dy_out, plane_g=plane_g, plane_m=plane_m, tile_sums=tile_sums)
-        conv2d_wgrad(x, dy_out, ksize, in_scale, in_shift, in_relu, out=dw_out)
+        dy = bn_bwd(g, y_bn, stats, gamma, dgamma, dbeta, relu, alpha_nc=alpha_nc, add_nc=add_nc,
+                    out=dy_out, plane_g=plane_g, plane_m=plane_m, tile_sums=tile_sums)
+        conv2d_wgrad(x, dy, ksize, in_scale, in_shift, in_relu, out=dw_out)
         return dy_out
     for t in (plane_g, plane_m):
         if t is not None and tuple(t.shape) != (n, cout, 2):
@@ -220,7 +222,7 @@ def bn_bwd_wgrad(x: torch.Tensor, g: torch.Tensor, y_bn: torch.Tensor, stats: to
                   ws.numel(), _stream())
     ws = _workspace(lib.lf_conv2d_wgrad_workspace(n, cin, h, w, cout, ksize), x.device)
     _lib.call("lf_conv2d_wgrad_bn_f32", x.data_ptr(), g.data_ptr(), y_bn.data_ptr(), _ptr(alpha_nc),
-              _ptr(add_nc), coef.data_ptr(), 1 if relu else 0, dy_out.data_ptr(), n, cin, h, w, cout,
+              _ptr(add_nc), coef.data_ptr(), 1 if relu else 0, _ptr(dy_out), n, cin, h, w, cout,
               ksize, _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, ws.data_ptr(), ws.numel(),
               _stream())
     _lib.call("lf_conv2d_wgrad_reduce_f32", ws.data_ptr(), dw_out.data_ptr(), n, cin, h, w, cout,

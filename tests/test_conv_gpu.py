@@ -137,6 +137,7 @@ def test_conv_bn_stats_epilogue(cuda, n, cin, cout, h, w, k):
 @pytest.mark.parametrize("n,cin,cout,h,w,with_se", [(3, 32, 32, 32, 32, True),    # fused, CI_T == Cin
                                                     (2, 64, 64, 32, 32, False),   # two ci blocks
                                                     (2, 32, 64, 56, 56, True),    # 28-wide tiles
+                                                    (2, 3, 32, 64, 64, False),    # stem: small-Cin kernel
                                                     (2, 16, 24, 20, 12, True)])   # unsupported -> fallback
 def test_bn_backward_inside_wgrad(cuda, n, cin, cout, h, w, with_se):
     """BatchNorm backward formed inside the weight-gradient kernel (dy written on the side) vs
