@@ -219,7 +219,7 @@ int lf_conv2d_wgrad_reduce_f32(void* workspace, float* dw, int n, int cin, int h
 /* Weight gradient whose dY operand is a BatchNormalization backward, formed on the fly:
  * dY = coef2*dz + coef3*bn_y + coef4, dz = (g*alpha_nc+add_nc)*[bn_y*coef0+coef1 > 0 or !bn_relu]
  * (coef from lf_bn_bwd_sums_f32), also written to dy_out [n][cout][h][w] (may be null: the stem
- * has no input gradient) for the input-gradient convolution that follows.  3x3 (the small-Cin stem kernel included), shapes for which lf_conv2d_wgrad_bn_supported() != 0; same
+ * has no input gradient) for the input-gradient convolution that follows.  3x3 (the small-Cin stem kernel included) and 1x1, shapes for which lf_conv2d_wgrad_bn_supported() != 0; same
  * workspace and reduce step as lf_conv2d_wgrad_f32. */
 int lf_conv2d_wgrad_bn_supported(int n, int cin, int h, int w, int cout, int ksize);
 int lf_conv2d_wgrad_bn_f32(const float* x, const float* g, const float* bn_y,
@@ -270,6 +270,7 @@ int lf_bn_infer_scale_shift_f32(int c, const float* gamma, const float* beta,
  * dbeta = sum dz.  plane_g / plane_m (optional, [n][c][2], relu case only): when the producer
  * of g already left per-plane sums {sum g*mask, sum g*mask*y} (lf_block_tail_bwd_f32) and the
  * forward left {sum mask, sum mask*y} (lf_gap_f32; needed with add_nc), the two channel sums
+ * (with relu == 0 the plane sums are unmasked and alpha_nc / add_nc must be null)
  * come from those and g / y are read once (for dy) instead of twice.  have_sums != 0: dgamma /
  * dbeta already hold the sums (lf_bn_bwd_sums_tiles_f32) and only the apply pass runs. */
 int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, const float* y,
@@ -329,11 +330,12 @@ int lf_block_tail_fwd_f32(const float* y, const float* a_scale, const float* a_s
 /* dr = gradient wrt (sc' + a*s): dp*drop routed to the recorded position of each window whose
  * maximum was > 0; ds[n][c] = sum_hw dr*a (SE gate gradient); plane_sums [n][c][2] =
  * {sum dr*[a>0], sum dr*[a>0]*y} for lf_bn_bwd_f32 (y goes with ds / plane_sums; plane_sums
- * needs a_scale). */
+ * needs a_scale); sc_y (the projection shortcut's pre-BN tensor, optional) with sc_sums
+ * [n][c][2] = {sum dr, sum dr*sc_y}: the same for the shortcut's BatchNormalization (no mask). */
 int lf_block_tail_bwd_f32(const float* dp, const uint8_t* route, const float* y,
                           const float* a_scale, const float* a_shift, const float* drop, float* dr,
-                          float* ds, float* plane_sums, int n, int c, int h, int w,
-                          lf_stream_t stream);
+                          float* ds, float* plane_sums, const float* sc_y, float* sc_sums, int n,
+                          int c, int h, int w, lf_stream_t stream);
 
 /* ---- head (cnn.py:98-101; train/utils.py:30-35) ---- */
 /* probs = softmax(feat w + b), w [f][c]; loss[n] = -sum_j ytrue[n][j] log(clip(probs)). */

@@ -73,7 +73,7 @@ SIGNATURES = {
     "lf_se_bwd_workspace": [c_int, c_int, c_int],
     "lf_se_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P, c_size_t, P],
     "lf_block_tail_fwd_f32": [P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P],
-    "lf_block_tail_bwd_f32": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "lf_block_tail_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "lf_head_fwd_f32": [P, P, P, P, P, P, c_int, c_int, c_int, P],
     "lf_head_bwd_f32": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     "lf_mul_f32": [P, P, P, c_size_t, P],

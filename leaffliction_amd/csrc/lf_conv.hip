@@ -579,6 +579,18 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
                 lsc[kMaxProC / 4 + c] = gc < p.cin ? p.in_shift[gc] : 0.f;
             }
         }
+        // optional: dY = BatchNorm backward of p.dy, formed while staging (see WgradArgs)
+        const bool bn = p.bn_y != nullptr;
+        float4 yv[DPT];
+        float dal[DPT], dad[DPT];
+        unsigned dok = 0;
+        __shared__ float lbn[5 * CO_T];
+        if (bn) {
+            for (int e = tid; e < 5 * CO_T; e += kThreads) {
+                const int kk = e / CO_T, gc = co0 + (e - kk * CO_T);
+                lbn[e] = gc < p.cout ? p.bn_coef[(size_t)kk * p.cout + gc] : 0.f;
+            }
+        }
         auto load_x = [&](int item, auto i0c, auto i1c) {
             constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
             const int n = item / tiles, t = item - n * tiles;
@@ -619,19 +631,40 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
             const int n = item / tiles, t = item - n * tiles;
             const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
             const float* din = p.dy + (size_t)n * p.cout * hw;
+            dok = 0;
 #pragma unroll
             for (int i = 0; i < DPT; ++i) {
                 const int e = tid + i * kThreads;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < NDI) {
-                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
-                    const int py = rem / TW4, slot = rem - py * TW4;
-                    const int gc = co0 + c, gy = ty0 + py;
-                    if (gc < p.cout && gy < p.h)
-                        v = *reinterpret_cast<const float4*>(din + (unsigned)gc * uhw +
-                                                             (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                const int py = rem / TW4, slot = rem - py * TW4;
+                const int gc = co0 + c, gy = ty0 + py;
+                if (e < NDI && gc < p.cout && gy < p.h) {
+                    v = *reinterpret_cast<const float4*>(din + (unsigned)gc * uhw +
+                                                         (unsigned)gy * (unsigned)p.wd + tx0 + 4 * slot);
+                    dok |= 1u << i;
                 }
                 dv[i] = v;
+            }
+            if (bn) {
+                const float* yin = p.bn_y + (size_t)n * p.cout * hw;
+#pragma unroll
+                for (int i = 0; i < DPT; ++i) {
+                    const int e = tid + i * kThreads;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                    const int py = rem / TW4, slot = rem - py * TW4;
+                    if (dok >> i & 1u)
+                        v = *reinterpret_cast<const float4*>(yin + (unsigned)(co0 + c) * uhw +
+                                                             (unsigned)(ty0 + py) * (unsigned)p.wd + tx0 + 4 * slot);
+                    yv[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < DPT; ++i) {
+                    const int gc = min(co0 + (tid + i * kThreads) / (TH * TW4), p.cout - 1);
+                    dal[i] = p.bn_alpha != nullptr ? p.bn_alpha[(size_t)n * p.cout + gc] : 1.f;
+                    dad[i] = p.bn_add != nullptr ? p.bn_add[(size_t)n * p.cout + gc] : 0.f;
+                }
             }
         };
         auto store_x = [&](auto i0c, auto i1c) {
@@ -672,17 +705,33 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
                 }
             }
         };
-        auto store_d = [&]() {
+        auto store_d = [&](int item) {
+            const int sn = item / tiles, st = item - sn * tiles;
+            const int stx0 = (st % p.tiles_x) * TW, sty0 = (st / p.tiles_x) * TH;
 #pragma unroll
             for (int i = 0; i < DPT; ++i) {
                 const int e = tid + i * kThreads;
                 if (e < NDI) {
                     const int c = e / (TH * TW4), rem = e - c * (TH * TW4);
+                    float4 v = dv[i];
+                    if (bn && (dok >> i & 1u)) {
+                        const float c0 = lbn[c], c1 = lbn[CO_T + c], c2 = lbn[2 * CO_T + c],
+                                    c3 = lbn[3 * CO_T + c], c4 = lbn[4 * CO_T + c];
+                        v.x = bn_dy1(v.x, yv[i].x, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
+                        v.y = bn_dy1(v.y, yv[i].y, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
+                        v.z = bn_dy1(v.z, yv[i].z, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
+                        v.w = bn_dy1(v.w, yv[i].w, dal[i], dad[i], c0, c1, c2, c3, c4, p.bn_relu);
+                        if (blockIdx.y == 0 && p.dy_out != nullptr) {
+                            const int py = rem / TW4, slot = rem - py * TW4;
+                            *reinterpret_cast<float4*>(p.dy_out + ((size_t)sn * p.cout + co0 + c) * hw +
+                                                       (size_t)(sty0 + py) * p.wd + stx0 + 4 * slot) = v;
+                        }
+                    }
                     float* dst = ld + c * DP + rem * 4;
-                    dst[0] = dv[i].x;
-                    dst[1] = dv[i].y;
-                    dst[2] = dv[i].z;
-                    dst[3] = dv[i].w;
+                    dst[0] = v.x;
+                    dst[1] = v.y;
+                    dst[2] = v.z;
+                    dst[3] = v.w;
                 }
             }
         };
@@ -696,7 +745,7 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
             for (int item = first; item < last; ++item) {
                 __syncthreads();
                 store_x(Z{}, E{});
-                store_d();
+                store_d(item);
                 __syncthreads();
                 if (item + 1 < last) {
                     load_x(item + 1, Z{}, E{});
@@ -717,7 +766,7 @@ __global__ __launch_bounds__(kThreads, (TAPS == 9 ? 2 : 4)) void wgrad_mfma_kern
                 load_x(item, H{}, E{});
                 store_x(H{}, E{});
                 load_d(item);
-                store_d();
+                store_d(item);
                 __syncthreads();
                 compute_item();
             }
@@ -1638,7 +1687,7 @@ int lf_conv2d_wgrad_f32(const float* x, const float* dy, int n, int cin, int h, 
 }
 
 int lf_conv2d_wgrad_bn_supported(int n, int cin, int h, int wd, int cout, int ksize) {
-    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || wd <= 0 || ksize != 3) return 0;
+    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || wd <= 0 || (ksize != 3 && ksize != 1)) return 0;
     const WgPlan pl = plan_wgrad(n, cin, cout, h, wd, ksize);
     return (wd % pl.tw == 0) && (wd % 4 == 0);
 }

@@ -673,17 +673,23 @@ __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(const float* __restric
                                                           const float* __restrict__ drop,
                                                           float* __restrict__ dr,
                                                           float* __restrict__ ds,
-                                                          float* __restrict__ plane_sums, int c,
+                                                          float* __restrict__ plane_sums,
+                                                          const float* __restrict__ sc_y,
+                                                          float* __restrict__ sc_sums, int c,
                                                           int h, int w) {
-    __shared__ float red[12];
+    __shared__ float red[20];
     const int plane = blockIdx.x, ch = plane % c;
     const float dv = drop ? drop[plane] : 1.f;
     const float as = a_scale ? a_scale[ch] : 1.f, ab = a_scale ? a_shift[ch] : 0.f;
     const int ph = h / 2, pw = w / 2;
     const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
     const bool sums = ds != nullptr || plane_sums != nullptr;
-    float acc[3] = {0.f, 0.f, 0.f};
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     auto tally = [&](float gg, size_t pos) {
+        if (sc_y != nullptr && gg != 0.f) {  // the shortcut branch's (projection) BN: no mask
+            acc[3] += gg;
+            acc[4] += gg * sc_y[pos];
+        }
         if (sums && gg != 0.f) {
             const float yv = y[pos];
             float av = yv;
@@ -737,13 +743,17 @@ __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(const float* __restric
             if (yy >= 2 * ph || x >= 2 * pw) dr[base + t] = 0.f;
         }
     }
-    if (sums) {
-        block_sum<3>(acc, red);
+    if (sums || sc_y != nullptr) {
+        block_sum<5>(acc, red);
         if (threadIdx.x == 0) {
             if (ds != nullptr) ds[plane] = acc[0];
             if (plane_sums != nullptr) {
                 plane_sums[2 * (size_t)plane] = acc[1];
                 plane_sums[2 * (size_t)plane + 1] = acc[2];
+            }
+            if (sc_sums != nullptr) {
+                sc_sums[2 * (size_t)plane] = acc[3];
+                sc_sums[2 * (size_t)plane + 1] = acc[4];
             }
         }
     }
@@ -1050,7 +1060,8 @@ int lf_bn_bwd_f32(const float* g, const float* alpha_nc, const float* add_nc, co
                "lf_bn_bwd: null buffer");
     LF_REQUIRE(!have_sums || plane_g == nullptr, "lf_bn_bwd: have_sums excludes plane sums");
     LF_REQUIRE(plane_g != nullptr || plane_m == nullptr, "lf_bn_bwd: plane_m needs plane_g");
-    LF_REQUIRE(plane_g == nullptr || relu != 0, "lf_bn_bwd: plane sums describe the ReLU-masked case");
+    LF_REQUIRE(plane_g == nullptr || relu != 0 || (alpha_nc == nullptr && add_nc == nullptr),
+               "lf_bn_bwd: plane sums without a mask take no alpha / add");
     LF_REQUIRE(plane_g == nullptr || add_nc == nullptr || plane_m != nullptr,
                "lf_bn_bwd: add_nc with plane sums needs plane_m");
     LF_REQUIRE(n > 0 && c > 0 && hw > 0 && c <= 65535 && (long long)n * c < (1LL << 31),
@@ -1087,7 +1098,8 @@ int lf_bn_bwd_sums_f32(const float* g, const float* alpha_nc, const float* add_n
     LF_REQUIRE(n > 0 && c > 0 && hw > 0 && c <= 65535 && (long long)n * c < (1LL << 31),
                "lf_bn_bwd_sums: bad dims n=%d c=%d hw=%d", n, c, hw);
     LF_REQUIRE(plane_g != nullptr || plane_m == nullptr, "lf_bn_bwd_sums: plane_m needs plane_g");
-    LF_REQUIRE(plane_g == nullptr || relu != 0, "lf_bn_bwd_sums: plane sums describe the ReLU-masked case");
+    LF_REQUIRE(plane_g == nullptr || relu != 0 || (alpha_nc == nullptr && add_nc == nullptr),
+               "lf_bn_bwd_sums: plane sums without a mask take no alpha / add");
     LF_REQUIRE(plane_g == nullptr || add_nc == nullptr || plane_m != nullptr,
                "lf_bn_bwd_sums: add_nc with plane sums needs plane_m");
     if (ws_bytes < lf_bn_workspace(c)) {
@@ -1206,8 +1218,9 @@ int lf_block_tail_fwd_f32(const float* y, const float* a_scale, const float* a_s
 
 int lf_block_tail_bwd_f32(const float* dp, const uint8_t* route, const float* y,
                           const float* a_scale, const float* a_shift, const float* drop, float* dr,
-                          float* ds, float* plane_sums, int n, int c, int h, int w,
-                          lf_stream_t stream) {
+                          float* ds, float* plane_sums, const float* sc_y, float* sc_sums, int n,
+                          int c, int h, int w, lf_stream_t stream) {
+    LF_REQUIRE((sc_y == nullptr) == (sc_sums == nullptr), "lf_block_tail_bwd: sc_y and sc_sums go together");
     LF_REQUIRE(dp && route && dr, "lf_block_tail_bwd: null buffer");
     LF_REQUIRE(plane_sums == nullptr || (y != nullptr && a_scale != nullptr),
                "lf_block_tail_bwd: plane_sums needs y and a_scale/a_shift");
@@ -1217,7 +1230,7 @@ int lf_block_tail_bwd_f32(const float* dp, const uint8_t* route, const float* y,
                "lf_block_tail_bwd: y goes with ds / plane_sums");
     LF_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "lf_block_tail_bwd: a_scale/a_shift");
     tail_bwd_kernel<<<n * c, kBlock, 0, lf::as_stream(stream)>>>(dp, route, y, a_scale, a_shift, drop, dr,
-                                                                ds, plane_sums, c, h, w);
+                                                                ds, plane_sums, sc_y, sc_sums, c, h, w);
     return lf::check_launch("lf_block_tail_bwd");
 }
 

@@ -411,7 +411,9 @@ class LeafCNN:
             ds = B(p + "ds", (n, f)) if self.use_se else None
             # dr (into gA), the SE gate gradient, and BN2's per-plane backward sums in one pass
             psum = B(p + "psum", (n, f, 2))
-            nn.block_tail_bwd(dp, route, y2, st2[2], st2[3], drop, gA, ds, psum)
+            yp = sv.get(p + "yp")  # projection shortcut: its BN's backward sums ride along
+            psum_p = B(p + "psum_p", (n, f, 2)) if yp is not None else None
+            nn.block_tail_bwd(dp, route, y2, st2[2], st2[3], drop, gA, ds, psum, yp, psum_p)
             add_nc = None
             if self.use_se:
                 dm = B(p + "dm", (n, f))
@@ -433,9 +435,10 @@ class LeafCNN:
                             tile_sums=tsum)
             if cin != f:
                 stp = self.stats[p + "bnp"]
-                nn.bn_bwd(gA, sv[p + "yp"], stp, P[p + "bnp.gamma"], G[p + "bnp.gamma"],
-                          G[p + "bnp.beta"], False, out=gC)                   # dyp
-                nn.conv2d_wgrad(xin, gC, 1, pro[0], pro[1], pro[2], out=G[p + "proj.w"])
+                # projection BN backward + 1x1 weight gradient (dyp -> gC)
+                nn.bn_bwd_wgrad(xin, gA, yp, stp, P[p + "bnp.gamma"], G[p + "bnp.gamma"],
+                                G[p + "bnp.beta"], False, 1, G[p + "proj.w"], gC, pro[0], pro[1], pro[2],
+                                plane_g=psum_p)
                 dx = B(p + "dx", xin.shape)
                 nn.conv2d(gC, self._dgrad_w(p + "proj.w", 1), 1, out=dx)
             else:

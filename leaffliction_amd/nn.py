@@ -397,17 +397,21 @@ def block_tail_fwd(y, a_scale, a_shift, s, sc, sc_scale, sc_shift, sc_relu, drop
     return route, p
 
 
-def block_tail_bwd(dp, route, y, a_scale, a_shift, drop, dr, ds, plane_sums=None):
+def block_tail_bwd(dp, route, y, a_scale, a_shift, drop, dr, ds, plane_sums=None, sc_y=None,
+                   sc_sums=None):
     _chk(dr, _F32, "block_tail_bwd.dr", 4)
     _chk(route, torch.uint8, "block_tail_bwd.route", 4)
     n, c, h, w = dr.shape
     if tuple(dp.shape) != (n, c, h // 2, w // 2) or route.shape != dp.shape:
         raise ValueError("block_tail_bwd: shape mismatch")
-    if plane_sums is not None and tuple(plane_sums.shape) != (n, c, 2):
-        raise ValueError("block_tail_bwd.plane_sums: expected [N,C,2]")
+    for t in (plane_sums, sc_sums):
+        if t is not None and tuple(t.shape) != (n, c, 2):
+            raise ValueError("block_tail_bwd plane sums: expected [N,C,2]")
+    if sc_y is not None and sc_y.shape != dr.shape:
+        raise ValueError("block_tail_bwd.sc_y: shape mismatch")
     _lib.call("lf_block_tail_bwd_f32", dp.data_ptr(), route.data_ptr(), _ptr(y), _ptr(a_scale),
-              _ptr(a_shift), _ptr(drop), dr.data_ptr(), _ptr(ds), _ptr(plane_sums), n, c, h, w,
-              _stream())
+              _ptr(a_shift), _ptr(drop), dr.data_ptr(), _ptr(ds), _ptr(plane_sums), _ptr(sc_y),
+              _ptr(sc_sums), n, c, h, w, _stream())
     return dr, ds
 
 

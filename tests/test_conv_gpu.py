@@ -134,12 +134,15 @@ def test_conv_bn_stats_epilogue(cuda, n, cin, cout, h, w, k):
     assert torch.allclose(stats, stats2, rtol=1e-4, atol=1e-5 * scale)
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w,with_se", [(3, 32, 32, 32, 32, True),    # fused, CI_T == Cin
-                                                    (2, 64, 64, 32, 32, False),   # two ci blocks
-                                                    (2, 32, 64, 56, 56, True),    # 28-wide tiles
-                                                    (2, 3, 32, 64, 64, False),    # stem: small-Cin kernel
-                                                    (2, 16, 24, 20, 12, True)])   # unsupported -> fallback
-def test_bn_backward_inside_wgrad(cuda, n, cin, cout, h, w, with_se):
+@pytest.mark.parametrize("n,cin,cout,h,w,with_se,k,relu", [
+    (3, 32, 32, 32, 32, True, 3, True),     # fused, CI_T == Cin
+    (2, 64, 64, 32, 32, False, 3, True),    # two ci blocks
+    (2, 32, 64, 56, 56, True, 3, True),     # 28-wide tiles
+    (2, 3, 32, 64, 64, False, 3, True),     # stem: small-Cin kernel
+    (2, 32, 64, 32, 32, False, 1, False),   # 1x1 projection BN (no ReLU)
+    (2, 64, 128, 56, 56, False, 1, False),
+    (2, 16, 24, 20, 12, True, 3, True)])    # unsupported -> fallback
+def test_bn_backward_inside_wgrad(cuda, n, cin, cout, h, w, with_se, k, relu):
     """BatchNorm backward formed inside the weight-gradient kernel (dy written on the side) vs
     the standalone BN-backward kernel followed by the plain wgrad, and vs torch autograd."""
     from leaffliction_amd import nn
@@ -157,14 +160,16 @@ def test_bn_backward_inside_wgrad(cuda, n, cin, cout, h, w, with_se):
     yr = y.clone().requires_grad_(True)
     mean = yr.mean((0, 2, 3), keepdim=True)
     var = yr.var((0, 2, 3), unbiased=False, keepdim=True)
-    a = torch.relu((yr - mean) / torch.sqrt(var + 1e-3) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+    a = (yr - mean) / torch.sqrt(var + 1e-3) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    if relu:
+        a = torch.relu(a)
     coeff = up * (alpha.view(n, cout, 1, 1) if with_se else 1.0) + (add.view(n, cout, 1, 1) if with_se else 0.0)
     (a * coeff).sum().backward()
     dy_ref = yr.grad
     xp = torch.relu(x * in_sc.view(1, -1, 1, 1) + in_sh.view(1, -1, 1, 1))
-    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
-    F.conv2d(xp, wr, padding=1).backward(dy_ref)
-    dw_ref = wr.grad.reshape(cout, cin, 9).permute(1, 2, 0)
+    wr = torch.zeros(cout, cin, k, k, requires_grad=True)
+    F.conv2d(xp, wr, padding=k // 2).backward(dy_ref)
+    dw_ref = wr.grad.reshape(cout, cin, k * k).permute(1, 2, 0)
 
     d = lambda t: None if t is None else t.to(cuda)  # noqa: E731
     stats = torch.zeros(4, cout, device=cuda)
@@ -173,15 +178,15 @@ def test_bn_backward_inside_wgrad(cuda, n, cin, cout, h, w, with_se):
     outs = []
     for fused in (True, False):
         dgamma, dbeta = torch.zeros(cout, device=cuda), torch.zeros(cout, device=cuda)
-        dw = torch.zeros(cin, 9, cout, device=cuda)
+        dw = torch.zeros(cin, k * k, cout, device=cuda)
         dy = torch.zeros(n, cout, h, w, device=cuda)
         if fused:
-            nn.bn_bwd_wgrad(d(x), d(up), d(y), stats, d(gamma), dgamma, dbeta, True, 3, dw, dy,
+            nn.bn_bwd_wgrad(d(x), d(up), d(y), stats, d(gamma), dgamma, dbeta, relu, k, dw, dy,
                             d(in_sc), d(in_sh), True, alpha_nc=d(alpha), add_nc=d(add))
         else:
-            nn.bn_bwd(d(up), d(y), stats, d(gamma), dgamma, dbeta, True, alpha_nc=d(alpha),
+            nn.bn_bwd(d(up), d(y), stats, d(gamma), dgamma, dbeta, relu, alpha_nc=d(alpha),
                       add_nc=d(add), out=dy)
-            nn.conv2d_wgrad(d(x), dy, 3, d(in_sc), d(in_sh), True, out=dw)
+            nn.conv2d_wgrad(d(x), dy, k, d(in_sc), d(in_sh), True, out=dw)
         outs.append((dy.cpu(), dw.cpu(), dgamma.cpu(), dbeta.cpu()))
     (dy_f, dw_f, dg_f, db_f), (dy_s, dw_s, dg_s, db_s) = outs
     close(dy_f, dy_ref, tol=1e-4)
