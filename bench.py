@@ -163,6 +163,7 @@ def augment_throughput(dev, n=4096, iters=5):
     ctab = ops.crop_resize_plan(IMG, IMG, boxes, dev)
     cut = torch.from_numpy(rng.uniform(0, 2, n)).to(dev)
     rot_out_b = sum(a * b * 3 for a, b in rplan["sizes"]) / n
+    mask = (torch.rand((n, IMG, IMG), generator=g) > 0.4).to(torch.uint8).mul_(255).to(dev)
     cases = {
         "flip": (lambda: ops.flip_u8(x, mode), 2 * img_b),
         "rotate": (lambda: ops.rotate_expand_apply(x, rplan, 255, rbuf), img_b + rot_out_b),
@@ -173,6 +174,12 @@ def augment_throughput(dev, n=4096, iters=5):
         "distortion": (lambda: ops.autocontrast_u8(ops.noise_philox_add_u8(x, 42, 5.0), cut), 5 * img_b),
         "pack": (lambda: ops.pack_hwc_u8_to_nchw_f32(x), img_b + 4 * img_b),
         "hist": (lambda: ops.hist_u8(x), img_b + 3072),
+        # the transform-side kernels the north star names: mask-and-composite, separable blur,
+        # colour-space conversion (image + mask in, image out; gray blur = 1 plane each way)
+        "mask_composite": (lambda: ops.mask_composite_u8(x, mask), 2 * img_b + IMG * IMG),
+        "gauss_blur_5x5": (lambda: ops.gauss_blur_u8(x, 5, 1.5), 2 * img_b),
+        "gauss_blur_15x15": (lambda: ops.gauss_blur_u8(x, 15, 0.0), 2 * img_b),
+        "rgb2hsv": (lambda: ops.rgb2hsv_u8(x), 2 * img_b),
     }
     out, inv = {}, 0.0
     for name, (fn, nbytes) in cases.items():

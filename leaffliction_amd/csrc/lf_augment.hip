@@ -105,9 +105,7 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const uint8_t* __restrict_
     const size_t nchunks = (nbytes - head) / 16;
     const uint4* mid = reinterpret_cast<const uint4*>(base + head);
     const unsigned hc = (unsigned)(head % 3);
-    for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < nchunks;
-         q += (size_t)gridDim.x * kBlock) {
-        const uint4 v = mid[q];
+    auto tally = [&](const uint4 v, size_t q) {
         // channel of byte 0 of this chunk: (head + 16 q) % 3 = (hc + q) % 3
         const unsigned r = (hc + (unsigned)(q % 3)) % 3;
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -117,7 +115,19 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const uint8_t* __restrict_
             c = c >= 3 ? c - 3 : c;
             atomicAdd(&my[c * 256 + byte_of(w[j >> 2], j & 3)], 1u);
         }
+    };
+    // four 16-byte loads in flight per thread: one load per trip leaves the kernel
+    // latency-bound (32 KB in flight per CU ~ 4.2 TB/s)
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; q + 3 * stride < nchunks; q += 4 * stride) {
+        const uint4 v0 = mid[q], v1 = mid[q + stride], v2 = mid[q + 2 * stride], v3 = mid[q + 3 * stride];
+        tally(v0, q);
+        tally(v1, q + stride);
+        tally(v2, q + 2 * stride);
+        tally(v3, q + 3 * stride);
     }
+    for (; q < nchunks; q += stride) tally(mid[q], q);
     if (blockIdx.x == 0) {
         const size_t tail0 = head + nchunks * 16;
         for (size_t i = threadIdx.x; i < head; i += kBlock)
