@@ -103,7 +103,8 @@ int lf_rgb2gray_u8(const uint8_t* rgb, uint8_t* gray, size_t npixels, lf_stream_
 
 /* cv2.GaussianBlur(img, (k,k), sigma) on uint8 with BORDER_REFLECT_101
  * (blur.py:61,72): separable, both passes fused through LDS, OpenCV's 8.8
- * fixed-point kernel (kq[k] uint16, sum 256).  channels = 1 or 3. ksize odd <= 31. */
+ * fixed-point kernel (kq: HOST array of ksize uint16 taps, sum 256).  channels = 1 or 3,
+ * ksize odd <= 31; odd ksize 3..15 with every tap <= 255 takes the dot-product fast path. */
 int lf_gauss_blur_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int channels,
                      const uint16_t* kq, int ksize, lf_stream_t stream);
 

@@ -599,6 +599,9 @@ __global__ __launch_bounds__(kBlock) void hsv_stats_kernel(const uint8_t* __rest
 // horizontal pass -> Q8.8 uint16 rows in LDS, vertical pass -> (acc + 2^15) >> 16.
 constexpr int kBT = 32;
 constexpr int kMaxR = 15;
+struct BlurTaps {  // kernel argument: the Q8.8 taps live in scalar registers
+    uint16_t k[2 * kMaxR + 2];
+};
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -612,8 +615,8 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 template <int CH>
 __global__ __launch_bounds__(kBlock) void gauss_blur_kernel(const uint8_t* __restrict__ in,
                                                             uint8_t* __restrict__ out, int h,
-                                                            int w, const uint16_t* __restrict__ kq,
-                                                            int ksize) {
+                                                            int w, BlurTaps taps, int ksize) {
+    const uint16_t* kq = taps.k;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int r = ksize / 2;
     const int pw = kBT + 2 * r;  // patch width/height in pixels
@@ -648,6 +651,206 @@ __global__ __launch_bounds__(kBlock) void gauss_blur_kernel(const uint8_t* __res
         unsigned acc = 0;
         for (int k = 0; k < ksize; ++k) acc += kc[k] * p[k * kBT * CH];
         dst[((size_t)(y0 + ty) * w + x0) * CH + rem] = (uint8_t)((acc + (1u << 15)) >> 16);
+    }
+}
+
+// Fast path for the usual kernels (odd ksize 3..15, every Q8.8 tap <= 255).  Same arithmetic as
+// gauss_blur_kernel, reorganised for the integer dot-product units:
+//   1. the (TY+2r) x (TXP+2r) patch is loaded once (12-byte unaligned groups), de-interleaved
+//      into one byte plane per channel in LDS, BORDER_REFLECT_101 applied while loading;
+//   2. horizontal pass: a thread makes 4 pixels of two consecutive rows with v_dot4_u32_u8 on
+//      byte-aligned windows (v_alignbyte) and stores them as (row 2p | row 2p+1 << 16) pairs;
+//   3. vertical pass: v_dot2_u32_u16 over those row pairs with (even, odd) tap pairs, the
+//      accumulator seeded with 2^15 so that the result is simply byte 2;
+//   4. planes are re-interleaved and stored 12 bytes per thread.
+struct __attribute__((packed)) Bytes12 {
+    unsigned a, b, c;
+};
+struct __attribute__((packed)) Bytes4 {
+    unsigned a;
+};
+typedef unsigned short lf_us2 __attribute__((ext_vector_type(2)));
+constexpr int kFTX = 64, kFTY = 32;
+
+template <int CH, int KS>
+__global__ __launch_bounds__(kBlock) void gauss_blur_fast_kernel(const uint8_t* __restrict__ in,
+                                                                 uint8_t* __restrict__ out, int h,
+                                                                 int w, BlurTaps taps) {
+    const uint16_t* kq = taps.k;
+    constexpr int R = KS / 2, PR = kFTY + 2 * R;
+    constexpr int NG = (kFTX + 2 * R + 3) / 4;  // 4-pixel groups per patch row
+    constexpr int PITCH = 4 * (NG + 1);         // + one dword the shifted windows may touch
+    constexpr int NK = (KS + 3) / 4, NP = (KS + 1) / 2;
+    constexpr int PLANE = PR * PITCH;
+    constexpr int MIDP = (PR / 2) * kFTX;  // dwords per channel
+    static_assert(PR % 2 == 0 && CH * kFTY * kFTX <= CH * PLANE, "tile geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char patch[CH * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned midT[CH * MIDP];
+    unsigned char* stage = patch;  // [CH][kFTY][kFTX], reuses the patch after the horizontal pass
+
+    const unsigned n = blockIdx.z;
+    const int x0 = blockIdx.x * kFTX, y0 = blockIdx.y * kFTY;
+    const uint8_t* src = in + (size_t)n * h * w * CH;
+    uint8_t* dst = out + (size_t)n * h * w * CH;
+
+    // taps packed for the dot products (uniform -> scalar registers)
+    unsigned k4[NK], ke[NP], ko[NP];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        unsigned v = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * j + t < KS) v |= (unsigned)kq[4 * j + t] << (8 * t);
+        k4[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        ke[j] = (unsigned)kq[2 * j] | (2 * j + 1 < KS ? (unsigned)kq[2 * j + 1] << 16 : 0u);
+        ko[j] = (j > 0 ? (unsigned)kq[2 * j - 1] : 0u) | ((unsigned)kq[2 * j] << 16);
+    }
+
+    // ---- 1. patch -> byte planes
+    for (int i = threadIdx.x; i < PR * NG; i += kBlock) {
+        const int py = i / NG, g = i - py * NG;
+        const int sy = reflect101(y0 + py - R, h);
+        const int gx0 = x0 - R + 4 * g;
+        unsigned pl[CH];
+        if (gx0 >= 0 && gx0 + 3 < w) {
+            const uint8_t* s = src + ((size_t)sy * w + gx0) * CH;
+            if (CH == 3) {
+                const Bytes12 v = *reinterpret_cast<const Bytes12*>(s);
+                pl[0] = byte_of(v.a, 0) | byte_of(v.a, 3) << 8 | byte_of(v.b, 2) << 16 | byte_of(v.c, 1) << 24;
+                pl[CH > 1 ? 1 : 0] = byte_of(v.a, 1) | byte_of(v.b, 0) << 8 | byte_of(v.b, 3) << 16 | byte_of(v.c, 2) << 24;
+                pl[CH > 2 ? 2 : 0] = byte_of(v.a, 2) | byte_of(v.b, 1) << 8 | byte_of(v.c, 0) << 16 | byte_of(v.c, 3) << 24;
+            } else {
+                pl[0] = reinterpret_cast<const Bytes4*>(s)->a;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) pl[c] = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sx = reflect101(gx0 + t, w);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    pl[c] |= (unsigned)src[((size_t)sy * w + sx) * CH + c] << (8 * t);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            *reinterpret_cast<unsigned*>(patch + c * PLANE + py * PITCH + 4 * g) = pl[c];
+    }
+    __syncthreads();
+
+    // ---- 2. horizontal pass -> row-pair packed Q8.8
+    for (int i = threadIdx.x; i < CH * (PR / 2) * (kFTX / 4); i += kBlock) {
+        const int c = i / ((PR / 2) * (kFTX / 4)), rem = i - c * ((PR / 2) * (kFTX / 4));
+        const int rp = rem / (kFTX / 4), g = rem - rp * (kFTX / 4);
+        unsigned res[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const unsigned* row =
+                reinterpret_cast<const unsigned*>(patch + c * PLANE + (2 * rp + rr) * PITCH + 4 * g);
+            unsigned d[NK + 1];
+#pragma unroll
+            for (int j = 0; j <= NK; ++j) d[j] = row[j];
+#pragma unroll
+            for (int sft = 0; sft < 4; ++sft) {
+                unsigned acc = 0;
+#pragma unroll
+                for (int j = 0; j < NK; ++j) {
+                    const unsigned a = sft == 0 ? d[j] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sft);
+                    acc = __builtin_amdgcn_udot4(a, k4[j], acc, false);
+                }
+                res[rr][sft] = acc;  // <= 255 * 256: fits 16 bits
+            }
+        }
+        uint4 o;
+        o.x = res[0][0] | res[1][0] << 16;
+        o.y = res[0][1] | res[1][1] << 16;
+        o.z = res[0][2] | res[1][2] << 16;
+        o.w = res[0][3] | res[1][3] << 16;
+        *reinterpret_cast<uint4*>(midT + c * MIDP + rp * kFTX + 4 * g) = o;
+    }
+    __syncthreads();
+
+    // ---- 3. vertical pass -> byte planes of the output tile (two row pairs per item)
+    constexpr int RB = 2;
+    for (int i = threadIdx.x; i < CH * (kFTX / 4) * (kFTY / 2 / RB); i += kBlock) {
+        const int c = i / ((kFTX / 4) * (kFTY / 2 / RB)), rem = i - c * ((kFTX / 4) * (kFTY / 2 / RB));
+        const int yb = rem / (kFTX / 4), g = rem - yb * (kFTX / 4);
+        uint4 m[RB + NP - 1];
+#pragma unroll
+        for (int j = 0; j < RB + NP - 1; ++j)
+            m[j] = *reinterpret_cast<const uint4*>(midT + c * MIDP + (yb * RB + j) * kFTX + 4 * g);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            unsigned ev[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
+            unsigned od[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const unsigned mv[4] = {m[b + j].x, m[b + j].y, m[b + j].z, m[b + j].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ev[t] = __builtin_amdgcn_udot2(__builtin_bit_cast(lf_us2, mv[t]),
+                                                   __builtin_bit_cast(lf_us2, ke[j]), ev[t], false);
+                    od[t] = __builtin_amdgcn_udot2(__builtin_bit_cast(lf_us2, mv[t]),
+                                                   __builtin_bit_cast(lf_us2, ko[j]), od[t], false);
+                }
+            }
+            const unsigned oe = byte_of(ev[0], 2) | byte_of(ev[1], 2) << 8 | byte_of(ev[2], 2) << 16 |
+                                byte_of(ev[3], 2) << 24;
+            const unsigned oo = byte_of(od[0], 2) | byte_of(od[1], 2) << 8 | byte_of(od[2], 2) << 16 |
+                                byte_of(od[3], 2) << 24;
+            const int ty = 2 * (yb * RB + b);
+            *reinterpret_cast<unsigned*>(stage + (c * kFTY + ty) * kFTX + 4 * g) = oe;
+            *reinterpret_cast<unsigned*>(stage + (c * kFTY + ty + 1) * kFTX + 4 * g) = oo;
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. interleave and store
+    for (int i = threadIdx.x; i < kFTY * (kFTX / 4); i += kBlock) {
+        const int ty = i / (kFTX / 4), g = i - ty * (kFTX / 4);
+        const int gy = y0 + ty, gx = x0 + 4 * g;
+        if (gy >= h || gx >= w) continue;
+        unsigned pl[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            pl[c] = *reinterpret_cast<const unsigned*>(stage + (c * kFTY + ty) * kFTX + 4 * g);
+        uint8_t* d = dst + ((size_t)gy * w + gx) * CH;
+        if (gx + 3 < w) {
+            if (CH == 3) {
+                const unsigned r4 = pl[0], g4 = pl[CH > 1 ? 1 : 0], b4 = pl[CH > 2 ? 2 : 0];
+                Bytes12 o;
+                o.a = byte_of(r4, 0) | byte_of(g4, 0) << 8 | byte_of(b4, 0) << 16 | byte_of(r4, 1) << 24;
+                o.b = byte_of(g4, 1) | byte_of(b4, 1) << 8 | byte_of(r4, 2) << 16 | byte_of(g4, 2) << 24;
+                o.c = byte_of(b4, 2) | byte_of(r4, 3) << 8 | byte_of(g4, 3) << 16 | byte_of(b4, 3) << 24;
+                *reinterpret_cast<Bytes12*>(d) = o;
+            } else {
+                reinterpret_cast<Bytes4*>(d)->a = pl[0];
+            }
+        } else {
+            for (int t = 0; gx + t < w; ++t)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) d[t * CH + c] = (uint8_t)byte_of(pl[c], t);
+        }
+    }
+}
+
+template <int CH>
+bool launch_blur_fast(const uint8_t* in, uint8_t* out, int n, int h, int w, const BlurTaps& kq,
+                      int ksize, hipStream_t s) {
+    dim3 grid((w + kFTX - 1) / kFTX, (h + kFTY - 1) / kFTY, n);
+    switch (ksize) {
+        case 3: gauss_blur_fast_kernel<CH, 3><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
+        case 5: gauss_blur_fast_kernel<CH, 5><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
+        case 7: gauss_blur_fast_kernel<CH, 7><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
+        case 9: gauss_blur_fast_kernel<CH, 9><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
+        case 11: gauss_blur_fast_kernel<CH, 11><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
+        case 13: gauss_blur_fast_kernel<CH, 13><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
+        case 15: gauss_blur_fast_kernel<CH, 15><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
+        default: return false;
     }
 }
 
@@ -847,15 +1050,25 @@ int lf_gauss_blur_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int c
     LF_REQUIRE(ksize >= 1 && ksize <= 2 * kMaxR + 1 && (ksize & 1), "lf_gauss_blur: bad ksize %d",
                ksize);
     LF_REQUIRE(in != out, "lf_gauss_blur: in-place blur is not supported");
+    LF_REQUIRE(n <= 65535, "lf_gauss_blur: batch too large for grid.z");
+    BlurTaps taps{};
+    bool fit_u8 = ksize >= 3;
+    for (int i = 0; i < ksize; ++i) {  // kq is a HOST array (it is a handful of model constants)
+        taps.k[i] = kq[i];
+        fit_u8 = fit_u8 && kq[i] <= 255;
+    }
+    hipStream_t s = lf::as_stream(stream);
+    if (fit_u8 && (channels == 3 ? launch_blur_fast<3>(in, out, n, h, w, taps, ksize, s)
+                                 : launch_blur_fast<1>(in, out, n, h, w, taps, ksize, s)))
+        return lf::check_launch("lf_gauss_blur");
     const int pw = kBT + (ksize / 2) * 2;
     const size_t lds = ((size_t)(pw * pw * channels + 15) & ~(size_t)15) +
                        (size_t)pw * kBT * channels * sizeof(uint16_t);
     dim3 grid((w + kBT - 1) / kBT, (h + kBT - 1) / kBT, n);
-    hipStream_t s = lf::as_stream(stream);
     if (channels == 3)
-        gauss_blur_kernel<3><<<grid, kBlock, lds, s>>>(in, out, h, w, kq, ksize);
+        gauss_blur_kernel<3><<<grid, kBlock, lds, s>>>(in, out, h, w, taps, ksize);
     else
-        gauss_blur_kernel<1><<<grid, kBlock, lds, s>>>(in, out, h, w, kq, ksize);
+        gauss_blur_kernel<1><<<grid, kBlock, lds, s>>>(in, out, h, w, taps, ksize);
     return lf::check_launch("lf_gauss_blur");
 }
 

@@ -200,9 +200,9 @@ def gauss_blur_u8(x: torch.Tensor, ksize: int, sigma: float) -> torch.Tensor:
         (n, h, w), ch = x.shape, 1
     else:
         raise ValueError("gauss_blur.x: expected [N,H,W,3] or [N,H,W]")
-    kq = torch.from_numpy(gaussian_kernel_q8(ksize, sigma).astype(np.int16)).to(x.device)
+    kq = np.ascontiguousarray(gaussian_kernel_q8(ksize, sigma).astype(np.uint16))  # host constants
     out = torch.empty_like(x)
-    _lib.call("lf_gauss_blur_u8", x.data_ptr(), out.data_ptr(), n, h, w, ch, kq.data_ptr(), ksize,
+    _lib.call("lf_gauss_blur_u8", x.data_ptr(), out.data_ptr(), n, h, w, ch, kq.ctypes.data, ksize,
               _stream())
     return out
 
