@@ -1402,6 +1402,11 @@ inline long long padded_work(const FwdVariant& v, int h, int w, int cout) {
 template <int TAPS>
 int launch_fwd(int variant, const ConvArgs& a, dim3 grid, hipStream_t s) {
     constexpr int KS = TAPS == 9 ? LF_KC_SMALL : 8;
+    if (TAPS == 9 && variant == 0 && a.cin <= 4) {
+        // the stem (Cin = 3): a 4-channel K-chunk instead of 8 halves the MFMAs spent on zeros
+        conv_mfma_kernel<9, 32, 8, 1, 1, 4, 2, 4><<<grid, kThreads, 0, s>>>(a);
+        return LF_OK;
+    }
     switch (variant) {
         case 0: conv_mfma_kernel<TAPS, 32, 8, 1, 1, 4, 2, KS><<<grid, kThreads, 0, s>>>(a); break;
         case 1: conv_mfma_kernel<TAPS, 32, 8, 1, 2, 4, 2, KS><<<grid, kThreads, 0, s>>>(a); break;
