@@ -76,6 +76,10 @@ struct ConvArgs {
     int in_relu;
     int accumulate;  // y += conv(...) instead of y = conv(...)
     int vec_ok;      // W % 4 == 0, Cout % 4 == 0, 16-byte aligned bases
+    // images per workgroup column (1, or 2 for the STK instantiation): with H = 28 and 8-row
+    // tiles two images are walked as one 56-row strip, so no tile is half empty; the tile that
+    // straddles the seam carries each image's own halo rows
+    int stack;
     // optional BatchNorm statistics of the output, gathered in the epilogue: per (channel, tile)
     // sum and sum of squares of (y - pivot[co]) -> stat_part[(co * stat_tiles + tile) * 2 + {0,1}]
     float* stat_part;
@@ -113,7 +117,7 @@ __device__ __forceinline__ float half_sum32(float v) {
 // Waves: WCO x WPX = 4; each wave computes MB cout-blocks x NB pixel-blocks.
 // min waves/SIMD asked of the register allocator: accumulators + VGPRs share one 512-entry
 // file per SIMD lane; with the prefetch registers <=32 accumulators fit 3 waves, more fit 2.
-template <int TAPS, int TW, int TH, int WCO, int MB, int WPX, int NB, int kKC>
+template <int TAPS, int TW, int TH, int WCO, int MB, int WPX, int NB, int kKC, bool STK = false>
 __global__ __launch_bounds__(kThreads, (MB * NB * 16 <= 32 ? 3 : 2))
 void conv_mfma_kernel(ConvArgs p) {
     constexpr int NPB = TW * TH / 32;
@@ -121,7 +125,7 @@ void conv_mfma_kernel(ConvArgs p) {
     static_assert(WCO * WPX == 4 && WPX * NB == NPB, "wave decomposition");
     constexpr int CT = 32 * WCO * MB;
     constexpr int HALO = TAPS == 9 ? 1 : 0;
-    constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO, PP = PW * PH;
+    constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO + (STK ? 2 * HALO : 0), PP = PW * PH;
     constexpr int PATCH = kKC * PP;
     constexpr int WSZ = kKC * TAPS * CT;
     // vector staging: per patch row TW/4 float4 interior items + 2 halo scalars, kept in two
@@ -143,10 +147,27 @@ void conv_mfma_kernel(ConvArgs p) {
     const int tile = blockIdx.x;
     const int tx0 = (tile % p.tiles_x) * TW, ty0 = (tile / p.tiles_x) * TH;
     const int co0 = blockIdx.y * CT;
-    const int n = blockIdx.z;
+    const int n = blockIdx.z * p.stack;  // first image of this workgroup's strip
     const size_t hw = (size_t)p.h * p.wd;
     const unsigned uhw = (unsigned)hw;
     const float* xin = p.x + ((LF_ABLATE & 2) ? (size_t)0 : (size_t)n * p.cin * hw);
+    // strip rows ty0 .. ty0+TH-1: the first `ra` belong to image n + imgA (rows gyA0 ..), the
+    // rest (only when the tile straddles a seam, or hangs over the bottom) to the next image
+    const int imgA = ty0 / p.h, gyA0 = ty0 - imgA * p.h;
+    const int ra = min(TH, p.h - gyA0);
+    const bool imgA_ok = imgA < p.stack && n + imgA < p.n;
+    const bool imgB_ok = STK && imgA + 1 < p.stack && n + imgA + 1 < p.n;
+    // patch row -> (image, row): [0, ra+2H) image A from gyA0-H; then image B from -H
+    auto patch_row = [&](int py, int& img, int& gy) {
+        if (py < ra + 2 * HALO) {
+            img = imgA;
+            gy = gyA0 - HALO + py;
+            return imgA_ok && gy >= 0 && gy < p.h;
+        }
+        img = imgA + 1;
+        gy = py - (ra + 2 * HALO) - HALO;
+        return imgB_ok && ra < TH && gy >= 0 && gy < p.h && gy < TH - ra + HALO;
+    };
 
     // per-lane LDS read bases
     const int khalf = lane >> 5, j = lane & 31;
@@ -154,7 +175,8 @@ void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int f = (wave_px * NB + nb) * 32 + j;
-        bbase[nb] = khalf * PP + (f / TW) * PW + (f % TW);
+        const int r = f / TW, prow = (STK && r >= ra) ? r + 2 * HALO : r;
+        bbase[nb] = khalf * PP + prow * PW + (f % TW);
     }
     const int abase = khalf * TAPS * CT + wave_co * MB * 32 + j;
 
@@ -224,9 +246,9 @@ void conv_mfma_kernel(ConvArgs p) {
             const int e = tid + i * kThreads;
             const int kc = e / (PH * TW4), rem = e - kc * (PH * TW4);
             const int py = rem / TW4, slot = rem - py * TW4;
-            const int gy = ty0 + py - HALO;
-            const bool ok = e < NVI && gy >= 0 && gy < p.h;
-            pg[i] = ok ? 4u * ((unsigned)kc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)(tx0 + 4 * slot)) : kBufOob;
+            int img, gy;
+            const bool ok = patch_row(py, img, gy) && e < NVI;
+            pg[i] = ok ? 4u * ((unsigned)(img * p.cin + kc) * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)(tx0 + 4 * slot)) : kBufOob;
             pl[i] = (unsigned)(kc * PP + py * PW + HALO + 4 * slot) | ((unsigned)kc << 16);
             okmask |= (ok ? 1u : 0u) << i;
         }
@@ -235,9 +257,10 @@ void conv_mfma_kernel(ConvArgs p) {
             const int e = tid + i * kThreads;
             const int kc = e / (PH * 2), rem = e - kc * (PH * 2);
             const int py = rem >> 1, side = rem & 1;
-            const int gy = ty0 + py - HALO, gx = side ? tx0 + TW : tx0 - 1;
-            const bool ok = e < NHI && gy >= 0 && gy < p.h && gx >= 0 && gx < p.wd;
-            hg[i] = ok ? 4u * ((unsigned)kc * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx) : kBufOob;
+            const int gx = side ? tx0 + TW : tx0 - 1;
+            int img, gy;
+            const bool ok = patch_row(py, img, gy) && e < NHI && gx >= 0 && gx < p.wd;
+            hg[i] = ok ? 4u * ((unsigned)(img * p.cin + kc) * uhw + (unsigned)gy * (unsigned)p.wd + (unsigned)gx) : kBufOob;
             hl[i] = (unsigned)(kc * PP + py * PW + (side ? PW - 1 : 0)) | ((unsigned)kc << 16);
             okmask |= (ok ? 1u : 0u) << (16 + i);
         }
@@ -248,8 +271,11 @@ void conv_mfma_kernel(ConvArgs p) {
             wg[i] = (e < NWI && co0 + col < p.cout) ? 4u * ((unsigned)row * (unsigned)p.cout + (unsigned)(co0 + col)) : kBufOob;
         }
         auto load_patch = [&](int c0) {
-            const __amdgpu_buffer_rsrc_t rx =
-                buf_rsrc(xin + (size_t)c0 * hw, 4u * (unsigned)min(kKC, p.cin - c0) * uhw);
+            // (with a strip of two images the second image's chunk lies Cin planes further on;
+            // the host only stacks when Cin is a whole number of chunks)
+            const __amdgpu_buffer_rsrc_t rx = buf_rsrc(
+                xin + (size_t)c0 * hw,
+                4u * (unsigned)((STK ? (p.stack - 1) * p.cin : 0) + min(kKC, p.cin - c0)) * uhw);
 #pragma unroll
             for (int i = 0; i < IPT; ++i) pv[i] = buf_load4(rx, pg[i]);
 #pragma unroll
@@ -374,9 +400,13 @@ void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int f = (wave_px * NB + nb) * 32 + j;
-        const int oy = ty0 + f / TW, ox = tx0 + f % TW;
-        pix_ok[nb] = oy < p.h && ox < p.wd;
-        pixc[nb] = pix_ok[nb] ? (unsigned)oy * (unsigned)p.wd + (unsigned)ox : 0u;
+        const int r = f / TW, ox = tx0 + f % TW;
+        const bool in_a = r < ra;
+        const int oy = in_a ? gyA0 + r : r - ra;
+        pix_ok[nb] = (in_a ? imgA_ok : imgB_ok) && oy < p.h && ox < p.wd;
+        pixc[nb] = pix_ok[nb] ? (unsigned)((in_a ? imgA : imgA + 1) * p.cout) * uhw +
+                                    (unsigned)oy * (unsigned)p.wd + (unsigned)ox
+                              : 0u;
     }
     float* red = lds;  // [WPX][CT][2] statistics scratch
     static_assert(WPX * CT * 2 <= PATCH + WSZ, "stat scratch must fit the staging LDS");
@@ -452,7 +482,7 @@ void conv_mfma_kernel(ConvArgs p) {
     }
     if (stats) {
         __syncthreads();
-        const long long tg = (long long)n * (p.tiles_x * p.tiles_y) + tile;
+        const long long tg = (long long)blockIdx.z * (p.tiles_x * p.tiles_y) + tile;
         for (int c = tid; c < CT; c += kThreads) {
             if (co0 + c >= p.cout) continue;
             float a = 0.f, b = 0.f;
@@ -1412,7 +1442,7 @@ int launch_fwd(int variant, const ConvArgs& a, dim3 grid, hipStream_t s) {
         case 1: conv_mfma_kernel<TAPS, 32, 8, 1, 2, 4, 2, KS><<<grid, kThreads, 0, s>>>(a); break;
         case 2: conv_mfma_kernel<TAPS, 16, 16, 1, 1, 4, 2, KS><<<grid, kThreads, 0, s>>>(a); break;
         case 3: conv_mfma_kernel<TAPS, 16, 16, 1, 2, 4, 2, KS><<<grid, kThreads, 0, s>>>(a); break;
-        case 4: conv_mfma_kernel<TAPS, 28, 8, 4, 1, 1, 7, 8><<<grid, kThreads, 0, s>>>(a); break;
+        case 4: conv_mfma_kernel<TAPS, 28, 8, 4, 1, 1, 7, 8, true><<<grid, kThreads, 0, s>>>(a); break;
         case 5: conv_mfma_kernel<TAPS, 32, 8, 2, 2, 2, 4, 8><<<grid, kThreads, 0, s>>>(a); break;
         case 6: conv_mfma_kernel<TAPS, 56, 8, 2, 1, 2, 7, 8><<<grid, kThreads, 0, s>>>(a); break;
         default: return LF_ERR_INVALID;
@@ -1513,6 +1543,18 @@ constexpr int kReduceGroup = 32;  // slabs summed per first-stage workgroup row
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
+// Images per workgroup strip: 2 when the 28x8 tile would leave the last tile of every image
+// half empty (H = 28: 3.5 tiles) and the shape meets what the strip path needs (full-width
+// vector tiles, Cin a whole number of K-chunks, two images within 32-bit byte offsets).
+inline int conv_stack(int variant, int n, int cin, int h, int wd, int cout) {
+    const FwdVariant& v = kFwdVariants[variant];
+    if (variant != 4 || n < 2 || v.th > h) return 1;
+    if (h % v.th == 0 || (2 * h) % v.th != 0) return 1;
+    if (wd % v.tw != 0 || wd % 4 != 0 || cout % 4 != 0 || cin % 8 != 0) return 1;
+    if ((size_t)2 * cin * h * wd >= (1ull << 29) || (size_t)2 * cout * h * wd >= (1ull << 30)) return 1;
+    return 2;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1556,17 +1598,26 @@ static int conv2d_launch(const char* who, const float* x, const float* w, float*
     ConvArgs a;
     a.x = x; a.w = w; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
     a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.wd = wd;
-    a.tiles_x = (wd + v.tw - 1) / v.tw;
-    a.tiles_y = (h + v.th - 1) / v.th;
     a.in_relu = in_relu;
     a.accumulate = accumulate;
     a.vec_ok = (wd % 4 == 0) && (cout % 4 == 0) && aligned16(x) && aligned16(w);
+    a.stack = conv_stack(best, n, cin, h, wd, cout);
+    if (a.stack > 1 && !a.vec_ok) {
+        if (stat_part != nullptr) {  // the tile count the caller sized its buffers for assumes it
+            lf::set_error("%s: the statistics epilogue needs 16-byte aligned x / w", who);
+            return LF_ERR_INVALID;
+        }
+        a.stack = 1;
+    }
+    a.tiles_x = (wd + v.tw - 1) / v.tw;
+    a.tiles_y = (a.stack * h + v.th - 1) / v.th;
     a.stat_part = stat_part;
     a.stat_pivot = stat_pivot;
     a.stat_mask_y = stat_mask_y; a.mask_scale = mask_scale; a.mask_shift = mask_shift;
     a.mask_relu = mask_relu;
-    a.stat_tiles = (long long)n * a.tiles_x * a.tiles_y;
-    dim3 grid(a.tiles_x * a.tiles_y, (cout + v.ct - 1) / v.ct, n);
+    const int gz = (n + a.stack - 1) / a.stack;
+    a.stat_tiles = (long long)gz * a.tiles_x * a.tiles_y;
+    dim3 grid(a.tiles_x * a.tiles_y, (cout + v.ct - 1) / v.ct, gz);
     hipStream_t s = lf::as_stream(stream);
     const int rc = ksize == 3 ? launch_fwd<9>(best, a, grid, s) : launch_fwd<1>(best, a, grid, s);
     if (rc != LF_OK) return rc;
@@ -1580,10 +1631,12 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
                          accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
-long long lf_conv2d_stats_tiles(int n, int h, int wd, int cout) {
-    if (n <= 0 || h <= 0 || wd <= 0 || cout <= 0) return 0;
-    const FwdVariant& v = kFwdVariants[lf_conv2d_variant(h, wd, cout)];
-    return (long long)n * ((wd + v.tw - 1) / v.tw) * ((h + v.th - 1) / v.th);
+long long lf_conv2d_stats_tiles(int n, int cin, int h, int wd, int cout) {
+    if (n <= 0 || cin <= 0 || h <= 0 || wd <= 0 || cout <= 0) return 0;
+    const int best = lf_conv2d_variant(h, wd, cout);
+    const FwdVariant& v = kFwdVariants[best];
+    const int stack = conv_stack(best, n, cin, h, wd, cout);
+    return (long long)((n + stack - 1) / stack) * ((wd + v.tw - 1) / v.tw) * ((stack * h + v.th - 1) / v.th);
 }
 
 int lf_conv2d_stats_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd,
@@ -1591,7 +1644,7 @@ int lf_conv2d_stats_f32(const float* x, const float* w, float* y, int n, int cin
                         int in_relu, const float* pivot, float* tile_part, size_t tile_part_bytes,
                         lf_stream_t stream) {
     LF_REQUIRE(tile_part, "lf_conv2d_stats: null tile_part");
-    const long long tiles = lf_conv2d_stats_tiles(n, h, wd, cout);
+    const long long tiles = lf_conv2d_stats_tiles(n, cin, h, wd, cout);
     if (tile_part_bytes < (size_t)tiles * (size_t)(cout > 0 ? cout : 0) * 2 * sizeof(float)) {
         lf::set_error("lf_conv2d_stats: tile_part %zu bytes < %lld tiles x %d channels x 8",
                       tile_part_bytes, tiles, cout);
@@ -1606,7 +1659,7 @@ int lf_conv2d_bnbwd_f32(const float* x, const float* w, float* y, int n, int cin
                         const float* mask_scale, const float* mask_shift, int mask_relu,
                         float* tile_part, size_t tile_part_bytes, lf_stream_t stream) {
     LF_REQUIRE(tile_part && mask_y && mask_scale && mask_shift, "lf_conv2d_bnbwd: null buffer");
-    const long long tiles = lf_conv2d_stats_tiles(n, h, wd, cout);
+    const long long tiles = lf_conv2d_stats_tiles(n, cin, h, wd, cout);
     if (tile_part_bytes < (size_t)tiles * (size_t)(cout > 0 ? cout : 0) * 2 * sizeof(float)) {
         lf::set_error("lf_conv2d_bnbwd: tile_part %zu bytes < %lld tiles x %d channels x 8",
                       tile_part_bytes, tiles, cout);

@@ -28,6 +28,8 @@ SHAPES = [  # n, cin, cout, h, w, k
     (2, 32, 64, 32, 32, 3),
     (2, 64, 128, 56, 56, 3),   # 28x8 tiles
     (1, 128, 256, 28, 28, 3),  # masked 28-wide tiles, two cout tiles
+    (3, 128, 256, 28, 28, 3),  # two-image strips (H = 28 is 3.5 tiles) + a lone last image
+    (4, 64, 128, 28, 28, 1),   # 1x1 on strips
     (2, 16, 16, 20, 12, 3),    # ragged: Cout < 32, partial tiles
     (2, 5, 7, 9, 11, 3),       # everything ragged
     (2, 32, 64, 32, 32, 1),    # 1x1 projection
