@@ -71,6 +71,12 @@ int lf_autocontrast_lut(const int32_t* hist, const double* cutoff, uint8_t* lut,
 int lf_lut_apply_u8(const uint8_t* in, const uint8_t* lut, uint8_t* out, int n, int h, int w,
                     lf_stream_t stream);
 
+/* Batch assembly from a device-resident dataset (the loader's cache=True, sequence.py:47-58,
+ * kept in HBM instead of host RAM): dst[i][:] = src[index[i]][:] for rows of row_bytes bytes
+ * (one resized uint8 image each).  index: int32 device array, values the caller has checked. */
+int lf_gather_rows_u8(const uint8_t* src, const int32_t* index, uint8_t* dst, int n_out,
+                      size_t row_bytes, lf_stream_t stream);
+
 /* ImageAugmenter.flip (image_augmenter.py:20-31): mode[n] = 0 -> FLIP_LEFT_RIGHT,
  * 1 -> FLIP_TOP_BOTTOM. */
 int lf_flip_u8(const uint8_t* in, uint8_t* out, const int32_t* mode, int n, int h, int w,

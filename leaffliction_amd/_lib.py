@@ -27,6 +27,7 @@ SIGNATURES = {
     "lf_hist_u8": [P, P, c_int, c_int, c_int, P],
     "lf_autocontrast_lut": [P, P, P, c_int, P],
     "lf_lut_apply_u8": [P, P, P, c_int, c_int, c_int, P],
+    "lf_gather_rows_u8": [P, P, P, c_int, c_size_t, P],
     "lf_flip_u8": [P, P, P, c_int, c_int, c_int, P],
     "lf_noise_wrap_add_u8": [P, P, P, c_size_t, P],
     "lf_noise_philox_add_u8": [P, P, c_size_t, c_u64, c_float, P],

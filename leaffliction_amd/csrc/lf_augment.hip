@@ -654,6 +654,29 @@ __global__ __launch_bounds__(kBlock) void gauss_blur_kernel(const uint8_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------
+// batch gather: dst[i] = src[index[i]] for rows of row_bytes bytes (device-resident dataset)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const uint8_t* __restrict__ src,
+                                                             const int32_t* __restrict__ index,
+                                                             uint8_t* __restrict__ dst,
+                                                             size_t row_bytes, int vec16) {
+    const unsigned i = blockIdx.y;
+    const uint8_t* s = src + (size_t)index[i] * row_bytes;
+    uint8_t* d = dst + (size_t)i * row_bytes;
+    if (vec16) {  // rows are multiples of 16 bytes and both bases 16-byte aligned
+        const uint4* s4 = reinterpret_cast<const uint4*>(s);
+        uint4* d4 = reinterpret_cast<uint4*>(d);
+        const size_t n16 = row_bytes / 16;
+        for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < n16; q += (size_t)gridDim.x * kBlock)
+            d4[q] = s4[q];
+    } else {
+        for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < row_bytes;
+             q += (size_t)gridDim.x * kBlock)
+            d[q] = s[q];
+    }
+}
+
 // Fast path for the usual kernels (odd ksize 3..15, every Q8.8 tap <= 255).  Same arithmetic as
 // gauss_blur_kernel, reorganised for the integer dot-product units:
 //   1. the (TY+2r) x (TXP+2r) patch is loaded once (12-byte unaligned groups), de-interleaved
@@ -944,6 +967,18 @@ int lf_lut_apply_u8(const uint8_t* in, const uint8_t* lut, uint8_t* out, int n, 
         lut_apply_scalar_kernel<<<dim3(splits, n), kBlock, 0, s>>>(in, lut, out, nbytes);
     }
     return lf::check_launch("lf_lut_apply");
+}
+
+int lf_gather_rows_u8(const uint8_t* src, const int32_t* index, uint8_t* dst, int n_out,
+                      size_t row_bytes, lf_stream_t stream) {
+    LF_REQUIRE(src && index && dst, "lf_gather_rows: null buffer");
+    LF_REQUIRE(n_out > 0 && n_out <= 65535 && row_bytes > 0, "lf_gather_rows: bad n_out=%d row_bytes=%zu",
+               n_out, row_bytes);
+    const int vec16 = row_bytes % 16 == 0 &&
+                      ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0;
+    dim3 grid(lf::stream_grid(vec16 ? row_bytes / 16 : row_bytes, kBlock, 16), n_out);
+    gather_rows_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(src, index, dst, row_bytes, vec16);
+    return lf::check_launch("lf_gather_rows");
 }
 
 int lf_flip_u8(const uint8_t* in, uint8_t* out, const int32_t* mode, int n, int h, int w,

@@ -514,7 +514,10 @@ class LeafCNN:
 
     def _targets(self, by) -> Tuple[torch.Tensor, torch.Tensor]:
         """labels (one-hot [B,C] or sparse [B]) -> (smoothed one-hot f32 on device, indices)."""
-        by = torch.as_tensor(np.asarray(by)).to(self.device)
+        if not isinstance(by, torch.Tensor):
+            # pinned staging + asynchronous copy: a pageable upload would drain the stream
+            by = torch.as_tensor(np.ascontiguousarray(by)).pin_memory()
+        by = by.to(self.device, non_blocking=True)
         if by.dim() == 1:
             idx = by.long()
             yt = torch.nn.functional.one_hot(idx, self.num_classes).float()

@@ -93,6 +93,21 @@ def autocontrast_u8(x: torch.Tensor, cutoff: torch.Tensor) -> torch.Tensor:
     return lut_apply_u8(x, autocontrast_lut(hist_u8(x), cutoff))
 
 
+def gather_images_u8(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """Batch = src[index] for a device-resident uint8 dataset [M,H,W,3]; index int32 [B] (device)."""
+    m, h, w = _hwc(src, "gather.src")
+    _chk(index, _I32, "gather.index", 1)
+    b = index.shape[0]
+    if b == 0:
+        raise ValueError("gather.index: empty batch")
+    out = torch.empty((b, h, w, 3), dtype=_U8, device=src.device)
+    for k in range(0, b, 65535):
+        kk = min(b, k + 65535)
+        _lib.call("lf_gather_rows_u8", src.data_ptr(), index[k:kk].data_ptr(), out[k:kk].data_ptr(),
+                  kk - k, h * w * 3, _stream())
+    return out
+
+
 def flip_u8(x: torch.Tensor, mode: torch.Tensor) -> torch.Tensor:
     """mode[n] = 0: FLIP_LEFT_RIGHT, 1: FLIP_TOP_BOTTOM."""
     n, h, w = _hwc(x, "flip.x")

@@ -164,3 +164,29 @@ def test_fit_learns_separable_classes(cuda, tmp_path):
     assert variant in ("base", "ema")
     cm = json.loads((tmp_path / "out/confusion_matrix.json").read_text())["matrix"]
     assert cm[0][0] + cm[1][1] == len(va)      # after best-variant selection: all correct
+
+
+def test_device_resident_cache_batches_equal_host_loader(cuda, tmp_path):
+    """cache=True keeps the resized uint8 dataset in HBM and assembles batches with the gather
+    kernel: same pixels, same labels, same shuffling and rank slicing as the uncached loader."""
+    import torch
+    from leaffliction_amd.dataio.manifest import load_manifest, select_items, build_label_mapping
+    from leaffliction_amd.dataio.sequence import ManifestSequence
+    colour_tree(tmp_path / "images", 14, 40)   # native 40x40 -> resized to 32 on the GPU
+    man = tmp_path / "m.json"
+    write_split_manifest(tmp_path / "images", man)
+    items = load_manifest(man)
+    tr = select_items(items, "train")
+    l2i = build_label_mapping(tr)
+    for world in (1, 2):
+        for rank in range(world):
+            a = ManifestSequence(tr, l2i, 32, 6, True, 7, num_classes=2, one_hot=True, rank=rank, world=world)
+            b = ManifestSequence(tr, l2i, 32, 6, True, 7, num_classes=2, one_hot=True, cache=True,
+                                 rank=rank, world=world)
+            assert b._cache_dev is not None and tuple(b._cache_dev.shape) == (len(tr), 32, 32, 3)
+            for epoch in range(2):
+                for i in range(len(a)):
+                    (xa, ya), (xb, yb) = a[i], b[i]
+                    assert xb.is_cuda and torch.equal(xa, xb) and np.array_equal(ya, yb)
+                a.on_epoch_end()
+                b.on_epoch_end()
