@@ -156,3 +156,96 @@ def test_balancer_task_list_matches_reference(tmp_path):
     assert [(Path(t["source_img"]).name, Path(t["output_path"]).name, t["transform_name"], t["seed"])
             for t in tasks] == [(t["source"], t["output"], t["transform"], t["seed"])
                                 for t in gold["tasks"]]
+
+
+def test_split_matches_reference_golden(tmp_path):
+    """leaffliction_amd.cli.split vs the reference's split functions (tests/golden/
+    make_golden_split.py): scan order, both allocation strategies, seeded split maps, summary
+    rows, manifest schema, and the CLI end to end."""
+    import csv
+    import json
+    from pathlib import Path
+    from leaffliction_amd.cli import split as S
+    from leaffliction_amd.dataio.manifest import load_manifest, select_items
+    gold = json.loads((Path(__file__).parent / "golden" / "split_golden.json").read_text())
+    root = tmp_path / "images"
+    for plant, classes in gold["layout"].items():
+        for cls, n in classes.items():
+            d = root / plant / cls
+            d.mkdir(parents=True)
+            for i in range(n):
+                (d / f"image ({i + 1}).{'JPG' if i % 2 else 'jpg'}").write_bytes(b"")
+            (d / "notes.txt").write_text("x")
+            (d / "picture.png").write_bytes(b"")
+    images = S.scan_dataset(root)
+    assert [im.rel_id for im in images] == gold["scan"]
+    by_label = {}
+    for im in images:
+        by_label.setdefault(im.label, []).append(im)
+    counts = {k: len(v) for k, v in by_label.items()}
+    assert counts == gold["counts"]
+    allocs = {"ratio_0.2": S.allocate_validation_by_ratio(counts, 0.2),
+              "ratio_0.5": S.allocate_validation_by_ratio(counts, 0.5),
+              "min_val_6": S.allocate_validation_counts(counts, 6),
+              "min_val_100": S.allocate_validation_counts(counts, 100),
+              "min_val_0": S.allocate_validation_counts(counts, 0)}
+    for case in gold["cases"]:
+        alloc = allocs[case["name"]]
+        assert alloc == case["alloc"], case["name"]
+        sm = S.build_split_map(by_label, alloc, case["seed"])
+        assert sm == case["split"], (case["name"], case["seed"])
+        assert [[str(v) for v in row] for row in S.summary_rows(by_label, sm)] == case["summary"]
+    # CLI: defaults are ratio 0.2 / seed 32 -> the first golden case
+    out = tmp_path / "out"
+    S.main(["--src", str(root), "--out", str(out), "--out-manifest", str(out / "manifest_split.json")])
+    doc = json.loads((out / "manifest_split.json").read_text())
+    assert sorted(doc["meta"]) == gold["manifest_meta_keys"] and doc["meta"]["strategy"] == gold["manifest_strategy"]
+    assert list(doc["items"][0]) == gold["manifest_item_keys"] and doc["meta"]["min_val"] == 20
+    assert {it["id"]: it["split"] for it in doc["items"]} == gold["cases"][0]["split"]
+    with (out / "split_summary.csv").open() as f:
+        assert list(csv.reader(f)) == gold["cases"][0]["summary"]
+    items = load_manifest(out / "manifest_split.json")      # and it feeds the train entrypoint's loader
+    assert len(select_items(items, "val")) == 5 and len(select_items(items, "train")) == 23
+    import pytest
+    with pytest.raises(SystemExit) as e:
+        S.main(["--src", str(tmp_path / "missing")])
+    assert e.value.code == 1
+    with pytest.raises(ValueError):
+        S.allocate_validation_by_ratio(counts, 1.0)
+
+
+def test_distribution_matches_reference_golden(tmp_path, monkeypatch):
+    """leaffliction_amd.cli.Distribution / utils.distribution vs the reference's functions."""
+    import csv
+    import json
+    from pathlib import Path
+    from leaffliction_amd.cli import Distribution as D
+    from leaffliction_amd.utils.distribution import count_images, merge_csv
+    gold = json.loads((Path(__file__).parent / "golden" / "split_golden.json").read_text())
+    root = tmp_path / "images"
+    for plant, classes in gold["layout"].items():
+        for cls, n in classes.items():
+            d = root / plant / cls
+            d.mkdir(parents=True)
+            for i in range(n):
+                (d / f"image ({i + 1}).{'JPG' if i % 2 else 'jpg'}").write_bytes(b"")
+            (d / "notes.txt").write_text("x")
+    g = gold["distribution"]
+    assert [list(r) for r in count_images(root, None)] == g["rows_all"]
+    assert [list(r) for r in count_images(root, {"Grape"})] == g["rows_grape"]
+    p = tmp_path / "d.csv"
+    p.write_text("plant,class,count\nApple,healthy,99\nPear,ripe,4\n")
+    merge_csv(count_images(root, {"Grape"}), p)
+    with p.open() as f:
+        assert list(csv.reader(f)) == g["merged"]
+    p2 = tmp_path / "e.csv"
+    p2.write_text("a,b\n1,2\n")
+    merge_csv(count_images(root, None), p2)
+    with p2.open() as f:
+        assert list(csv.reader(f)) == g["fresh"]
+    monkeypatch.chdir(tmp_path)
+    D.main([str(root), "--no-plots"])
+    with (tmp_path / "artifacts/plots/distribution.csv").open() as f:
+        assert list(csv.reader(f)) == g["fresh"]
+    D.main([str(root), "--plants", "Nope", "--no-plots"])       # unknown plant: logs, returns
+    D.main([str(tmp_path / "missing"), "--no-plots"])           # missing root: logs, returns
