@@ -136,8 +136,6 @@ def augment_throughput(dev, n=4096, iters=5):
     resident in HBM (BASELINE configs[2]; op mix 1/6 each like the balancer's plan).  Host-side
     parameter tables are built outside the timed region (they are inputs); JPEG decode/encode
     is excluded.  GB/s = algorithmic bytes (input once + output once) / time."""
-    import math as _m
-
     import numpy as np
 
     from leaffliction_amd import ops

@@ -1,9 +1,8 @@
 """Host-side launchers for the leaf_cnn kernels of libleafhip.so (fp32, NCHW)."""
 from __future__ import annotations
 
-from typing import Optional
-
 import os
+from typing import Optional
 
 import torch
 

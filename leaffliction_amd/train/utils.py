@@ -12,7 +12,7 @@ import logging
 import math
 from datetime import datetime, timezone
 from pathlib import Path
-from typing import Any, Callable, Dict, List, Optional, Tuple
+from typing import Any, Dict, List, Optional, Tuple
 
 from ..utils.confusion_matrix import (_gather_predictions_and_labels, compute_confusion_counts,
                                       save_confusion_json)
