@@ -74,7 +74,7 @@ class KernelTimer:
             lib = timer.lib_mod.load()
             if name in ("lf_conv2d_f32", "lf_conv2d_stats_f32", "lf_conv2d_bnbwd_f32"):
                 n, cin, h, w, cout, k = args[3:9]
-                kname = FWD_NAMES[lib.lf_conv2d_variant(h, w, cout)].replace("T", str(k * k))
+                kname = FWD_NAMES[lib.lf_conv2d_variant(h, w, cout, k)].replace("T", str(k * k))
             else:
                 n, cin, h, w, cout, k = args[8:14] if name == "lf_conv2d_wgrad_bn_f32" else args[2:8]
                 kname = (WG_NAMES3 if k == 3 else WG_NAMES1)[lib.lf_conv2d_wgrad_variant(n, cin, h, w, cout, k)]

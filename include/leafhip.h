@@ -182,7 +182,7 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
 
 /* Which tile variant (template instantiation) the dispatcher picks for a shape — used by
  * bench.py to attribute measured launch durations to kernel names. */
-int lf_conv2d_variant(int h, int wd, int cout);
+int lf_conv2d_variant(int h, int wd, int cout, int ksize);
 int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout, int ksize);
 
 /* Conv2D followed by BatchNormalization in training mode (cnn.py:28-33,40-45): the same
@@ -191,7 +191,7 @@ int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout, int ksize);
  * (device, [cout], may be null) only conditions the sum of squares; pass the layer's moving
  * mean.  lf_bn_train_stats_tiles_f32 (below) turns the tile sums into the batch statistics, so
  * the activation is not read again. */
-long long lf_conv2d_stats_tiles(int n, int cin, int h, int w, int cout);
+long long lf_conv2d_stats_tiles(int n, int cin, int h, int w, int cout, int ksize);
 int lf_conv2d_stats_f32(const float* x, const float* w, float* y, int n, int cin, int h, int wd,
                         int cout, int ksize, const float* in_scale, const float* in_shift,
                         int in_relu, const float* pivot, float* tile_part, size_t tile_part_bytes,

@@ -41,9 +41,9 @@ SIGNATURES = {
     "lf_resample_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int,
                        c_int, P],
     "lf_conv2d_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P],
-    "lf_conv2d_variant": [c_int, c_int, c_int],
+    "lf_conv2d_variant": [c_int, c_int, c_int, c_int],
     "lf_conv2d_wgrad_variant": [c_int, c_int, c_int, c_int, c_int, c_int],
-    "lf_conv2d_stats_tiles": [c_int, c_int, c_int, c_int, c_int],
+    "lf_conv2d_stats_tiles": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_stats_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_size_t, P],
     "lf_conv2d_bnbwd_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P,
                             c_size_t, P],

@@ -1561,12 +1561,16 @@ extern "C" {
 
 int lf_conv2d_wgrad_bn_supported(int n, int cin, int h, int wd, int cout, int ksize);
 
-int lf_conv2d_variant(int h, int wd, int cout) {
+int lf_conv2d_variant(int h, int wd, int cout, int ksize) {
     int best = 0;
     long long bw = -1;
     for (int v = 0; v < kNumFwd; ++v) {
         const long long c = padded_work(kFwdVariants[v], h, wd, cout);
-        if (bw < 0 || c < bw) {
+        // 1x1 convolutions are bandwidth-bound: among equally padded tilings take the widest
+        // cout tile, so that the input tile is read once instead of once per cout tile
+        const bool better = bw < 0 || c < bw ||
+                            (ksize == 1 && c == bw && kFwdVariants[v].ct > kFwdVariants[best].ct);
+        if (better) {
             bw = c;
             best = v;
         }
@@ -1593,7 +1597,7 @@ static int conv2d_launch(const char* who, const float* x, const float* w, float*
     LF_REQUIRE(n <= 65535, "%s: batch too large for grid.z", who);
     LF_REQUIRE((size_t)cin * h * wd < (1ull << 30) && (size_t)cin * ksize * ksize * cout < (1ull << 30),
                "%s: per-image tensor too large for 32-bit offsets", who);
-    const int best = lf_conv2d_variant(h, wd, cout);
+    const int best = lf_conv2d_variant(h, wd, cout, ksize);
     const FwdVariant& v = kFwdVariants[best];
     ConvArgs a;
     a.x = x; a.w = w; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
@@ -1631,9 +1635,9 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
                          accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
-long long lf_conv2d_stats_tiles(int n, int cin, int h, int wd, int cout) {
+long long lf_conv2d_stats_tiles(int n, int cin, int h, int wd, int cout, int ksize) {
     if (n <= 0 || cin <= 0 || h <= 0 || wd <= 0 || cout <= 0) return 0;
-    const int best = lf_conv2d_variant(h, wd, cout);
+    const int best = lf_conv2d_variant(h, wd, cout, ksize);
     const FwdVariant& v = kFwdVariants[best];
     const int stack = conv_stack(best, n, cin, h, wd, cout);
     return (long long)((n + stack - 1) / stack) * ((wd + v.tw - 1) / v.tw) * ((stack * h + v.th - 1) / v.th);
@@ -1644,7 +1648,7 @@ int lf_conv2d_stats_f32(const float* x, const float* w, float* y, int n, int cin
                         int in_relu, const float* pivot, float* tile_part, size_t tile_part_bytes,
                         lf_stream_t stream) {
     LF_REQUIRE(tile_part, "lf_conv2d_stats: null tile_part");
-    const long long tiles = lf_conv2d_stats_tiles(n, cin, h, wd, cout);
+    const long long tiles = lf_conv2d_stats_tiles(n, cin, h, wd, cout, ksize);
     if (tile_part_bytes < (size_t)tiles * (size_t)(cout > 0 ? cout : 0) * 2 * sizeof(float)) {
         lf::set_error("lf_conv2d_stats: tile_part %zu bytes < %lld tiles x %d channels x 8",
                       tile_part_bytes, tiles, cout);
@@ -1659,7 +1663,7 @@ int lf_conv2d_bnbwd_f32(const float* x, const float* w, float* y, int n, int cin
                         const float* mask_scale, const float* mask_shift, int mask_relu,
                         float* tile_part, size_t tile_part_bytes, lf_stream_t stream) {
     LF_REQUIRE(tile_part && mask_y && mask_scale && mask_shift, "lf_conv2d_bnbwd: null buffer");
-    const long long tiles = lf_conv2d_stats_tiles(n, cin, h, wd, cout);
+    const long long tiles = lf_conv2d_stats_tiles(n, cin, h, wd, cout, ksize);
     if (tile_part_bytes < (size_t)tiles * (size_t)(cout > 0 ? cout : 0) * 2 * sizeof(float)) {
         lf::set_error("lf_conv2d_bnbwd: tile_part %zu bytes < %lld tiles x %d channels x 8",
                       tile_part_bytes, tiles, cout);

@@ -93,7 +93,7 @@ def conv2d_bn_stats(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, gamma, bet
         if tuple(out.shape) != (n, cout, h, w):
             raise ValueError("conv2d_bn_stats.out: shape mismatch")
     lib = _lib.load()
-    tiles = lib.lf_conv2d_stats_tiles(n, cin, h, w, cout)
+    tiles = lib.lf_conv2d_stats_tiles(n, cin, h, w, cout, ksize)
     tp = _workspace(tiles * cout * 8, x.device, slot=1)
     _lib.call("lf_conv2d_stats_f32", x.data_ptr(), w_iko.data_ptr(), out.data_ptr(), n, cin, h, w,
               cout, ksize, _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, mmean.data_ptr(),
@@ -122,7 +122,7 @@ def conv2d_bnbwd(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, mask_y: torch
     cout = w_iko.shape[2]
     if tuple(out.shape) != (n, cout, h, w) or mask_y.shape != out.shape or tuple(stats.shape) != (4, cout):
         raise ValueError("conv2d_bnbwd: shape mismatch")
-    tiles = _lib.load().lf_conv2d_stats_tiles(n, cin, h, w, cout)
+    tiles = _lib.load().lf_conv2d_stats_tiles(n, cin, h, w, cout, ksize)
     tp = _workspace(tiles * cout * 8, x.device, slot=1)
     _lib.call("lf_conv2d_bnbwd_f32", x.data_ptr(), w_iko.data_ptr(), out.data_ptr(), n, cin, h, w,
               cout, ksize, 1 if accumulate else 0, mask_y.data_ptr(), stats[2].data_ptr(),
