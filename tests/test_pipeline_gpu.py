@@ -190,3 +190,39 @@ def test_device_resident_cache_batches_equal_host_loader(cuda, tmp_path):
                     assert xb.is_cuda and torch.equal(xa, xb) and np.array_equal(ya, yb)
                 a.on_epoch_end()
                 b.on_epoch_end()
+
+
+def test_five_step_workflow_distribution_augment_split_train_predict(cuda, tmp_path, monkeypatch):
+    """The reference README's workflow end to end with this repo's entrypoints only:
+    Distribution -> Augmentation (balance) -> split -> train -> predict --evaluate."""
+    import csv
+    from leaffliction_amd.cli import Augmentation, Distribution, predict as predict_cli, split, train as train_cli
+    monkeypatch.chdir(tmp_path)
+    root = tmp_path / "images" / "Apple"
+    rng = np.random.RandomState(3)
+    for cls, colour, n in (("Apple_healthy", (40, 170, 60), 14), ("Apple_rust", (170, 80, 40), 6)):
+        d = root / cls
+        d.mkdir(parents=True)
+        for i in range(n):
+            img = np.clip(np.array(colour)[None, None] + rng.normal(0, 12, (72, 72, 3)), 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(d / f"image ({i + 1}).JPG", quality=95)
+    Distribution.main([str(tmp_path / "images"), "--no-plots"])
+    with (tmp_path / "artifacts/plots/distribution.csv").open() as f:
+        assert list(csv.reader(f))[1:] == [["Apple", "Apple_healthy", "14"], ["Apple", "Apple_rust", "6"]]
+    Augmentation.main([str(tmp_path / "images"), "-seed", "42"])
+    aug = tmp_path / "artifacts/augmented_directory"
+    counts = {d.name: len(list(d.glob("*.JPG"))) for d in (aug / "Apple").iterdir()}
+    assert counts == {"Apple_healthy": 14, "Apple_rust": 14}          # balanced up to the largest class
+    man = tmp_path / "artifacts/datasets/manifest_split.json"
+    split.main(["--src", str(aug), "--out", str(man.parent), "--out-manifest", str(man), "--val-ratio", "0.25"])
+    items = json.loads(man.read_text())["items"]
+    assert len(items) == 28 and sum(it["split"] == "val" for it in items) == 8
+    train_cli.main(["--manifest", str(man), "--epochs", "4", "--batch-size", "8", "--img-size", "32",
+                    "--no-mixed-precision", "--seed", "1", "--tiny"])
+    mdir = tmp_path / "artifacts/models"
+    hist = json.loads((mdir / "history.json").read_text())
+    assert hist["val_accuracy"][-1] >= 0.75
+    predict_cli.main([str(aug), "-batch", "--evaluate", "--manifest", str(man), "--split", "val",
+                      "--sample-size", "8", "--target-acc", "0.7", "--max-attempts", "3", "-learnings", str(mdir)])
+    ev = json.loads((tmp_path / "artifacts/prediction_output/evaluation/evaluation_results.json").read_text())
+    assert ev["metrics"]["accuracy"] >= 0.7 and ev["evaluation_info"]["valid_predictions"] == 8
