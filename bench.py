@@ -199,6 +199,24 @@ def augment_throughput(dev, n=4096, iters=5):
     return out
 
 
+def inference_throughput(model, dev, batch=1024, iters=5):
+    """Forward pass only (predict.py's batch mode, BASELINE configs[4] shape: 1024 images per GPU;
+    fp32 here): uint8 batch resident in HBM -> pack/normalise -> conv stack (inference
+    BatchNorm folded into the consumers' prologues) -> softmax -> argmax."""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randint(0, 256, (batch, IMG, IMG, 3), dtype=torch.uint8, generator=g).to(dev)
+    model.predict_device(x[:64])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        labels = model.predict_device(x).argmax(-1)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / iters
+    return {"images_per_sec": round(batch / sec, 1), "batch": batch, "dtype": "f32",
+            "tflops": round(TRAIN_GFLOP_PER_IMG / 3.0 * batch / sec / 1e3, 2),
+            "labels_checksum": int(labels.sum().item())}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +342,8 @@ def main() -> None:
             "step_tflops": round(TRAIN_GFLOP_PER_IMG * n * args.steps / elapsed / 1e3, 2),
             "final_loss": round(final_loss, 4),
         }
+        if world == 1:
+            out["inference"] = inference_throughput(model, dev)
         if not args.no_augment and world == 1:
             del model
             torch.cuda.empty_cache()
