@@ -112,6 +112,14 @@ def test_train_and_predict_cli_config_c1(cuda, tmp_path, monkeypatch):
     assert np.array(cm["matrix"]).sum() == n_val and cm["labels"] == meta["labels"]
     # missing manifest: logs and returns (exit code 0), like the reference
     train_cli.main(["--manifest", str(tmp_path / "nope.json"), "--epochs", "1"])
+    # --fast preset (Adam, sparse labels, cached loader) and the small / tiny scales run too
+    for extra in (["--fast", "--small"], ["--tiny", "--no-normalization"]):
+        train_cli.main(["--manifest", str(man), "--epochs", "1", "--batch-size", "8", "--img-size", "64",
+                        "--no-mixed-precision", "--seed", "3"] + extra)
+        h2 = json.loads((mdir / "history.json").read_text())
+        assert len(h2["loss"]) == 1 and np.isfinite(h2["loss"][0]) and np.isfinite(h2["val_loss"][0])
+    train_cli.main(["--manifest", str(man), "--epochs", "2", "--batch-size", "8", "--img-size", "64",
+                    "--no-mixed-precision", "--seed", "42"])   # restore the base model for predict
 
     # predict: batch mode -> JSON schema
     predict_cli.main([str(tmp_path / "images/Apple/Apple_rust"), "-batch", "-learnings", str(mdir),
