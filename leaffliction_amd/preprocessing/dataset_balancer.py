@@ -16,7 +16,7 @@ import shutil
 from collections import defaultdict
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import numpy as np
 
@@ -108,52 +108,73 @@ class DatasetBalancer:
         return tasks
 
     # ------------------------------------------------------------------ GPU execution
-    def _run_chunk(self, chunk: List[dict], pool: ThreadPoolExecutor) -> None:
+    # A chunk goes through three stages: JPEG decode (host threads), parameter draws + HIP
+    # kernels (this thread), JPEG encode (host threads).  The stages of consecutive chunks
+    # overlap: chunk i+1 is being decoded and chunk i-1 encoded while chunk i is on the GPU.
+    @staticmethod
+    def _decode(task):
+        try:
+            return ImageLoader.load_as_array(task["source_img"])
+        except Exception as e:  # noqa: BLE001 — the reference counts any failure
+            logger.error(f"Failed to process {task['source_img']} - {e}")
+            return None
+
+    @staticmethod
+    def _encode(item):
+        arr, path = item
+        try:
+            ImageLoader.save_array(arr, path)
+            return True
+        except Exception as e:  # noqa: BLE001
+            logger.error(f"Failed: {path} - {e}")
+            return False
+
+    @staticmethod
+    def _draw_seeded(job):
+        """One task's parameters from its own seeded generators (same values as seeding the
+        process-global streams with that seed, which is what the reference's worker does)."""
+        op, w, h, seed = job
+        return draw_params(op, w, h, random.Random(seed), np.random.RandomState(seed))
+
+    def _gpu_stage(self, chunk: List[dict], images: List[Optional[np.ndarray]], pool) -> List[tuple]:
+        """Draw every task's parameters (a fresh seeded RNG per task, like the reference's
+        `_process_single_transformation`; seeded tasks are independent and drawn on the host
+        threads, seed 0 = "unseeded" continues the global streams in order), run the ops
+        batched by (transform, size), return (pixels, output_path) pairs for the encoder."""
         import torch
-
-        def decode(task):
-            try:
-                return ImageLoader.load_as_array(task["source_img"])
-            except Exception as e:  # noqa: BLE001 — the reference counts any failure
-                logger.error(f"Failed to process {task['source_img']} - {e}")
-                return None
-
-        images = list(pool.map(decode, chunk))
         groups: Dict[tuple, List[int]] = defaultdict(list)
         params: List[dict] = [None] * len(chunk)  # type: ignore[list-item]
+        drawing = {}
         for k, (task, img) in enumerate(zip(chunk, images)):
             if img is None:
                 self.failed += 1
                 continue
-            # _process_single_transformation: a fresh ImageAugmenter(seed) per task
-            seed = task["seed"]
-            if seed:
-                random.seed(seed)
-                np.random.seed(seed)
             h, w, _ = img.shape
-            params[k] = draw_params(task["transform_name"], w, h)
+            if task["seed"]:
+                drawing[k] = pool.submit(self._draw_seeded, (task["transform_name"], w, h, task["seed"]))
+            else:
+                params[k] = draw_params(task["transform_name"], w, h)
             groups[(task["transform_name"], h, w)].append(k)
-        results: Dict[int, np.ndarray] = {}
+        for k, fut in drawing.items():
+            params[k] = fut.result()
+        out: List[tuple] = []
         for (op, _h, _w), ks in groups.items():
             try:
                 x = torch.from_numpy(np.stack([images[k] for k in ks])).cuda()
-                outs = apply_batch(op, x, [params[k] for k in ks])
-                for k, o in zip(ks, outs):
-                    results[k] = o.cpu().numpy()
+                res = apply_batch(op, x, [params[k] for k in ks])
+                if op != "rotate":   # same-sized results: one device->host copy for the group
+                    host = torch.stack(res).cpu().numpy()
+                    out.extend((host[j], chunk[k]["output_path"]) for j, k in enumerate(ks))
+                else:
+                    out.extend((o.cpu().numpy(), chunk[k]["output_path"]) for o, k in zip(res, ks))
             except Exception as e:  # noqa: BLE001
                 logger.error(f"Failed batch {op}: {e}")
                 self.failed += len(ks)
+        return out
 
-        def encode(k):
-            try:
-                ImageLoader.save_array(results[k], chunk[k]["output_path"])
-                return True
-            except Exception as e:  # noqa: BLE001
-                logger.error(f"Failed: {chunk[k]['output_path']} - {e}")
-                return False
-
-        for ok in pool.map(encode, list(results)):
-            if ok:
+    def _finish_encodes(self, futures) -> None:
+        for f in futures:
+            if f.result():
                 self.completed += 1
             else:
                 self.failed += 1
@@ -167,13 +188,21 @@ class DatasetBalancer:
         total = len(self.tasks)
         logger.info(f"Starting GPU augmentation: {total} images to generate")
         state = (random.getstate(), np.random.get_state())
+        chunks = [self.tasks[b:b + CHUNK] for b in range(0, total, CHUNK)]
         with ThreadPoolExecutor(max_workers=self.workers) as pool:
-            for b in range(0, total, CHUNK):
-                self._run_chunk(self.tasks[b:b + CHUNK], pool)
+            decoding = [pool.submit(self._decode, t) for t in chunks[0]] if chunks else []
+            encoding: list = []
+            for i, chunk in enumerate(chunks):
+                images = [f.result() for f in decoding]
+                decoding = [pool.submit(self._decode, t) for t in chunks[i + 1]] if i + 1 < len(chunks) else []
+                results = self._gpu_stage(chunk, images, pool)
+                self._finish_encodes(encoding)
+                encoding = [pool.submit(self._encode, r) for r in results]
                 done = self.completed + self.failed
                 if done % 500 < CHUNK and done:
                     logger.info(f"Progress: {done}/{total} ({done / total * 100:.1f}%) - "
                                 f"{self.completed} success, {self.failed} failed")
+            self._finish_encodes(encoding)
         random.setstate(state[0])
         np.random.set_state(state[1])
         logger.info(f"Augmentation complete: {self.completed} images generated, {self.failed} failed")

@@ -24,29 +24,32 @@ TRANSFORMATIONS = ["flip", "rotate", "skew", "shear", "crop", "distortion"]
 NOISE_LEVEL = 5
 
 
-def draw_params(op: str, width: int, height: int) -> Dict[str, Any]:
-    """Draw one op's random parameters with the reference's RNG calls, in its order."""
+def draw_params(op: str, width: int, height: int, py_rng=random, np_rng=np.random) -> Dict[str, Any]:
+    """Draw one op's random parameters with the reference's RNG calls, in its order.  By default
+    from the process-global `random` / `np.random` streams (what the reference seeds per task);
+    `random.Random(seed)` / `np.random.RandomState(seed)` instances produce the same values as
+    seeding the globals with `seed`, and let independent tasks be drawn on separate threads."""
     if op == "flip":  # image_augmenter.py:23
-        return {"mode": 0 if random.choice([True, False]) else 1}
+        return {"mode": 0 if py_rng.choice([True, False]) else 1}
     if op == "rotate":  # :36
-        return {"angle": random.uniform(-30, 30)}
+        return {"angle": py_rng.uniform(-30, 30)}
     if op == "skew":  # :48-59
-        f = random.uniform(0.05, 0.15)
+        f = py_rng.uniform(0.05, 0.15)
         return {"coeffs": [1 + f, 0, -f * width, 0, 1 + f, -f * height, 0, 0]}
     if op == "shear":  # :77-82
-        s = random.uniform(-0.2, 0.2)
-        if random.choice([True, False]):
+        s = py_rng.uniform(-0.2, 0.2)
+        if py_rng.choice([True, False]):
             return {"coeffs": [1, s, 0, 0, 1, 0, 0, 0]}
         return {"coeffs": [1, 0, 0, s, 1, 0, 0, 0]}
     if op == "crop":  # :101-107
-        r = random.uniform(0.8, 0.95)
+        r = py_rng.uniform(0.8, 0.95)
         nw, nh = int(width * r), int(height * r)
-        left = random.randint(0, width - nw)
-        top = random.randint(0, height - nh)
+        left = py_rng.randint(0, width - nw)
+        top = py_rng.randint(0, height - nh)
         return {"box": (left, top, nw, nh)}
     if op == "distortion":  # :121, :127 — np.random first, then random.uniform
-        noise = np.random.normal(0, NOISE_LEVEL, (height, width, 3))
-        return {"noise": noise, "cutoff": random.uniform(0, 2)}
+        noise = np_rng.normal(0, NOISE_LEVEL, (height, width, 3))
+        return {"noise": noise, "cutoff": py_rng.uniform(0, 2)}
     raise AttributeError(op)
 
 
