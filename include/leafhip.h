@@ -181,7 +181,8 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
                   int accumulate, lf_stream_t stream);
 
 /* Which tile variant (template instantiation) the dispatcher picks for a shape — used by
- * bench.py to attribute measured launch durations to kernel names. */
+ * bench.py to attribute measured launch durations to kernel names.  (For H = 28 the 28x8
+ * variant walks two images as one strip; lf_conv2d_stats_tiles accounts for that.) */
 int lf_conv2d_variant(int h, int wd, int cout, int ksize);
 int lf_conv2d_wgrad_variant(int n, int cin, int h, int wd, int cout, int ksize);
 
@@ -226,7 +227,8 @@ int lf_conv2d_wgrad_reduce_f32(void* workspace, float* dw, int n, int cin, int h
 /* Weight gradient whose dY operand is a BatchNormalization backward, formed on the fly:
  * dY = coef2*dz + coef3*bn_y + coef4, dz = (g*alpha_nc+add_nc)*[bn_y*coef0+coef1 > 0 or !bn_relu]
  * (coef from lf_bn_bwd_sums_f32), also written to dy_out [n][cout][h][w] (may be null: the stem
- * has no input gradient) for the input-gradient convolution that follows.  3x3 (the small-Cin stem kernel included) and 1x1, shapes for which lf_conv2d_wgrad_bn_supported() != 0; same
+ * has no input gradient) for the input-gradient convolution that follows.  3x3 (the small-Cin
+ * stem kernel included) and 1x1, shapes for which lf_conv2d_wgrad_bn_supported() != 0; same
  * workspace and reduce step as lf_conv2d_wgrad_f32. */
 int lf_conv2d_wgrad_bn_supported(int n, int cin, int h, int w, int cout, int ksize);
 int lf_conv2d_wgrad_bn_f32(const float* x, const float* g, const float* bn_y,
