@@ -190,6 +190,27 @@ def test_geometric_batch_vs_oracle(cuda):
             else:
                 exp = P.warp_bicubic(x[i], ps[i]["coeffs"], op == "skew")
             assert np.array_equal(outs[i].cpu().numpy(), exp), (op, i)
+    # the dataset's native 256x256 and a non-square size (rows != columns in every index formula)
+    for (hh, ww, seed) in ((256, 256, 21), (150, 260, 22)):
+        xs = batch_inputs(3, hh, ww, seed)
+        xsd = dev(xs, cuda)
+        random.seed(seed)
+        np.random.seed(seed)
+        for op in ("flip", "rotate", "skew", "shear", "crop", "distortion"):
+            ps = [IA.draw_params(op, ww, hh) for _ in range(3)]
+            outs = IA.apply_batch(op, xsd, ps)
+            for i in range(3):
+                if op == "flip":
+                    exp = P.flip(xs[i], ps[i]["mode"])
+                elif op == "rotate":
+                    exp = P.rotate_expand_white(xs[i], ps[i]["angle"])
+                elif op == "crop":
+                    exp = P.crop_resize_lanczos(xs[i], *ps[i]["box"])
+                elif op == "distortion":
+                    exp = P.autocontrast(P.noise_wrap_add(xs[i], ps[i]["noise"]), ps[i]["cutoff"])
+                else:
+                    exp = P.warp_bicubic(xs[i], ps[i]["coeffs"], op == "skew")
+                assert np.array_equal(outs[i].cpu().numpy(), exp), (op, i, hh, ww)
     # flip is an involution; identity warp reproduces the input
     mode = torch.zeros(6, dtype=torch.int32, device=cuda)
     assert torch.equal(ops.flip_u8(ops.flip_u8(xd, mode), mode), xd)
