@@ -15,7 +15,7 @@ from pathlib import Path
 from typing import Any, Dict, List, Optional, Tuple
 
 from ..utils.confusion_matrix import (_gather_predictions_and_labels, compute_confusion_counts,
-                                      save_confusion_json)
+                                      plot_confusion_png, save_confusion_json)
 
 LOGGER = logging.getLogger(__name__)
 
@@ -212,4 +212,5 @@ def save_best_variant(model, val_data, ema_cb: Optional[EMACallback], out_dir: P
     except (OSError, TypeError) as e:
         LOGGER.warning("Failed to write meta.json: %s", e)
     save_confusion_json(cm, labels_sorted, out_dir / "confusion_matrix.json")
+    plot_confusion_png(cm, labels_sorted, out_dir / "confusion_matrix.png")
     return saved_variant

@@ -1,7 +1,7 @@
 """Confusion-matrix contract (mirror of srcs/utils/confusion_matrix.py:14-50,103-129).
 
-Counts are integers [true][pred]; JSON = {"matrix": [[int]], "labels": [str]}.  The PNG
-rendering of the reference is presentation and out of scope.
+Counts are integers [true][pred]; JSON = {"matrix": [[int]], "labels": [str]}.  The PNG is
+presentation: drawn when matplotlib is installed, skipped otherwise.
 """
 from __future__ import annotations
 
@@ -49,3 +49,39 @@ def confusion_matrix(model: Any, data: Any, labels: List[str], out_dir: Path) ->
     json_path = out_dir / "confusion_matrix.json"
     save_confusion_json(cm, labels, json_path)
     return json_path
+
+
+def plot_confusion_png(cm: List[List[int]], labels: List[str], out_path: Path, *, normalize: bool = True) -> bool:
+    """`confusion_matrix.png` next to the JSON (srcs/utils/confusion_matrix.py:51-97): rows
+    normalised by default, cell values printed.  Presentation only — skipped (False) when
+    matplotlib is not installed; the JSON is the contract."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception as exc:  # noqa: BLE001
+        import logging
+        logging.getLogger(__name__).warning("matplotlib unavailable, skipping confusion matrix PNG: %s", exc)
+        return False
+    k = len(labels)
+    counts = np.asarray(cm, dtype=float)
+    shown = counts / np.maximum(counts.sum(axis=1, keepdims=True), 1.0) if normalize else counts
+    fig, ax = plt.subplots(figsize=(8, 6), dpi=150)
+    img = ax.imshow(shown, cmap="Blues")
+    plt.colorbar(img, ax=ax, fraction=0.046, pad=0.04)
+    ax.set_xticks(range(k))
+    ax.set_yticks(range(k))
+    ax.set_xticklabels(labels, rotation=45, ha="right")
+    ax.set_yticklabels(labels)
+    ax.set_xlabel("Predicted")
+    ax.set_ylabel("True")
+    ax.set_title("Confusion Matrix" + (" (normalized)" if normalize else ""))
+    for i in range(k):
+        for j in range(k):
+            ax.text(j, i, f"{shown[i, j]:.2f}" if normalize else f"{int(shown[i, j])}", ha="center",
+                    va="center", color="black", fontsize=8)
+    fig.tight_layout()
+    Path(out_path).parent.mkdir(parents=True, exist_ok=True)
+    fig.savefig(out_path)
+    plt.close(fig)
+    return True

@@ -97,7 +97,8 @@ def test_train_and_predict_cli_config_c1(cuda, tmp_path, monkeypatch):
     train_cli.main(["--manifest", str(man), "--epochs", "2", "--batch-size", "8", "--img-size", "64",
                     "--no-mixed-precision", "--seed", "42"])
     mdir = tmp_path / "artifacts/models"
-    for f in ("leaf_cnn.keras", "labels.json", "history.json", "meta.json", "confusion_matrix.json"):
+    for f in ("leaf_cnn.keras", "labels.json", "history.json", "meta.json", "confusion_matrix.json",
+              "confusion_matrix.png"):
         assert (mdir / f).exists(), f
     labels = json.loads((mdir / "labels.json").read_text())["label2idx"]
     assert labels == {"Apple__Apple_healthy": 0, "Apple__Apple_rust": 1}
