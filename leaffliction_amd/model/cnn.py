@@ -91,7 +91,12 @@ class LeafCNN:
                  augment: bool = True, use_se: bool = True, seed: int = 0,
                  device: Optional[torch.device] = None) -> None:
         if separable:
-            raise NotImplementedError("SeparableConv2D (--separable) is outside the hot-path scope")
+            # cnn.py:22-25 passes `kernel_regularizer=` to keras.layers.SeparableConv2D, which
+            # Keras 3 (requirements: keras>=3) rejects as an unrecognised keyword with a
+            # ValueError — `train --separable` therefore logs the error and returns in the
+            # reference too (train.py:471-473).  Same outcome here, no depthwise kernels.
+            raise ValueError("--separable: SeparableConv2D is not available (the reference's "
+                             "own call is rejected by Keras 3; no depthwise path is provided)")
         if not torch.cuda.is_available():
             raise RuntimeError("LeafCNN needs a HIP device: there is no CPU fallback")
         self.num_classes = int(num_classes)
