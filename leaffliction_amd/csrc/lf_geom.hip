@@ -327,6 +327,70 @@ __global__ __launch_bounds__(kBlock) void resample_h_kernel(const uint8_t* __res
     }
 }
 
+// horizontal, coefficient-resident form: one thread per (output column, strip of kHStrip rows).
+// An output column's window and taps are the same on every row, so they are read once into
+// registers (<= kHMaxTaps of them) and reused down the strip instead of being re-fetched per
+// pixel — the per-pixel version spends most of its loads on coefficients (36 B per 3 B written).
+constexpr int kHStrip = 8, kHMaxTaps = 12;
+__global__ __launch_bounds__(kBlock) void resample_h_strip_kernel(const uint8_t* __restrict__ in,
+                                                                  uint8_t* __restrict__ tmp, int h,
+                                                                  int w, int ow,
+                                                                  const int32_t* __restrict__ bounds,
+                                                                  const int32_t* __restrict__ kk, int ks,
+                                                                  int per_image) {
+    const unsigned n = blockIdx.y;
+    const int32_t* bnd = bounds + (per_image ? (size_t)n * ow * 2 : 0);
+    const int32_t* kx = kk + (per_image ? (size_t)n * ow * ks : 0);
+    const uint8_t* src = in + (size_t)n * h * w * 3;
+    uint8_t* dst = tmp + (size_t)n * h * ow * 3;
+    const int strips = (h + kHStrip - 1) / kHStrip;
+    const int total = strips * ow;
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
+        const int strip = t / ow, ox = t - strip * ow;
+        const int xmin = clampi(bnd[2 * ox], 0, w);
+        const int cnt = min(bnd[2 * ox + 1], min(ks, w - xmin));
+        int c[kHMaxTaps];
+#pragma unroll
+        for (int i = 0; i < kHMaxTaps; ++i) c[i] = i < cnt ? kx[(size_t)ox * ks + i] : 0;
+        // whole groups of four taps may read up to 3 pixels past the window: keep them in the row
+        const int groups = (cnt + 3) / 4;
+        const bool vec = xmin + 4 * groups <= w;
+        const int y1 = min((strip + 1) * kHStrip, h);
+        for (int y = strip * kHStrip; y < y1; ++y) {
+            const uint8_t* p = src + ((size_t)y * w + xmin) * 3;
+            int s0 = 1 << (kPrec - 1), s1 = s0, s2 = s0;
+            if (vec) {
+#pragma unroll
+                for (int g = 0; g < kHMaxTaps / 4; ++g) {
+                    if (g < groups) {
+                        const Row12 q = *reinterpret_cast<const Row12*>(p + 12 * g);
+                        const int c0 = c[4 * g], c1 = c[4 * g + 1], c2 = c[4 * g + 2], c3 = c[4 * g + 3];
+                        s0 += (int)(q.a & 0xff) * c0 + (int)(q.a >> 24) * c1 + (int)((q.b >> 16) & 0xff) * c2 +
+                              (int)((q.c >> 8) & 0xff) * c3;
+                        s1 += (int)((q.a >> 8) & 0xff) * c0 + (int)(q.b & 0xff) * c1 + (int)(q.b >> 24) * c2 +
+                              (int)((q.c >> 16) & 0xff) * c3;
+                        s2 += (int)((q.a >> 16) & 0xff) * c0 + (int)((q.b >> 8) & 0xff) * c1 +
+                              (int)(q.c & 0xff) * c2 + (int)(q.c >> 24) * c3;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kHMaxTaps; ++i) {
+                    if (i < cnt) {
+                        s0 += p[3 * i] * c[i];
+                        s1 += p[3 * i + 1] * c[i];
+                        s2 += p[3 * i + 2] * c[i];
+                    }
+                }
+            }
+            uint8_t* o = dst + ((size_t)y * ow + ox) * 3;
+            o[0] = clip8(s0);
+            o[1] = clip8(s1);
+            o[2] = clip8(s2);
+        }
+    }
+}
+
 // vertical: tmp [n][h][ow][3] -> out [n][oh][ow][3]; one thread per (oy, 4 consecutive bytes)
 // when the row is a whole number of dwords, else one thread per byte.
 template <int VEC>
@@ -415,8 +479,12 @@ int lf_resample_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int n, int h, 
                "lf_resample: bad dims n=%d h=%d w=%d oh=%d ow=%d kx=%d ky=%d", n, h, w, oh, ow, kx,
                ky);
     hipStream_t s = lf::as_stream(stream);
-    resample_h_kernel<<<dim3(lf::stream_grid((size_t)h * ow, kBlock, 1024), n), kBlock, 0, s>>>(
-        in, tmp, h, w, ow, xbounds, xk, kx, per_image_coeffs);
+    if (kx <= kHMaxTaps)
+        resample_h_strip_kernel<<<dim3(lf::stream_grid((size_t)((h + kHStrip - 1) / kHStrip) * ow, kBlock, 1024), n),
+                                  kBlock, 0, s>>>(in, tmp, h, w, ow, xbounds, xk, kx, per_image_coeffs);
+    else
+        resample_h_kernel<<<dim3(lf::stream_grid((size_t)h * ow, kBlock, 1024), n), kBlock, 0, s>>>(
+            in, tmp, h, w, ow, xbounds, xk, kx, per_image_coeffs);
     const bool vec = (ow * 3) % 4 == 0 && ((reinterpret_cast<size_t>(tmp) | reinterpret_cast<size_t>(out)) & 3) == 0;
     if (vec)
         resample_v_kernel<4><<<dim3(lf::stream_grid((size_t)oh * ow * 3 / 4, kBlock, 1024), n), kBlock,
