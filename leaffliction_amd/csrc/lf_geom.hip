@@ -232,8 +232,9 @@ __global__ __launch_bounds__(kBlock) void affine_nearest_kernel(const uint8_t* _
                                                                 const int32_t* __restrict__ ohw,
                                                                 const int64_t* __restrict__ out_off,
                                                                 int h, int w, unsigned fill) {
-    // One thread = one output DWORD (4 consecutive bytes = parts of at most 2 pixels): the
-    // packed RGB output is written with coalesced 4-byte stores instead of byte stores.
+    // One thread = four consecutive output pixels = three whole dwords of the packed RGB
+    // output: every pixel is computed once, the row/column split costs one integer division
+    // per group (the following pixels step along the row), stores are whole dwords.
     // out_off[n] is 16-byte aligned and each image's region is padded to 16 bytes.
     const unsigned n = blockIdx.y;
     const int32_t* a = fix6 + (size_t)n * 6;
@@ -242,35 +243,44 @@ __global__ __launch_bounds__(kBlock) void affine_nearest_kernel(const uint8_t* _
     const uint8_t* src = in + (size_t)n * h * w * 3;
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + out_off[n]);
     const int total = oh * ow;            // pixels
-    const int nd = (total * 3 + 3) / 4;   // dwords
-    for (int t = blockIdx.x * kBlock + threadIdx.x; t < nd; t += gridDim.x * kBlock) {
-        const int b0 = 4 * t, p0 = b0 / 3, c0 = b0 - 3 * p0;
-        unsigned px[2];
+    const int nd = (total * 3 + 3) / 4;   // dwords that hold at least one pixel byte
+    const int ng = (total + 3) / 4;       // groups of four pixels
+    const int last = h * w - 1;
+    for (int g = blockIdx.x * kBlock + threadIdx.x; g < ng; g += gridDim.x * kBlock) {
+        const int p0 = 4 * g;
+        unsigned oy = (unsigned)p0 / (unsigned)ow, ox = (unsigned)p0 - oy * (unsigned)ow;
+        // unsigned arithmetic == two's-complement wrap of the C int accumulation
+        unsigned xx = a2 + a1 * oy + a0 * ox, yy = a5 + a4 * oy + a3 * ox;
+        unsigned px[4];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int p = p0 + k;
+        for (int k = 0; k < 4; ++k) {
             unsigned v = fill * 0x010101u;
-            if (p < total) {
-                const unsigned oy = p / ow, ox = p - oy * ow;
-                // unsigned arithmetic == two's-complement wrap of the C int accumulation
-                const int xx = (int)(a2 + a1 * oy + a0 * ox);
-                const int yy = (int)(a5 + a4 * oy + a3 * ox);
-                const int xin = xx >> 16, yin = yy >> 16;
-                if (xin >= 0 && xin < w && yin >= 0 && yin < h) {
-                    const int sp = yin * w + xin;
-                    const uint8_t* s = src + (size_t)sp * 3;
-                    if (sp + 1 < h * w) {  // 4-byte unaligned load stays inside the image
-                        v = reinterpret_cast<const Pix4*>(s)->v & 0xffffffu;
-                    } else {
-                        v = s[0] | s[1] << 8 | s[2] << 16;
-                    }
+            const int xin = (int)xx >> 16, yin = (int)yy >> 16;
+            if (p0 + k < total && xin >= 0 && xin < w && yin >= 0 && yin < h) {
+                const int sp = yin * w + xin;
+                const uint8_t* s = src + (size_t)sp * 3;
+                if (sp < last) {  // 4-byte unaligned load stays inside the image
+                    v = reinterpret_cast<const Pix4*>(s)->v & 0xffffffu;
+                } else {
+                    v = s[0] | s[1] << 8 | s[2] << 16;
                 }
             }
             px[k] = v;
+            // next pixel of the row, or the first of the next row
+            if (++ox == (unsigned)ow) {
+                ox = 0;
+                ++oy;
+                xx = a2 + a1 * oy;
+                yy = a5 + a4 * oy;
+            } else {
+                xx += a0;
+                yy += a3;
+            }
         }
-        // bytes c0..2 of pixel p0, then bytes of pixel p0+1
-        const unsigned long long both = (unsigned long long)px[0] | (unsigned long long)px[1] << 24;
-        dst[t] = (unsigned)(both >> (8 * c0));
+        const int d0 = 3 * g;
+        if (d0 < nd) dst[d0] = px[0] | px[1] << 24;
+        if (d0 + 1 < nd) dst[d0 + 1] = px[1] >> 8 | px[2] << 16;
+        if (d0 + 2 < nd) dst[d0 + 2] = px[2] >> 16 | px[3] << 8;
     }
 }
 
@@ -464,7 +474,7 @@ int lf_affine_nearest_fixed_u8(const uint8_t* in, uint8_t* out, const int32_t* f
                max_out_pixels);
     LF_REQUIRE(h < 32768 && w < 32768, "lf_affine_nearest_fixed: 16.16 fixed point needs sizes < 32768");
     LF_REQUIRE(fill >= 0 && fill <= 255, "lf_affine_nearest_fixed: fill must be 0..255");
-    dim3 grid(lf::stream_grid((size_t)max_out_pixels, kBlock, 1024), n);
+    dim3 grid(lf::stream_grid(((size_t)max_out_pixels + 3) / 4, kBlock, 1024), n);
     affine_nearest_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, fix6, ohw, out_off, h,
                                                                       w, (unsigned)fill);
     return lf::check_launch("lf_affine_nearest_fixed");
