@@ -93,6 +93,23 @@ __device__ __forceinline__ void warp_pixel(const uint8_t* __restrict__ src, uint
     if (dy == 0.0) {
         // BICUBIC(v1, v2, v3, v4, 0) = v2: only footprint row y+1 (or its fallback) matters
         hrow(src + (size_t)(ok1 ? y + 1 : yr0) * w * 3, x, w, dx, v);
+    } else if (dx == 0.0) {
+        // no horizontal resampling (a shear along y): every footprint row contributes exactly its
+        // pixel at column x+1 (clamped like hrow's border path), so four pixels are fetched
+        // instead of sixteen; the polynomial's p2..p4 are sums of small integers, formed
+        // exactly in int before the one conversion to double each.
+        const int col = clampi(x + 1, 0, w - 1) * 3;
+        const uint8_t* r1 = src + (size_t)yr0 * w * 3 + col;
+        const uint8_t* r2 = ok1 ? src + (size_t)(y + 1) * w * 3 + col : r1;
+        const uint8_t* r3 = ok2 ? src + (size_t)(y + 2) * w * 3 + col : r2;
+        const uint8_t* r4 = ok3 ? src + (size_t)(y + 3) * w * 3 + col : r3;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int q1 = r1[b], q2 = r2[b], q3 = r3[b], q4 = r4[b];
+            const double p1 = (double)q2, p2 = (double)(q3 - q1), p3 = (double)(2 * (q1 - q2) + q3 - q4),
+                         p4 = (double)(-q1 + q2 - q3 + q4);
+            v[b] = p1 + dy * (p2 + dy * (p3 + dy * p4));
+        }
     } else {
         double v1[3], v2[3], v3[3], v4[3];
         hrow(src + (size_t)yr0 * w * 3, x, w, dx, v1);
