@@ -201,6 +201,8 @@ def test_bn_backward_inside_wgrad(cuda, n, cin, cout, h, w, with_se, k, relu):
 @pytest.mark.parametrize("n,cin,cout,h,w,k,acc", [(2, 32, 32, 64, 64, 3, False),
                                                   (2, 64, 32, 32, 32, 3, True),
                                                   (1, 256, 128, 28, 28, 3, False),   # masked 28-wide tiles
+                                                  (3, 128, 128, 28, 28, 3, True),    # two-image strips, accumulate
+                                                  (4, 64, 256, 28, 28, 3, False),    # strips, two cout tiles
                                                   (2, 16, 24, 20, 12, 3, True),      # ragged / scalar path
                                                   (2, 5, 7, 9, 11, 3, False)])
 def test_conv_bn_backward_sums_epilogue(cuda, n, cin, cout, h, w, k, acc):
