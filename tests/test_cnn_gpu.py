@@ -30,7 +30,11 @@ def rel_err(got, ref):
 
 @pytest.mark.parametrize("widths,img,n,classes", [([32, 64, 128, 256], 32, 6, 8),
                                                   ([16, 32, 64], 24, 5, 2),
-                                                  ([32, 64, 128], 64, 3, 5)])
+                                                  ([32, 64, 128], 64, 3, 5),
+                                                  # the benchmark geometry (224 -> 112 -> 56 -> 28: strip
+                                                  # tiles, every fused BatchNorm path) at a batch the
+                                                  # CPU oracle still finishes in seconds
+                                                  ([32, 64, 128, 256], 224, 2, 8)])
 def test_train_step_matches_oracle(cuda, widths, img, n, classes):
     from leaffliction_amd import nn
     m, ref_p, ref_s = make_model(cuda, widths, classes, img, use_norm=True)
@@ -61,7 +65,18 @@ def test_train_step_matches_oracle(cuda, widths, img, n, classes):
     assert torch.equal(probs.cpu().argmax(-1), probs_ref.argmax(-1))
     assert abs(loss.mean().item() - data_loss) < 1e-5 * max(1.0, abs(data_loss))
     for name, _s, _k in m.specs:
-        assert rel_err(m.g[name].cpu(), grads[name]) < 2e-3, name
+        got, ref = m.g[name].cpu(), grads[name]
+        if img < 128:
+            assert rel_err(got, ref) < 2e-3, name
+        else:
+            # 6.4 M activations per tensor: a handful sit within one rounding of a ReLU threshold
+            # or of a max-pool tie, and the two fp32 evaluation orders decide them differently.
+            # Each such flip moves ONE element's contribution (~1/160 of a weight-gradient entry
+            # that is a cancelling sum of 25 k terms), so the maximum error is spiky (1e-6 on one
+            # seed, 6e-3 on the next — measured against a float64 oracle) while the error NORM
+            # stays at rounding level.  Bound both.
+            l2 = (got - ref).norm().item() / (ref.norm().item() + 1e-30)
+            assert l2 < 1e-3 and rel_err(got, ref) < 2e-2, (name, l2, rel_err(got, ref))
     for bn, _c in m.bn_layers:  # moving statistics updated identically
         assert (m.s[bn + ".mean"].cpu() - ref_s[bn + ".mean"]).abs().max().item() < 1e-5
         assert (m.s[bn + ".var"].cpu() - ref_s[bn + ".var"]).abs().max().item() < 1e-5
