@@ -225,6 +225,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-augment", action="store_true", help="skip the augmentation-pass measurement")
+    ap.add_argument("--no-inference", action="store_true", help="skip the forward-only measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -342,7 +343,7 @@ def main() -> None:
             "step_tflops": round(TRAIN_GFLOP_PER_IMG * n * args.steps / elapsed / 1e3, 2),
             "final_loss": round(final_loss, 4),
         }
-        if world == 1:
+        if world == 1 and not args.no_inference:
             out["inference"] = inference_throughput(model, dev)
         if not args.no_augment and world == 1:
             del model
