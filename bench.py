@@ -83,6 +83,10 @@ class KernelTimer:
             nbytes = 4.0 * (n * h * w * (cin + cout) + cin * cout * k * k)
             if name == "lf_conv2d_wgrad_bn_f32":  # also reads the BN input and writes dy
                 nbytes += 8.0 * n * h * w * cout
+            elif name == "lf_conv2d_bnbwd_f32":     # also reads the BN input for the mask ...
+                nbytes += 4.0 * n * h * w * cout * (2 if args[9] else 1)   # ... and y when accumulating
+            elif name == "lf_conv2d_f32" and args[12]:  # accumulate: y is read and written
+                nbytes += 4.0 * n * h * w * cout
             timer.records.append((kname, flop, e0, e1, nbytes))
             return rc
 
