@@ -21,7 +21,7 @@ __device__ __forceinline__ unsigned byte_of(unsigned w, int i) { return (w >> (8
 // pack: u8 HWC -> f32 NCHW, x/255 (+ optional per-channel normalisation)
 // ---------------------------------------------------------------------------
 // One thread = 4 pixels = 12 input bytes (3 dwords) -> one float4 per plane.
-template <bool NORM>
+template <bool NORM, bool NT>
 __global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t* __restrict__ in,
                                                       float* __restrict__ out, unsigned hw4,
                                                       float m0, float m1, float m2, float d0,
@@ -31,14 +31,15 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t* __restrict_
     const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (size_t)n * hw * 3);
     float* dst = out + (size_t)n * hw * 3;
     for (unsigned g = blockIdx.x * kBlock + threadIdx.x; g < hw4; g += gridDim.x * kBlock) {
-        const unsigned w0 = src[3 * g + 0], w1 = src[3 * g + 1], w2 = src[3 * g + 2];
+        const unsigned w0 = lf::ldg<NT>(src + 3 * g), w1 = lf::ldg<NT>(src + 3 * g + 1),
+                       w2 = lf::ldg<NT>(src + 3 * g + 2);
         float r[4] = {(float)byte_of(w0, 0), (float)byte_of(w0, 3), (float)byte_of(w1, 2),
                       (float)byte_of(w2, 1)};
         float gch[4] = {(float)byte_of(w0, 1), (float)byte_of(w1, 0), (float)byte_of(w1, 3),
                         (float)byte_of(w2, 2)};
         float b[4] = {(float)byte_of(w0, 2), (float)byte_of(w1, 1), (float)byte_of(w2, 0),
                       (float)byte_of(w2, 3)};
-        float4 o0, o1, o2;
+        lf::f32x4 o0, o1, o2;
         float* pr = reinterpret_cast<float*>(&o0);
         float* pg = reinterpret_cast<float*>(&o1);
         float* pb = reinterpret_cast<float*>(&o2);
@@ -55,9 +56,9 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const uint8_t* __restrict_
             pg[i] = vg;
             pb[i] = vb;
         }
-        reinterpret_cast<float4*>(dst)[g] = o0;
-        reinterpret_cast<float4*>(dst + hw)[g] = o1;
-        reinterpret_cast<float4*>(dst + 2 * hw)[g] = o2;
+        lf::stg<NT>(reinterpret_cast<lf::f32x4*>(dst) + g, o0);
+        lf::stg<NT>(reinterpret_cast<lf::f32x4*>(dst + hw) + g, o1);
+        lf::stg<NT>(reinterpret_cast<lf::f32x4*>(dst + 2 * hw) + g, o2);
     }
 }
 
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(kBlock) void pack_scalar_kernel(const uint8_t* __re
 // and flushed with one global atomic per bin per workgroup.
 constexpr int kHistCopies = kBlock / 64;
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void hist_kernel(const uint8_t* __restrict__ in,
                                                       int32_t* __restrict__ hist, size_t nbytes) {
     __shared__ unsigned lh[kHistCopies][768];
@@ -103,9 +105,9 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const uint8_t* __restrict_
     size_t head = (16 - (addr & 15)) & 15;
     if (head > nbytes) head = nbytes;
     const size_t nchunks = (nbytes - head) / 16;
-    const uint4* mid = reinterpret_cast<const uint4*>(base + head);
+    const lf::u32x4* mid = reinterpret_cast<const lf::u32x4*>(base + head);
     const unsigned hc = (unsigned)(head % 3);
-    auto tally = [&](const uint4 v, size_t q) {
+    auto tally = [&](const lf::u32x4 v, size_t q) {
         // channel of byte 0 of this chunk: (head + 16 q) % 3 = (hc + q) % 3
         const unsigned r = (hc + (unsigned)(q % 3)) % 3;
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -121,13 +123,14 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const uint8_t* __restrict_
     const size_t stride = (size_t)gridDim.x * kBlock;
     size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
     for (; q + 3 * stride < nchunks; q += 4 * stride) {
-        const uint4 v0 = mid[q], v1 = mid[q + stride], v2 = mid[q + 2 * stride], v3 = mid[q + 3 * stride];
+        const lf::u32x4 v0 = lf::ldg<NT>(mid + q), v1 = lf::ldg<NT>(mid + q + stride),
+                        v2 = lf::ldg<NT>(mid + q + 2 * stride), v3 = lf::ldg<NT>(mid + q + 3 * stride);
         tally(v0, q);
         tally(v1, q + stride);
         tally(v2, q + 2 * stride);
         tally(v3, q + 3 * stride);
     }
-    for (; q < nchunks; q += stride) tally(mid[q], q);
+    for (; q < nchunks; q += stride) tally(lf::ldg<NT>(mid + q), q);
     if (blockIdx.x == 0) {
         const size_t tail0 = head + nchunks * 16;
         for (size_t i = threadIdx.x; i < head; i += kBlock)
@@ -229,6 +232,7 @@ __global__ void autocontrast_lut_kernel(const int32_t* __restrict__ hist,
 // ---------------------------------------------------------------------------
 // LUT apply (Image.point)
 // ---------------------------------------------------------------------------
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void lut_apply_kernel(const uint8_t* __restrict__ in,
                                                            const uint8_t* __restrict__ lut,
                                                            uint8_t* __restrict__ out,
@@ -240,11 +244,11 @@ __global__ __launch_bounds__(kBlock) void lut_apply_kernel(const uint8_t* __rest
     const uint8_t* src = in + (size_t)n * nbytes;
     uint8_t* dst = out + (size_t)n * nbytes;
     const size_t nchunks = nbytes / 16;  // caller guarantees 16-byte aligned images
-    const uint4* s4 = reinterpret_cast<const uint4*>(src);
-    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    const lf::u32x4* s4 = reinterpret_cast<const lf::u32x4*>(src);
+    lf::u32x4* d4 = reinterpret_cast<lf::u32x4*>(dst);
     for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < nchunks;
          q += (size_t)gridDim.x * kBlock) {
-        const uint4 v = s4[q];
+        const lf::u32x4 v = lf::ldg<NT>(s4 + q);
         const unsigned r = (unsigned)(q % 3);
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
         unsigned o[4] = {0, 0, 0, 0};
@@ -254,7 +258,9 @@ __global__ __launch_bounds__(kBlock) void lut_apply_kernel(const uint8_t* __rest
             c = c >= 3 ? c - 3 : c;
             o[j >> 2] |= (unsigned)sl[c * 256 + byte_of(w[j >> 2], j & 3)] << (8 * (j & 3));
         }
-        d4[q] = make_uint4(o[0], o[1], o[2], o[3]);
+        lf::u32x4 ov;
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        lf::stg<NT>(d4 + q, ov);
     }
     if (blockIdx.x == 0) {
         for (size_t i = nchunks * 16 + threadIdx.x; i < nbytes; i += kBlock)
@@ -293,26 +299,19 @@ __global__ __launch_bounds__(kBlock) void flip_kernel(const uint8_t* __restrict_
     const unsigned total = (unsigned)h * w4;
     for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
         const unsigned y = t / w4, g = t - y * w4;
-        if (m == 0) {  // FLIP_LEFT_RIGHT: reverse the pixel order of the mirrored group
-            const uint32_t* s = src + ((size_t)y * w4 + (w4 - 1 - g)) * 3;
-            const unsigned w0 = s[0], w1 = s[1], w2 = s[2];
-            const unsigned o0 = byte_of(w2, 1) | byte_of(w2, 2) << 8 | byte_of(w2, 3) << 16 |
-                                byte_of(w1, 2) << 24;
-            const unsigned o1 = byte_of(w1, 3) | byte_of(w2, 0) << 8 | byte_of(w0, 3) << 16 |
-                                byte_of(w1, 0) << 24;
-            const unsigned o2 = byte_of(w1, 1) | byte_of(w0, 0) << 8 | byte_of(w0, 1) << 16 |
-                                byte_of(w0, 2) << 24;
-            uint32_t* d = dst + (size_t)t * 3;
-            d[0] = o0;
-            d[1] = o1;
-            d[2] = o2;
-        } else {  // FLIP_TOP_BOTTOM
-            const uint32_t* s = src + ((size_t)(h - 1 - y) * w4 + g) * 3;
-            uint32_t* d = dst + (size_t)t * 3;
-            d[0] = s[0];
-            d[1] = s[1];
-            d[2] = s[2];
+        const uint32_t* s = src + (m == 0 ? ((size_t)y * w4 + (w4 - 1 - g)) * 3
+                                          : ((size_t)(h - 1 - y) * w4 + g) * 3);
+        uint32_t* d = dst + (size_t)t * 3;
+        const unsigned w0 = s[0], w1 = s[1], w2 = s[2];
+        unsigned o0 = w0, o1 = w1, o2 = w2;
+        if (m == 0) {  // FLIP_LEFT_RIGHT: reverse the pixel order inside the group
+            o0 = byte_of(w2, 1) | byte_of(w2, 2) << 8 | byte_of(w2, 3) << 16 | byte_of(w1, 2) << 24;
+            o1 = byte_of(w1, 3) | byte_of(w2, 0) << 8 | byte_of(w0, 3) << 16 | byte_of(w1, 0) << 24;
+            o2 = byte_of(w1, 1) | byte_of(w0, 0) << 8 | byte_of(w0, 1) << 16 | byte_of(w0, 2) << 24;
         }
+        d[0] = o0;
+        d[1] = o1;
+        d[2] = o2;
     }
 }
 
@@ -368,6 +367,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // One thread = 4 bytes: one Philox block -> two Box-Muller pairs.
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void noise_philox_kernel(const uint8_t* __restrict__ in,
                                                               uint8_t* __restrict__ out,
                                                               size_t nwords, size_t nbytes,
@@ -390,12 +390,12 @@ __global__ __launch_bounds__(kBlock) void noise_philox_kernel(const uint8_t* __r
         }
         const size_t b = q * 4;
         if (b + 4 <= nbytes) {
-            const unsigned v = reinterpret_cast<const uint32_t*>(in)[q];
+            const unsigned v = lf::ldg<NT>(reinterpret_cast<const uint32_t*>(in) + q);
             unsigned o = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 o |= ((byte_of(v, j) + (unsigned)(int)z[j]) & 0xffu) << (8 * j);
-            reinterpret_cast<uint32_t*>(out)[q] = o;
+            lf::stg<NT>(reinterpret_cast<uint32_t*>(out) + q, o);
         } else {
             for (size_t i = b; i < nbytes; ++i) out[i] = (uint8_t)(in[i] + (uint8_t)(int)z[i - b]);
         }
@@ -406,6 +406,7 @@ __global__ __launch_bounds__(kBlock) void noise_philox_kernel(const uint8_t* __r
 // mask-and-composite
 // ---------------------------------------------------------------------------
 // One thread = 4 pixels: 12 image bytes + 4 mask bytes.
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void composite_kernel(const uint8_t* __restrict__ img,
                                                            const uint8_t* __restrict__ mask,
                                                            uint8_t* __restrict__ out, size_t npx4,
@@ -416,17 +417,18 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const uint8_t* __rest
     const unsigned f4 = fill * 0x01010101u;
     for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < npx4;
          g += (size_t)gridDim.x * kBlock) {
-        const unsigned mk = m[g];
-        const unsigned w0 = s[3 * g], w1 = s[3 * g + 1], w2 = s[3 * g + 2];
+        const unsigned mk = lf::ldg<NT>(m + g);
+        const unsigned w0 = lf::ldg<NT>(s + 3 * g), w1 = lf::ldg<NT>(s + 3 * g + 1),
+                       w2 = lf::ldg<NT>(s + 3 * g + 2);
         // per-pixel keep masks expanded to the byte lanes each pixel occupies
         const unsigned k0 = byte_of(mk, 0) > 127, k1 = byte_of(mk, 1) > 127,
                        k2 = byte_of(mk, 2) > 127, k3 = byte_of(mk, 3) > 127;
         const unsigned m0 = (k0 ? 0x00ffffffu : 0u) | (k1 ? 0xff000000u : 0u);
         const unsigned m1 = (k1 ? 0x0000ffffu : 0u) | (k2 ? 0xffff0000u : 0u);
         const unsigned m2 = (k2 ? 0x000000ffu : 0u) | (k3 ? 0xffffff00u : 0u);
-        d[3 * g] = (w0 & m0) | (f4 & ~m0);
-        d[3 * g + 1] = (w1 & m1) | (f4 & ~m1);
-        d[3 * g + 2] = (w2 & m2) | (f4 & ~m2);
+        lf::stg<NT>(d + 3 * g, (w0 & m0) | (f4 & ~m0));
+        lf::stg<NT>(d + 3 * g + 1, (w1 & m1) | (f4 & ~m1));
+        lf::stg<NT>(d + 3 * g + 2, (w2 & m2) | (f4 & ~m2));
     }
 }
 
@@ -481,6 +483,7 @@ __device__ __forceinline__ void unpack4(unsigned w0, unsigned w1, unsigned w2, i
     r[3] = byte_of(w2, 1); g[3] = byte_of(w2, 2); b[3] = byte_of(w2, 3);
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void rgb2hsv_kernel(const uint8_t* __restrict__ rgb,
                                                          uint8_t* __restrict__ hsv, size_t npx) {
     __shared__ int sdiv[256], hdiv[256];
@@ -492,12 +495,12 @@ __global__ __launch_bounds__(kBlock) void rgb2hsv_kernel(const uint8_t* __restri
     for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < npx4;
          q += (size_t)gridDim.x * kBlock) {
         int r[4], g[4], b[4], hh[4], ss[4], vv[4];
-        unpack4(s[3 * q], s[3 * q + 1], s[3 * q + 2], r, g, b);
+        unpack4(lf::ldg<NT>(s + 3 * q), lf::ldg<NT>(s + 3 * q + 1), lf::ldg<NT>(s + 3 * q + 2), r, g, b);
 #pragma unroll
         for (int i = 0; i < 4; ++i) rgb2hsv_px(r[i], g[i], b[i], sdiv, hdiv, hh[i], ss[i], vv[i]);
-        d[3 * q] = hh[0] | ss[0] << 8 | vv[0] << 16 | hh[1] << 24;
-        d[3 * q + 1] = ss[1] | vv[1] << 8 | hh[2] << 16 | ss[2] << 24;
-        d[3 * q + 2] = vv[2] | hh[3] << 8 | ss[3] << 16 | vv[3] << 24;
+        lf::stg<NT>(d + 3 * q, (uint32_t)(hh[0] | ss[0] << 8 | vv[0] << 16 | hh[1] << 24));
+        lf::stg<NT>(d + 3 * q + 1, (uint32_t)(ss[1] | vv[1] << 8 | hh[2] << 16 | ss[2] << 24));
+        lf::stg<NT>(d + 3 * q + 2, (uint32_t)(vv[2] | hh[3] << 8 | ss[3] << 16 | vv[3] << 24));
     }
     if (blockIdx.x == 0) {
         for (size_t p = npx4 * 4 + threadIdx.x; p < npx; p += kBlock) {
@@ -514,6 +517,7 @@ __device__ __forceinline__ unsigned gray_px(int r, int g, int b) {
     return (unsigned)(r * 4899 + g * 9617 + b * 1868 + 8192) >> 14;
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void rgb2gray_kernel(const uint8_t* __restrict__ rgb,
                                                           uint8_t* __restrict__ gray, size_t npx) {
     const size_t npx4 = npx / 4;
@@ -522,9 +526,9 @@ __global__ __launch_bounds__(kBlock) void rgb2gray_kernel(const uint8_t* __restr
     for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < npx4;
          q += (size_t)gridDim.x * kBlock) {
         int r[4], g[4], b[4];
-        unpack4(s[3 * q], s[3 * q + 1], s[3 * q + 2], r, g, b);
-        d[q] = gray_px(r[0], g[0], b[0]) | gray_px(r[1], g[1], b[1]) << 8 |
-               gray_px(r[2], g[2], b[2]) << 16 | gray_px(r[3], g[3], b[3]) << 24;
+        unpack4(lf::ldg<NT>(s + 3 * q), lf::ldg<NT>(s + 3 * q + 1), lf::ldg<NT>(s + 3 * q + 2), r, g, b);
+        lf::stg<NT>(d + q, (uint32_t)(gray_px(r[0], g[0], b[0]) | gray_px(r[1], g[1], b[1]) << 8 |
+                               gray_px(r[2], g[2], b[2]) << 16 | gray_px(r[3], g[3], b[3]) << 24));
     }
     if (blockIdx.x == 0) {
         for (size_t p = npx4 * 4 + threadIdx.x; p < npx; p += kBlock)
@@ -901,13 +905,11 @@ int lf_pack_hwc_u8_to_nchw_f32(const uint8_t* in, float* out, int n, int h, int 
     }
     hipStream_t s = lf::as_stream(stream);
     if (hw % 4 == 0) {
-        dim3 grid(lf::stream_grid(hw / 4, kBlock, 64), n);
-        if (norm)
-            pack_kernel<true><<<grid, kBlock, 0, s>>>(in, out, (unsigned)(hw / 4), m[0], m[1], m[2],
-                                                      d[0], d[1], d[2]);
-        else
-            pack_kernel<false><<<grid, kBlock, 0, s>>>(in, out, (unsigned)(hw / 4), m[0], m[1],
-                                                       m[2], d[0], d[1], d[2]);
+        dim3 grid(lf::stream_grid(hw / 4, kBlock, 1024), n);
+        const bool nt = lf::streaming((size_t)n * hw * 15);
+        auto kern = norm ? (nt ? pack_kernel<true, true> : pack_kernel<true, false>)
+                         : (nt ? pack_kernel<false, true> : pack_kernel<false, false>);
+        kern<<<grid, kBlock, 0, s>>>(in, out, (unsigned)(hw / 4), m[0], m[1], m[2], d[0], d[1], d[2]);
     } else {
         dim3 grid(lf::stream_grid(hw, kBlock, 64), n);
         if (norm)
@@ -934,7 +936,10 @@ int lf_hist_u8(const uint8_t* in, int32_t* hist, int n, int h, int w, lf_stream_
     const unsigned maxs = lf::stream_grid(nbytes / 16 + 1, kBlock, 64);
     if (splits > maxs) splits = maxs;
     dim3 grid(splits, n);
-    hist_kernel<<<grid, kBlock, 0, s>>>(in, hist, nbytes);
+    if (lf::streaming((size_t)n * nbytes))
+        hist_kernel<true><<<grid, kBlock, 0, s>>>(in, hist, nbytes);
+    else
+        hist_kernel<false><<<grid, kBlock, 0, s>>>(in, hist, nbytes);
     return lf::check_launch("lf_hist");
 }
 
@@ -959,8 +964,13 @@ int lf_lut_apply_u8(const uint8_t* in, const uint8_t* lut, uint8_t* out, int n, 
                                                reinterpret_cast<size_t>(out)) & 15) == 0;
     if (aligned) {
         const unsigned maxs = lf::stream_grid(nbytes / 16, kBlock, 64);
+        const unsigned few = (maxs + 3) / 4;  // about four 16-byte chunks per thread
+        if (splits < few) splits = few;
         if (splits > maxs) splits = maxs;
-        lut_apply_kernel<<<dim3(splits, n), kBlock, 0, s>>>(in, lut, out, nbytes);
+        if (lf::streaming((size_t)n * nbytes * 2))
+            lut_apply_kernel<true><<<dim3(splits, n), kBlock, 0, s>>>(in, lut, out, nbytes);
+        else
+            lut_apply_kernel<false><<<dim3(splits, n), kBlock, 0, s>>>(in, lut, out, nbytes);
     } else {
         const unsigned maxs = lf::stream_grid(nbytes, kBlock, 64);
         if (splits > maxs) splits = maxs;
@@ -991,6 +1001,8 @@ int lf_flip_u8(const uint8_t* in, uint8_t* out, const int32_t* mode, int n, int 
                                          reinterpret_cast<size_t>(out)) & 3) == 0;
     if (aligned) {
         dim3 grid(lf::stream_grid((size_t)h * (w / 4), kBlock, 64), n);
+        // plain accesses, destination order: nontemporal or source-ordered variants measured
+        // within noise of this one (5.6-5.8 TB/s) or slower
         flip_kernel<<<grid, kBlock, 0, s>>>(in, out, mode, h, w / 4);
     } else {
         dim3 grid(lf::stream_grid((size_t)h * w, kBlock, 64), n);
@@ -1015,8 +1027,13 @@ int lf_noise_philox_add_u8(const uint8_t* in, uint8_t* out, size_t nbytes, uint6
     LF_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out)) & 3) == 0,
                "lf_noise_philox_add: buffers must be 4-byte aligned");
     const size_t nwords = (nbytes + 3) / 4;
-    noise_philox_kernel<<<lf::stream_grid(nwords, kBlock), kBlock, 0, lf::as_stream(stream)>>>(
-        in, out, nwords, nbytes, seed, sigma);
+    const unsigned grid = lf::stream_grid(nwords, kBlock, lf::kFullGrid);
+    if (lf::streaming(nbytes * 2))
+        noise_philox_kernel<true><<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, nwords, nbytes,
+                                                                             seed, sigma);
+    else
+        noise_philox_kernel<false><<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, nwords,
+                                                                              nbytes, seed, sigma);
     return lf::check_launch("lf_noise_philox_add");
 }
 
@@ -1030,9 +1047,13 @@ int lf_mask_composite_u8(const uint8_t* img, const uint8_t* mask, uint8_t* out, 
     const bool aligned = ((reinterpret_cast<size_t>(img) | reinterpret_cast<size_t>(mask) |
                            reinterpret_cast<size_t>(out)) & 3) == 0;
     const size_t npx4 = aligned ? npx / 4 : 0;
-    if (npx4)
-        composite_kernel<<<lf::stream_grid(npx4, kBlock), kBlock, 0, s>>>(img, mask, out, npx4,
-                                                                       (unsigned)color);
+    if (npx4) {
+        const unsigned grid = lf::stream_grid(npx4, kBlock, lf::kFullGrid);
+        if (lf::streaming(npx * 7))
+            composite_kernel<true><<<grid, kBlock, 0, s>>>(img, mask, out, npx4, (unsigned)color);
+        else
+            composite_kernel<false><<<grid, kBlock, 0, s>>>(img, mask, out, npx4, (unsigned)color);
+    }
     if (npx4 * 4 < npx)
         composite_scalar_kernel<<<lf::stream_grid(npx - npx4 * 4, kBlock), kBlock, 0, s>>>(
             img, mask, out, npx4 * 4, npx, (unsigned)color);
@@ -1044,8 +1065,12 @@ int lf_rgb2hsv_u8(const uint8_t* rgb, uint8_t* hsv, size_t npixels, lf_stream_t 
     LF_REQUIRE(npixels > 0, "lf_rgb2hsv: empty input");
     LF_REQUIRE(((reinterpret_cast<size_t>(rgb) | reinterpret_cast<size_t>(hsv)) & 3) == 0,
                "lf_rgb2hsv: buffers must be 4-byte aligned");
-    rgb2hsv_kernel<<<lf::stream_grid(npixels / 4 + 1, kBlock), kBlock, 0, lf::as_stream(stream)>>>(
-        rgb, hsv, npixels);
+    // four 4-pixel groups per thread: the per-workgroup divide tables stay a small share
+    const unsigned grid = lf::stream_grid(npixels / 16 + 1, kBlock, lf::kFullGrid);
+    if (lf::streaming(npixels * 6))
+        rgb2hsv_kernel<true><<<grid, kBlock, 0, lf::as_stream(stream)>>>(rgb, hsv, npixels);
+    else
+        rgb2hsv_kernel<false><<<grid, kBlock, 0, lf::as_stream(stream)>>>(rgb, hsv, npixels);
     return lf::check_launch("lf_rgb2hsv");
 }
 
@@ -1054,8 +1079,11 @@ int lf_rgb2gray_u8(const uint8_t* rgb, uint8_t* gray, size_t npixels, lf_stream_
     LF_REQUIRE(npixels > 0, "lf_rgb2gray: empty input");
     LF_REQUIRE(((reinterpret_cast<size_t>(rgb) | reinterpret_cast<size_t>(gray)) & 3) == 0,
                "lf_rgb2gray: buffers must be 4-byte aligned");
-    rgb2gray_kernel<<<lf::stream_grid(npixels / 4 + 1, kBlock), kBlock, 0,
-                      lf::as_stream(stream)>>>(rgb, gray, npixels);
+    const unsigned grid = lf::stream_grid(npixels / 4 + 1, kBlock, lf::kFullGrid);
+    if (lf::streaming(npixels * 4))
+        rgb2gray_kernel<true><<<grid, kBlock, 0, lf::as_stream(stream)>>>(rgb, gray, npixels);
+    else
+        rgb2gray_kernel<false><<<grid, kBlock, 0, lf::as_stream(stream)>>>(rgb, gray, npixels);
     return lf::check_launch("lf_rgb2gray");
 }
 

@@ -40,4 +40,32 @@ inline unsigned stream_grid(size_t work_items, unsigned block, unsigned cap = 25
     return (unsigned)g;
 }
 
+// Byte-moving kernels run one short pass per thread on the largest grid that fits
+// (measured on MI355X, 4096 x 224x224x3: a 2048-workgroup grid-stride copy moves
+// 5.1 TB/s, one 16-byte item per thread 6.1 TB/s, the same with nontemporal accesses
+// 6.6 TB/s; scripts/microbench/copy_bw.hip).
+constexpr unsigned kFullGrid = 1u << 30;
+
+// Nontemporal accesses pay once the launch is larger than what the Infinity Cache would
+// have kept for the next kernel anyway (256 MiB); below that plain accesses win
+// (ping-pong copy of 512 images: 7.0 TB/s plain, 6.3 TB/s nontemporal).
+inline bool streaming(size_t bytes_touched) { return bytes_touched >= ((size_t)256 << 20); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#if defined(__HIPCC__)
+template <bool NT, typename T>
+__device__ __forceinline__ T ldg(const T* p) {
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void stg(T* p, T v) {
+    if (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+#endif
+
 }  // namespace lf
