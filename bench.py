@@ -182,6 +182,8 @@ def augment_throughput(dev, n=4096, iters=5, only=None):
         "gauss_blur_5x5": (lambda: ops.gauss_blur_u8(x, 5, 1.5), 2 * img_b),
         "gauss_blur_15x15": (lambda: ops.gauss_blur_u8(x, 15, 0.0), 2 * img_b),
         "rgb2hsv": (lambda: ops.rgb2hsv_u8(x), 2 * img_b),
+        # the whole saliency filter of transform/filters/blur.py (image + leaf mask in, image out)
+        "blur_saliency": (lambda: ops.blur_saliency_u8(x, mask), 2 * img_b + IMG * IMG),
     }
     out, inv = {}, 0.0
     if only:

@@ -124,6 +124,21 @@ int lf_gauss_blur_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int c
 int lf_hsv_region_stats(const uint8_t* rgb, int32_t* counts, int32_t* hsv_hist, int n, int h,
                         int w, lf_stream_t stream);
 
+/* apply_blur_filter (srcs/transform/filters/blur.py:18-79) given the leaf mask its
+ * make_mask_func returned (leaf = mask > 0): gray -> Canny(50,150,L2) dilated by the 3x3
+ * MORPH_ELLIPSE element (x0.4) + uint8(min-max normalised Sobel magnitude) (x0.3) + brown
+ * regions (hue_lo <= H <= hue_hi, S >= s_min, V <= v_max, inside the leaf; closed, then dilated
+ * twice) (x0.6, skipped when use_brown = 0) + min-max normalised mean |rgb - GaussianBlur15|
+ * (x0.2) -> min-max normalised to uint8 -> GaussianBlur 5x5 -> kept under the leaf mask,
+ * replicated to RGB.  rgb/out [n][h][w][3], leaf_mask [n][h][w]; kq15 / kq5: HOST arrays of
+ * the 8.8 fixed-point Gaussian taps (15 taps for sigma 0 -> 2.6, 5 taps for cfg.gaussian_sigma).
+ * Parity unpinned (no cv2); every step follows oracle/cv_ops.py:blur_saliency bit for bit. */
+size_t lf_blur_saliency_workspace(int n, int h, int w);
+int lf_blur_saliency_u8(const uint8_t* rgb, const uint8_t* leaf_mask, uint8_t* out, int n, int h,
+                        int w, int use_brown, int hue_lo, int hue_hi, int s_min, int v_max,
+                        const uint16_t* kq15, const uint16_t* kq5, void* workspace,
+                        size_t ws_bytes, lf_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* Geometric ops (Pillow semantics, bit-exact; coordinates in IEEE double)    */
 /* ------------------------------------------------------------------------- */

@@ -36,6 +36,9 @@ SIGNATURES = {
     "lf_rgb2gray_u8": [P, P, c_size_t, P],
     "lf_gauss_blur_u8": [P, P, c_int, c_int, c_int, c_int, P, c_int, P],
     "lf_hsv_region_stats": [P, P, P, c_int, c_int, c_int, P],
+    "lf_blur_saliency_workspace": [c_int, c_int, c_int],
+    "lf_blur_saliency_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P,
+                            c_size_t, P],
     "lf_warp_bicubic_u8": [P, P, P, c_int, c_int, c_int, c_int, P],
     "lf_affine_nearest_fixed_u8": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "lf_resample_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int,
@@ -85,7 +88,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t,
              "lf_bn_workspace": c_size_t, "lf_se_bwd_workspace": c_size_t,
-             "lf_adamw_workspace": c_size_t, "lf_conv2d_stats_tiles": C.c_longlong}
+             "lf_adamw_workspace": c_size_t, "lf_conv2d_stats_tiles": C.c_longlong,
+             "lf_blur_saliency_workspace": c_size_t}
 
 
 class LeafHipError(RuntimeError):

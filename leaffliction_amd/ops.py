@@ -222,6 +222,29 @@ def gauss_blur_u8(x: torch.Tensor, ksize: int, sigma: float) -> torch.Tensor:
     return out
 
 
+def blur_saliency_u8(x: torch.Tensor, leaf_mask: torch.Tensor, gaussian_sigma: float = 1.5,
+                     brown_hue_range=(0, 30), brown_s_min: int = 20, brown_v_max: int = 200,
+                     use_brown: bool = True) -> torch.Tensor:
+    """apply_blur_filter (srcs/transform/filters/blur.py:18-79) for a batch [N,H,W,3] uint8 and
+    the leaf masks [N,H,W] uint8 (leaf = mask > 0) its make_mask_func produced; defaults are
+    srcs/transform/config.yaml:2,42-44.  Returns the gray saliency image replicated to RGB."""
+    n, h, w = _hwc(x, "blur_saliency.x")
+    _chk(leaf_mask, _U8, "blur_saliency.leaf_mask", 3)
+    if tuple(leaf_mask.shape) != (n, h, w) or leaf_mask.device != x.device:
+        raise ValueError(f"blur_saliency.leaf_mask: expected {[n, h, w]} on {x.device}, got "
+                         f"{list(leaf_mask.shape)} on {leaf_mask.device}")
+    kq15 = np.ascontiguousarray(gaussian_kernel_q8(15, 0.0).astype(np.uint16))  # host constants
+    kq5 = np.ascontiguousarray(gaussian_kernel_q8(5, float(gaussian_sigma)).astype(np.uint16))
+    nbytes = int(_lib.load().lf_blur_saliency_workspace(n, h, w))
+    ws = torch.empty(nbytes, dtype=_U8, device=x.device)
+    out = torch.empty_like(x)
+    _lib.call("lf_blur_saliency_u8", x.data_ptr(), leaf_mask.data_ptr(), out.data_ptr(), n, h, w,
+              1 if use_brown else 0, int(brown_hue_range[0]), int(brown_hue_range[1]),
+              int(brown_s_min), int(brown_v_max), kq15.ctypes.data, kq5.ctypes.data, ws.data_ptr(),
+              nbytes, _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------
 # geometric ops (Pillow semantics)
 # ---------------------------------------------------------------------------

@@ -161,3 +161,127 @@ def hsv_region_stats(rgb: np.ndarray):
     counts = np.array([int(p.sum()) for p in preds], dtype=np.int64)
     hist = np.stack([np.bincount(c[leaf], minlength=256) for c in (h, s, v)])
     return counts, hist
+
+
+# ---------------------------------------------------------------------------
+# apply_blur_filter (srcs/transform/filters/blur.py:18-79).  PARITY UNPINNED like the rest of
+# this file: the steps restate OpenCV 4.x's CPU paths (imgproc canny.cpp, deriv.cpp Sobel,
+# morph.dispatch, core norm.cpp normalize + convert_scale.simd cvt_32f with its fused
+# multiply-add) and numpy's float32 arithmetic in the order blur.py applies it.
+# ---------------------------------------------------------------------------
+def _replicate(idx: np.ndarray, n: int) -> np.ndarray:
+    return np.clip(idx, 0, n - 1)
+
+
+def sobel3(gray: np.ndarray, border: str):
+    """cv2.Sobel(gray, ddepth, 1|0, 0|1, ksize=3) as exact integers (dx, dy).
+    border: 'replicate' (what cv2.Canny asks for) or 'reflect101' (cv2.Sobel's default)."""
+    h, w = gray.shape
+    fn = _replicate if border == "replicate" else _reflect101
+    yi = fn(np.arange(-1, h + 1), h)
+    xi = fn(np.arange(-1, w + 1), w)
+    p = gray.astype(np.int64)[yi][:, xi]
+    dx = (p[:-2, 2:] + 2 * p[1:-1, 2:] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[1:-1, :-2] + p[2:, :-2])
+    dy = (p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:])
+    return dx, dy
+
+
+def canny(gray: np.ndarray, low: float, high: float) -> np.ndarray:
+    """cv2.Canny(gray, low, high, L2gradient=True), aperture 3 (blur.py:30): squared thresholds
+    on dx^2 + dy^2, 22.5/67.5-degree sector tests in 15-bit fixed point (TG22 = 13573),
+    asymmetric > / >= neighbour tests, 8-connected hysteresis."""
+    h, w = gray.shape
+    lo = int(np.floor(min(32767.0, low) ** 2)) if low > 0 else int(np.floor(low))
+    hi = int(np.floor(min(32767.0, high) ** 2)) if high > 0 else int(np.floor(high))
+    dx, dy = sobel3(gray, "replicate")
+    mag = np.zeros((h + 2, w + 2), dtype=np.int64)
+    mag[1:-1, 1:-1] = dx * dx + dy * dy
+    m = mag[1:-1, 1:-1]
+    x = np.abs(dx)
+    y = np.abs(dy) << 15
+    tg22x = x * 13573
+    tg67x = tg22x + (x << 16)
+    left, right = mag[1:-1, :-2], mag[1:-1, 2:]
+    up, down = mag[:-2, 1:-1], mag[2:, 1:-1]
+    s_pos = (dx ^ dy) < 0                      # s = +1 : previous row j-1, next row j+1
+    prev_d = np.where(s_pos, mag[:-2, :-2], mag[:-2, 2:])
+    next_d = np.where(s_pos, mag[2:, 2:], mag[2:, :-2])
+    horiz = y < tg22x
+    vert = ~horiz & (y > tg67x)
+    diag = ~horiz & ~vert
+    keep = (m > lo) & ((horiz & (m > left) & (m >= right)) | (vert & (m > up) & (m >= down)) |
+                       (diag & (m > prev_d) & (m > next_d)))
+    strong = keep & (m > hi)
+    weak = keep & ~strong
+    while True:
+        pad = np.zeros((h + 2, w + 2), dtype=bool)
+        pad[1:-1, 1:-1] = strong
+        near = np.zeros((h, w), dtype=bool)
+        for oy in range(3):
+            for ox in range(3):
+                near |= pad[oy:oy + h, ox:ox + w]
+        grow = weak & near & ~strong
+        if not grow.any():
+            break
+        strong |= grow
+    return (strong * 255).astype(np.uint8)
+
+
+def morph_cross3(img: np.ndarray, erode: bool) -> np.ndarray:
+    """cv2.dilate / cv2.erode with getStructuringElement(MORPH_ELLIPSE, (3,3)) (a plus-shaped
+    element), default border: pixels outside the image never win (blur.py:31-33,57-60)."""
+    h, w = img.shape
+    fill = 255 if erode else 0
+    pad = np.full((h + 2, w + 2), fill, dtype=np.uint8)
+    pad[1:-1, 1:-1] = img
+    taps = [pad[1:-1, 1:-1], pad[:-2, 1:-1], pad[2:, 1:-1], pad[1:-1, :-2], pad[1:-1, 2:]]
+    out = taps[0]
+    for t in taps[1:]:
+        out = np.minimum(out, t) if erode else np.maximum(out, t)
+    return out
+
+
+def normalize_minmax_f32(src: np.ndarray) -> np.ndarray:
+    """cv2.normalize(src, None, 0, 255, cv2.NORM_MINMAX) for a float32 image: double scale and
+    shift, then convertTo's float32 fused multiply-add per pixel."""
+    src = src.astype(np.float32)
+    smin, smax = float(src.min()), float(src.max())
+    scale = 255.0 * ((1.0 / (smax - smin)) if (smax - smin) > np.finfo(np.float64).eps else 0.0)
+    shift = 0.0 - smin * scale
+    a, b = np.float32(scale), np.float32(shift)
+    # fma(x, a, b) rounded once to float32: the 80-bit product/sum below is exact for these ranges
+    wide = src.astype(np.longdouble) * np.longdouble(a) + np.longdouble(b)
+    return wide.astype(np.float32)
+
+
+def blur_saliency(rgb: np.ndarray, mask: np.ndarray, gaussian_sigma: float = 1.5,
+                  brown_hue_range=(0, 30), brown_s_min: int = 20, brown_v_max: int = 200,
+                  use_brown: bool = True) -> np.ndarray:
+    """apply_blur_filter (blur.py:18-79) for one image given the leaf mask `make_mask` returned
+    (defaults: srcs/transform/config.yaml:2,42-44)."""
+    leaf = (mask > 0) if mask.ndim == 2 else (mask[..., 0] > 0)
+    gray = rgb2gray(rgb)
+    f32 = np.float32
+    edges = morph_cross3(canny(gray, 50, 150), erode=False)
+    sal = edges.astype(f32) * f32(0.4)
+    gx, gy = sobel3(gray, "reflect101")
+    gmag = np.sqrt((gx * gx + gy * gy).astype(f32))
+    gnorm = normalize_minmax_f32(gmag).astype(np.uint8)
+    sal = sal + gnorm.astype(f32) * f32(0.3)
+    if use_brown:
+        hsv = rgb2hsv(rgb)
+        hh, ss, vv = hsv[..., 0], hsv[..., 1], hsv[..., 2]
+        brown = ((hh >= brown_hue_range[0]) & (hh <= brown_hue_range[1]) & (ss >= brown_s_min) &
+                 (vv <= brown_v_max) & leaf).astype(np.uint8) * 255
+        closed = morph_cross3(morph_cross3(brown, erode=False), erode=True)
+        grown = morph_cross3(morph_cross3(closed, erode=False), erode=False)
+        sal = sal + grown.astype(f32) * f32(0.6)
+    blurred = gaussian_blur(rgb, 15, 0.0)
+    diff = np.abs(rgb.astype(f32) - blurred.astype(f32))
+    cdiff = (diff[..., 0] + diff[..., 1] + diff[..., 2]) / f32(3.0)
+    sal = sal + normalize_minmax_f32(cdiff) * f32(0.2)
+    sal_u8 = normalize_minmax_f32(sal).astype(np.uint8)
+    sal_blur = gaussian_blur(sal_u8, 5, gaussian_sigma)
+    out = np.zeros_like(gray)
+    out[leaf] = sal_blur[leaf]
+    return np.repeat(out[..., None], 3, axis=2)

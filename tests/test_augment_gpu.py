@@ -143,6 +143,27 @@ def test_gauss_blur_bit_exact(cuda, h, w, ksize, sigma):
         assert np.array_equal(got[i], CV.gaussian_blur(g[i], ksize, sigma))
 
 
+@pytest.mark.parametrize("h,w", [(224, 224), (64, 48), (33, 17), (416, 400)])
+def test_blur_saliency_bit_exact(cuda, h, w):
+    """apply_blur_filter (blur.py:18-79) given the leaf mask: every pixel equal to the oracle's.
+    416x400 does not fit the LDS copy of the Canny map (hysteresis sweeps in global memory)."""
+    from leaffliction_amd import ops
+    n = 2 if h > 300 else 4
+    x = batch_inputs(n, h, w, 9)
+    yy, xx = np.mgrid[0:h, 0:w]
+    rng = np.random.RandomState(3)
+    masks = np.stack([(((yy - h // 2) ** 2 + (xx - w // 2) ** 2 <= (min(h, w) * (0.3 + 0.05 * i)) ** 2)
+                       * rng.choice([1, 200, 255])).astype(np.uint8) for i in range(n)])
+    got = ops.blur_saliency_u8(dev(x, cuda), dev(masks, cuda)).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], CV.blur_saliency(x[i], masks[i])), i
+    got = ops.blur_saliency_u8(dev(x, cuda), dev(masks, cuda), gaussian_sigma=0.8, brown_hue_range=(5, 25),
+                               brown_s_min=40, brown_v_max=180).cpu().numpy()
+    assert np.array_equal(got[1], CV.blur_saliency(x[1], masks[1], 0.8, (5, 25), 40, 180))
+    got = ops.blur_saliency_u8(dev(x, cuda), dev(masks, cuda), use_brown=False).cpu().numpy()
+    assert np.array_equal(got[0], CV.blur_saliency(x[0], masks[0], use_brown=False))
+
+
 def test_golden_augmenter_cases(cuda, golden):
     """Every reference ImageAugmenter output (42 cases) reproduced bit-exactly on the GPU."""
     import torch

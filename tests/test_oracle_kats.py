@@ -150,3 +150,56 @@ def test_param_count_matches_survey():
     assert n == 1_250_756
     assert sum(int(np.prod(s)) for _n, s, _k in R.param_specs(8, [32, 64, 128])) == 314_020
     assert sum(int(np.prod(s)) for _n, s, _k in R.param_specs(8, [16, 32, 64])) == 79_382
+
+
+def test_canny_step_edge_and_flat():
+    """A vertical 0->255 step gives equal Sobel magnitudes on both sides of the step; Canny's
+    asymmetric test (m > left, m >= right) keeps the left one only.  Flat input: no edges."""
+    g = np.zeros((8, 10), np.uint8)
+    g[:, 5:] = 255
+    e = CV.canny(g, 50, 150)
+    assert e[:, 4].tolist() == [255] * 8 and int(e.sum()) == 8 * 255
+    assert int(CV.canny(g.T.copy(), 50, 150)[4].sum()) == 8 * 255      # horizontal step: row 4
+    assert int(CV.canny(np.full((6, 6), 77, np.uint8), 50, 150).sum()) == 0
+
+
+def test_canny_hysteresis_keeps_weak_only_next_to_strong():
+    """A ramp edge whose gradient magnitude is between the thresholds (weak) survives only where it
+    touches a strong segment."""
+    g = np.zeros((12, 12), np.uint8)
+    g[:6, 6:] = 200          # strong edge on rows 0..5 (dx = 800 > 150)
+    g[6:, 6:] = 20           # weak edge on rows 6..11 (dx = 80, between 50 and 150)
+    e = CV.canny(g, 50, 150)
+    assert e[:5, 5].tolist() == [255] * 5
+    assert e[6:, 5].tolist() == [255] * 6      # weak run connected to the strong one: kept
+    iso = np.zeros((12, 12), np.uint8)
+    iso[:, 6:] = 20          # weak everywhere, no strong seed: dropped
+    assert int(CV.canny(iso, 50, 150).sum()) == 0
+
+
+def test_morph_cross_and_minmax_normalise():
+    m = np.zeros((5, 5), np.uint8)
+    m[2, 2] = 255
+    d = CV.morph_cross3(m, erode=False)
+    assert d.tolist() == [[0, 0, 0, 0, 0], [0, 0, 255, 0, 0], [0, 255, 255, 255, 0], [0, 0, 255, 0, 0],
+                          [0, 0, 0, 0, 0]]
+    assert int(CV.morph_cross3(d, erode=True).sum()) == 255 and CV.morph_cross3(d, erode=True)[2, 2] == 255
+    full = np.full((4, 4), 255, np.uint8)     # the border never erodes a full image
+    assert np.array_equal(CV.morph_cross3(full, erode=True), full)
+    x = np.array([[0.0, 1.0], [2.0, 3.0]], np.float32)
+    assert CV.normalize_minmax_f32(x).tolist() == [[0.0, 85.0], [170.0, 255.0]]
+    assert CV.normalize_minmax_f32(np.full((3, 3), 7.5, np.float32)).tolist() == [[0.0] * 3] * 3
+
+
+def test_blur_saliency_flat_image_and_mask():
+    """Flat image: no edges, zero gradient, zero colour difference -> all-zero output; the output
+    is gray replicated to RGB and zero outside the leaf mask."""
+    flat = np.full((20, 24, 3), 90, np.uint8)
+    mask = np.full((20, 24), 255, np.uint8)
+    assert int(CV.blur_saliency(flat, mask).sum()) == 0
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, (20, 24, 3)).astype(np.uint8)
+    mask[:, :12] = 0
+    out = CV.blur_saliency(img, mask)
+    assert out.shape == (20, 24, 3) and int(out[:, :12].sum()) == 0 and int(out[:, 12:].sum()) > 0
+    assert np.array_equal(out[..., 0], out[..., 1]) and np.array_equal(out[..., 0], out[..., 2])

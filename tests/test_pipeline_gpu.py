@@ -235,3 +235,34 @@ def test_five_step_workflow_distribution_augment_split_train_predict(cuda, tmp_p
                       "--sample-size", "8", "--target-acc", "0.7", "--max-attempts", "3", "-learnings", str(mdir)])
     ev = json.loads((tmp_path / "artifacts/prediction_output/evaluation/evaluation_results.json").read_text())
     assert ev["metrics"]["accuracy"] >= 0.7 and ev["evaluation_info"]["valid_predictions"] == 8
+
+
+def test_transform_filters_host_mirror(cuda):
+    """apply_blur_filter / analyze_color_regions with the reference's call shapes (blur.py:18-20,
+    hist.py:22-24,188-189) against the oracle."""
+    import numpy as np
+    from conftest import leaf_like
+    from leaffliction_amd.transform import TransformConfig, analyze_color_regions, apply_blur_filter, hue_range_counts
+    from leaffliction_amd.transform.filters import REGION_KEYS, HUE_KEYS
+    from oracle import cv_ops as CV
+    img = leaf_like(96, 80, 4)
+    yy, xx = np.mgrid[0:96, 0:80]
+    mask = (((yy - 48) ** 2 + (xx - 40) ** 2) <= 30 ** 2).astype(np.uint8) * 255
+    cfg = TransformConfig()
+    out = apply_blur_filter(img, cfg, lambda rgb: (mask, None))
+    assert np.array_equal(out, CV.blur_saliency(img, mask))
+    out3 = apply_blur_filter(img, cfg, lambda rgb: (np.repeat(mask[..., None], 3, 2), None))   # 3-channel mask
+    assert np.array_equal(out3, out)
+    assert apply_blur_filter(img, cfg, lambda rgb: (None, None)) is img                        # blur.py:22-24
+
+    class NoBrown:
+        gaussian_sigma = 1.5
+    assert np.array_equal(apply_blur_filter(img, NoBrown(), lambda rgb: (mask, None)),
+                          CV.blur_saliency(img, mask, use_brown=False))
+    counts, _ = CV.hsv_region_stats(img)
+    got = analyze_color_regions(img)
+    assert list(got) == list(REGION_KEYS)
+    for i, k in enumerate(REGION_KEYS):
+        assert got[k] == (int(counts[1 + i]) / int(counts[0])) * 100
+    assert hue_range_counts(img) == {k: int(counts[9 + i]) for i, k in enumerate(HUE_KEYS)}
+    assert analyze_color_regions(np.zeros((8, 8, 3), np.uint8)) == {}
