@@ -245,14 +245,21 @@ def main() -> None:
                      "(--nproc-per-node N --master-addr 127.0.0.1)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a box with fewer GPUs than ranks (BENCH_BACKEND=gloo): ranks share the cards
+    # and the collectives go through gloo; the driver's runs use one GPU per rank over RCCL.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from leaffliction_amd import _lib
     from leaffliction_amd.model.cnn import LeafCNN
@@ -276,7 +283,11 @@ def main() -> None:
     grad_sync = None
     if world > 1:
         def grad_sync(flat_g):  # one flat bucket, averaged over ranks (RCCL over xGMI)
-            dist.all_reduce(flat_g, op=dist.ReduceOp.AVG)
+            if backend == "nccl":
+                dist.all_reduce(flat_g, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+                flat_g.mul_(1.0 / world)
 
     def lr_at(step):
         return 2e-3 * 0.5 * (1.0 + math.cos(math.pi * min(step, total) / total))

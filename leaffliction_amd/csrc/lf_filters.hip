@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kPxPerThread = 8;  // passes that end in a per-image min / max: fewer, fatter workgroups
 constexpr int kHystThreads = 1024;
 constexpr unsigned kInfBits = 0x7f800000u;
 
@@ -47,15 +48,35 @@ __device__ __forceinline__ Sob sobel_at(const uint8_t* g, int w, int y0, int y1,
     return s;
 }
 
-// Per-image min / max of non-negative floats through their bit patterns (monotone as uint).
-__device__ __forceinline__ void minmax_publish(float v, bool valid, unsigned* mn, unsigned* mx) {
-    unsigned lo = valid ? __float_as_uint(v) : kInfBits, hi = valid ? __float_as_uint(v) : 0u;
+// Per-image min / max of non-negative floats through their bit patterns (monotone as uint):
+// wave shuffle, then the four waves through LDS, one atomic pair per workgroup.
+struct MinMax {
+    unsigned lo = kInfBits, hi = 0u;
+    __device__ __forceinline__ void take(float v) {
+        lo = min(lo, __float_as_uint(v));
+        hi = max(hi, __float_as_uint(v));
+    }
+};
+
+__device__ __forceinline__ void minmax_publish(MinMax r, unsigned* mn, unsigned* mx) {
+    __shared__ unsigned wlo[kBlock / 64], whi[kBlock / 64];
+    unsigned lo = r.lo, hi = r.hi;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64));
         hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64));
     }
     if ((threadIdx.x & 63) == 0) {
+        wlo[threadIdx.x >> 6] = lo;
+        whi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 1; k < kBlock / 64; ++k) {
+            lo = min(lo, wlo[k]);
+            hi = max(hi, whi[k]);
+        }
         atomicMin(mn, lo);
         atomicMax(mx, hi);
     }
@@ -91,9 +112,10 @@ __global__ __launch_bounds__(kBlock) void sal_sobel_kernel(const uint8_t* __rest
     const unsigned n = blockIdx.y;
     const int hw = h * w;
     const uint8_t* g = gray + (size_t)n * hw;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    float gm = 0.0f;
-    if (p < hw) {
+    MinMax mmx;
+    for (int k = 0; k < kPxPerThread; ++k) {
+        const int p = (blockIdx.x * kPxPerThread + k) * kBlock + threadIdx.x;
+        if (p >= hw) break;
         const int y = p / w, x = p - y * w;
         const Sob s = sobel_at(g, w, clampi(y - 1, 0, h - 1), y, clampi(y + 1, 0, h - 1),
                                clampi(x - 1, 0, w - 1), x, clampi(x + 1, 0, w - 1));
@@ -103,10 +125,11 @@ __global__ __launch_bounds__(kBlock) void sal_sobel_kernel(const uint8_t* __rest
         if (x == 0 || y == 0 || x == w - 1 || y == h - 1)
             r = sobel_at(g, w, reflect101i(y - 1, h), y, reflect101i(y + 1, h), reflect101i(x - 1, w), x,
                          reflect101i(x + 1, w));
-        gm = __fsqrt_rn((float)(r.dx * r.dx + r.dy * r.dy));  // the sum is < 2^24: exact in float32
+        const float gm = __fsqrt_rn((float)(r.dx * r.dx + r.dy * r.dy));  // the sum is < 2^24: exact
         gmag[(size_t)n * hw + p] = gm;
+        mmx.take(gm);
     }
-    minmax_publish(gm, p < hw, mm + n * 6 + 0, mm + n * 6 + 1);
+    minmax_publish(mmx, mm + n * 6 + 0, mm + n * 6 + 1);
 }
 
 // Non-maximum suppression + double threshold: map = 1 (no edge), 0 (weak), 2 (strong).
@@ -209,6 +232,27 @@ __global__ __launch_bounds__(kBlock) void morph_cross_kernel(const uint8_t* __re
     out[(size_t)n * hw + p] = (uint8_t)v;
 }
 
+// The planes this filter dilates / erodes hold 0 or 255 only, so max / min are OR / AND and four
+// pixels go through as one dword (w % 4 == 0): the left / right neighbours are byte funnels
+// with the adjacent dwords.
+template <bool ERODE>
+__global__ __launch_bounds__(kBlock) void morph_cross_bin4_kernel(const uint32_t* __restrict__ in,
+                                                                  uint32_t* __restrict__ out, int h,
+                                                                  int w4) {
+    const unsigned n = blockIdx.y;
+    const int total = h * w4;
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t* s = in + (size_t)n * total;
+    const int y = t / w4, g = t - y * w4;
+    const unsigned ident = ERODE ? 0xffffffffu : 0u;
+    const unsigned c = s[t];
+    const unsigned up = y > 0 ? s[t - w4] : ident, dn = y < h - 1 ? s[t + w4] : ident;
+    const unsigned pv = g > 0 ? s[t - 1] : ident, nx = g < w4 - 1 ? s[t + 1] : ident;
+    const unsigned left = (c << 8) | (pv >> 24), right = (c >> 8) | (nx << 24);
+    out[(size_t)n * total + t] = ERODE ? (c & up & dn & left & right) : (c | up | dn | left | right);
+}
+
 // brown_regions of blur.py:47-53 as a 0 / 255 plane (OpenCV 8-bit RGB2HSV, H in [0,180)).
 __global__ __launch_bounds__(kBlock) void brown_mask_kernel(const uint8_t* __restrict__ rgb,
                                                             const uint8_t* __restrict__ leaf,
@@ -239,9 +283,10 @@ __global__ __launch_bounds__(kBlock) void color_diff_kernel(const uint8_t* __res
                                                             float* __restrict__ cdiff,
                                                             unsigned* __restrict__ mm, int hw) {
     const unsigned n = blockIdx.y;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    float v = 0.0f;
-    if (p < hw) {
+    MinMax mmx;
+    for (int k = 0; k < kPxPerThread; ++k) {
+        const int p = (blockIdx.x * kPxPerThread + k) * kBlock + threadIdx.x;
+        if (p >= hw) break;
         const size_t o = ((size_t)n * hw + p) * 3;
         int acc = 0;
 #pragma unroll
@@ -249,10 +294,11 @@ __global__ __launch_bounds__(kBlock) void color_diff_kernel(const uint8_t* __res
             const int d = (int)rgb[o + c] - (int)blurred[o + c];
             acc += d < 0 ? -d : d;
         }
-        v = __fdiv_rn((float)acc, 3.0f);
+        const float v = __fdiv_rn((float)acc, 3.0f);
         cdiff[(size_t)n * hw + p] = v;
+        mmx.take(v);
     }
-    minmax_publish(v, p < hw, mm + n * 6 + 2, mm + n * 6 + 3);
+    minmax_publish(mmx, mm + n * 6 + 2, mm + n * 6 + 3);
 }
 
 // saliency = 0.4 edges + 0.3 uint8(norm(gradient)) + 0.6 brown + 0.2 norm(colour diff), each
@@ -264,31 +310,41 @@ __global__ __launch_bounds__(kBlock) void saliency_kernel(const uint8_t* __restr
                                                           float* __restrict__ sal,
                                                           unsigned* __restrict__ mm, int hw) {
     const unsigned n = blockIdx.y;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    float ga, gb, ca, cb;
-    norm_coeffs(mm[n * 6 + 0], mm[n * 6 + 1], ga, gb);
-    norm_coeffs(mm[n * 6 + 2], mm[n * 6 + 3], ca, cb);
-    float s = 0.0f;
-    if (p < hw) {
+    __shared__ float coef[4];
+    if (threadIdx.x == 0) {
+        norm_coeffs(mm[n * 6 + 0], mm[n * 6 + 1], coef[0], coef[1]);
+        norm_coeffs(mm[n * 6 + 2], mm[n * 6 + 3], coef[2], coef[3]);
+    }
+    __syncthreads();
+    const float ga = coef[0], gb = coef[1], ca = coef[2], cb = coef[3];
+    MinMax mmx;
+    for (int k = 0; k < kPxPerThread; ++k) {
+        const int p = (blockIdx.x * kPxPerThread + k) * kBlock + threadIdx.x;
+        if (p >= hw) break;
         const size_t i = (size_t)n * hw + p;
-        s = (float)edges[i] * 0.4f;
+        float s = (float)edges[i] * 0.4f;
         s = s + (float)trunc_u8(__fmaf_rn(gmag[i], ga, gb)) * 0.3f;
         if (brown) s = s + (float)brown[i] * 0.6f;
         s = s + __fmaf_rn(cdiff[i], ca, cb) * 0.2f;
         sal[i] = s;
+        mmx.take(s);
     }
-    minmax_publish(s, p < hw, mm + n * 6 + 4, mm + n * 6 + 5);
+    minmax_publish(mmx, mm + n * 6 + 4, mm + n * 6 + 5);
 }
 
 __global__ __launch_bounds__(kBlock) void saliency_norm_kernel(const float* __restrict__ sal,
                                                                const unsigned* __restrict__ mm,
                                                                uint8_t* __restrict__ out, int hw) {
     const unsigned n = blockIdx.y;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= hw) return;
-    float a, b;
-    norm_coeffs(mm[n * 6 + 4], mm[n * 6 + 5], a, b);
-    out[(size_t)n * hw + p] = trunc_u8(__fmaf_rn(sal[(size_t)n * hw + p], a, b));
+    __shared__ float coef[2];
+    if (threadIdx.x == 0) norm_coeffs(mm[n * 6 + 4], mm[n * 6 + 5], coef[0], coef[1]);
+    __syncthreads();
+    const float a = coef[0], b = coef[1];
+    for (int k = 0; k < kPxPerThread; ++k) {
+        const int p = (blockIdx.x * kPxPerThread + k) * kBlock + threadIdx.x;
+        if (p >= hw) break;
+        out[(size_t)n * hw + p] = trunc_u8(__fmaf_rn(sal[(size_t)n * hw + p], a, b));
+    }
 }
 
 // result[leaf] = blurred saliency, elsewhere 0, replicated to three channels.
@@ -346,10 +402,11 @@ int lf_blur_saliency_u8(const uint8_t* rgb, const uint8_t* leaf_mask, uint8_t* o
     float* sal = reinterpret_cast<float*>(dxdy);    // so is (dx, dy)
 
     const dim3 grid_px((hw + kBlock - 1) / kBlock, n);
+    const dim3 grid_fat((hw + kBlock * kPxPerThread - 1) / (kBlock * kPxPerThread), n);
     minmax_init_kernel<<<(n * 6 + 255) / 256, 256, 0, s>>>(mm, n);
     int rc = lf_rgb2gray_u8(rgb, pa, px, stream);
     if (rc != LF_OK) return rc;
-    sal_sobel_kernel<<<grid_px, kBlock, 0, s>>>(pa, mag2, dxdy, gmag, mm, h, w);
+    sal_sobel_kernel<<<grid_fat, kBlock, 0, s>>>(pa, mag2, dxdy, gmag, mm, h, w);
     // cv2.Canny(gray, 50, 150, L2gradient=True): thresholds are compared squared
     canny_nms_kernel<<<grid_px, kBlock, 0, s>>>(mag2, dxdy, pb, h, w, 50 * 50, 150 * 150);
     {
@@ -364,20 +421,37 @@ int lf_blur_saliency_u8(const uint8_t* rgb, const uint8_t* leaf_mask, uint8_t* o
         canny_hysteresis_kernel<<<n, kHystThreads, in_lds ? (size_t)((hw + 15) & ~15) : 0, s>>>(pb, h, w,
                                                                                                  in_lds);
     }
-    morph_cross_kernel<false><<<grid_px, kBlock, 0, s>>>(pb, pc, h, w);
+    // binary planes, 16-byte aligned, so rows of w % 4 == 0 pixels go four at a time
+    const bool quad = w % 4 == 0;
+    const dim3 grid_q((hw / 4 + kBlock - 1) / kBlock, n);
+    auto morph = [&](const uint8_t* src, uint8_t* dst, bool erode) {
+        if (quad) {
+            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src);
+            uint32_t* d4 = reinterpret_cast<uint32_t*>(dst);
+            if (erode)
+                morph_cross_bin4_kernel<true><<<grid_q, kBlock, 0, s>>>(s4, d4, h, w / 4);
+            else
+                morph_cross_bin4_kernel<false><<<grid_q, kBlock, 0, s>>>(s4, d4, h, w / 4);
+        } else if (erode) {
+            morph_cross_kernel<true><<<grid_px, kBlock, 0, s>>>(src, dst, h, w);
+        } else {
+            morph_cross_kernel<false><<<grid_px, kBlock, 0, s>>>(src, dst, h, w);
+        }
+    };
+    morph(pb, pc, false);
     if (use_brown) {
         brown_mask_kernel<<<lf::stream_grid(px / 4 + 1, kBlock, lf::kFullGrid), kBlock, 0, s>>>(
             rgb, leaf_mask, pa, px, hue_lo, hue_hi, s_min, v_max);
-        morph_cross_kernel<false><<<grid_px, kBlock, 0, s>>>(pa, pb, h, w);  // MORPH_CLOSE
-        morph_cross_kernel<true><<<grid_px, kBlock, 0, s>>>(pb, pa, h, w);
-        morph_cross_kernel<false><<<grid_px, kBlock, 0, s>>>(pa, pb, h, w);  // dilate, iterations=2
-        morph_cross_kernel<false><<<grid_px, kBlock, 0, s>>>(pb, pd, h, w);
+        morph(pa, pb, false);  // MORPH_CLOSE
+        morph(pb, pa, true);
+        morph(pa, pb, false);  // dilate, iterations=2
+        morph(pb, pd, false);
     }
     rc = lf_gauss_blur_u8(rgb, blurred, n, h, w, 3, kq15, 15, stream);
     if (rc != LF_OK) return rc;
-    color_diff_kernel<<<grid_px, kBlock, 0, s>>>(rgb, blurred, cdiff, mm, hw);
-    saliency_kernel<<<grid_px, kBlock, 0, s>>>(pc, gmag, use_brown ? pd : nullptr, cdiff, sal, mm, hw);
-    saliency_norm_kernel<<<grid_px, kBlock, 0, s>>>(sal, mm, pa, hw);
+    color_diff_kernel<<<grid_fat, kBlock, 0, s>>>(rgb, blurred, cdiff, mm, hw);
+    saliency_kernel<<<grid_fat, kBlock, 0, s>>>(pc, gmag, use_brown ? pd : nullptr, cdiff, sal, mm, hw);
+    saliency_norm_kernel<<<grid_fat, kBlock, 0, s>>>(sal, mm, pa, hw);
     rc = lf_gauss_blur_u8(pa, pb, n, h, w, 1, kq5, 5, stream);
     if (rc != LF_OK) return rc;
     saliency_out_kernel<<<lf::stream_grid(px / 4 + 1, kBlock, lf::kFullGrid), kBlock, 0, s>>>(pb, leaf_mask, out,
