@@ -171,7 +171,7 @@ def augment_throughput(dev, n=4096, iters=5, only=None):
         "rotate": (lambda: ops.rotate_expand_apply(x, rplan, 255, rbuf), img_b + rot_out_b),
         "skew": (lambda: ops.warp_bicubic_u8(x, skew, True, True), 2 * img_b),
         "shear": (lambda: ops.warp_bicubic_u8(x, shear, False), 2 * img_b),
-        "crop": (lambda: ops.resample_u8(x, IMG, IMG, ctab[0], ctab[1], ctab[2], ctab[3], True), 2 * img_b),
+        "crop": (lambda: ops.resample_u8(x, IMG, IMG, ctab[0], ctab[1], ctab[2], ctab[3], True, ctab[4]), 2 * img_b),
         # distortion = noise add (2 passes) + histogram (1 read) + LUT apply (2): 5 image passes
         "distortion": (lambda: ops.autocontrast_u8(ops.noise_philox_add_u8(x, 42, 5.0), cut), 5 * img_b),
         "pack": (lambda: ops.pack_hwc_u8_to_nchw_f32(x), img_b + 4 * img_b),

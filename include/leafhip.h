@@ -170,11 +170,22 @@ int lf_affine_nearest_fixed_u8(const uint8_t* in, uint8_t* out, const int32_t* f
  * them (xmin/ymin index the uncropped image).
  * Horizontal pass: in [n][h][w][3] -> tmp [n][h][ow][3]; vertical: -> out [n][oh][ow][3].
  * xbounds [ow][2] = (xmin, count), xk [ow][kx]; ybounds [oh][2], yk [oh][ky] (int32);
- * with per_image_coeffs != 0 each table has a leading [n] dimension. */
+ * with per_image_coeffs != 0 each table has a leading [n] dimension.  Coefficients must
+ * satisfy |k| < 2^23 (normalised 22-bit weights always do): the kernels multiply with
+ * full-rate 24-bit operands. */
 int lf_resample_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int n, int h, int w, int oh,
                    int ow, const int32_t* xbounds, const int32_t* xk, int kx,
                    const int32_t* ybounds, const int32_t* yk, int ky, int per_image_coeffs,
                    lf_stream_t stream);
+
+/* The same resample with both passes fused in one kernel (32x32 output tiles, the tile's input
+ * window and the 8-bit intermediate kept in LDS; no tmp buffer).  Preconditions: kx, ky <= 8,
+ * ow % 4 == 0, and the windows of any 32 consecutive outputs span at most 48 inputs on either
+ * axis (crop -> resize back, scales up to ~1.25); the host checks the last one on its tables
+ * before choosing this entry (ops.crop_resize_plan).  Bit-identical to lf_resample_u8. */
+int lf_resample_tile_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int oh, int ow,
+                        const int32_t* xbounds, const int32_t* xk, int kx, const int32_t* ybounds,
+                        const int32_t* yk, int ky, int per_image_coeffs, lf_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* A2 — leaf_cnn conv stack (fp32, NCHW activations)                           */

@@ -41,6 +41,7 @@ SIGNATURES = {
                             c_size_t, P],
     "lf_warp_bicubic_u8": [P, P, P, c_int, c_int, c_int, c_int, P],
     "lf_affine_nearest_fixed_u8": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "lf_resample_tile_u8": [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int, c_int, P],
     "lf_resample_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int,
                        c_int, P],
     "lf_conv2d_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P],

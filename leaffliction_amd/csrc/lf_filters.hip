@@ -119,13 +119,13 @@ __global__ __launch_bounds__(kBlock) void sal_sobel_kernel(const uint8_t* __rest
         const int y = p / w, x = p - y * w;
         const Sob s = sobel_at(g, w, clampi(y - 1, 0, h - 1), y, clampi(y + 1, 0, h - 1),
                                clampi(x - 1, 0, w - 1), x, clampi(x + 1, 0, w - 1));
-        mag2[(size_t)n * hw + p] = s.dx * s.dx + s.dy * s.dy;
+        mag2[(size_t)n * hw + p] = __mul24(s.dx, s.dx) + __mul24(s.dy, s.dy);  // |d| <= 1020
         dxdy[(size_t)n * hw + p] = ((unsigned)s.dx & 0xffffu) | ((unsigned)s.dy << 16);
         Sob r = s;
         if (x == 0 || y == 0 || x == w - 1 || y == h - 1)
             r = sobel_at(g, w, reflect101i(y - 1, h), y, reflect101i(y + 1, h), reflect101i(x - 1, w), x,
                          reflect101i(x + 1, w));
-        const float gm = __fsqrt_rn((float)(r.dx * r.dx + r.dy * r.dy));  // the sum is < 2^24: exact
+        const float gm = __fsqrt_rn((float)(__mul24(r.dx, r.dx) + __mul24(r.dy, r.dy)));  // < 2^24: exact
         gmag[(size_t)n * hw + p] = gm;
         mmx.take(gm);
     }
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void canny_nms_kernel(const int32_t* __rest
         const int xs = (int)(short)(pk & 0xffffu), ys = (int)(short)(pk >> 16);
         const int ax = xs < 0 ? -xs : xs;
         const int ay = (ys < 0 ? -ys : ys) << 15;
-        const int tg22x = ax * 13573;  // tan(22.5 deg) in 15-bit fixed point
+        const int tg22x = __mul24(ax, 13573);  // tan(22.5 deg) in 15-bit fixed point
         bool keep;
         if (ay < tg22x) {
             keep = m > at(y, x - 1) && m >= at(y, x + 1);
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(kBlock) void brown_mask_kernel(const uint8_t* __res
         const int r = rgb[3 * p], g = rgb[3 * p + 1], b = rgb[3 * p + 2];
         const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
         const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
-        const int s = (diff * sdiv[v] + (1 << 11)) >> 12;
+        const int s = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
         int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-        hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
+        hh = (__mul24(hh, hdiv[diff]) + (1 << 11)) >> 12;
         hh += hh < 0 ? 180 : 0;
         const bool brown = hh >= hue_lo && hh <= hue_hi && s >= s_min && v <= v_max && leaf[p] > 0;
         out[p] = brown ? 255 : 0;

@@ -275,9 +275,28 @@ __global__ __launch_bounds__(kBlock) void affine_nearest_kernel(const uint8_t* _
     const int nd = (total * 3 + 3) / 4;   // dwords that hold at least one pixel byte
     const int ng = (total + 3) / 4;       // groups of four pixels
     const int last = h * w - 1;
+    // row / column of the group's first pixel: float reciprocal + one correction step while the
+    // pixel index is exact in float32 (an integer division is a run of quarter-rate multiplies)
+    const bool small = total < (1 << 22);  // quotient error <= 2^22 * 1.2e-7 < 1: at most one step off
+    const float inv_ow = 1.0f / (float)ow;
     for (int g = blockIdx.x * kBlock + threadIdx.x; g < ng; g += gridDim.x * kBlock) {
         const int p0 = 4 * g;
-        unsigned oy = (unsigned)p0 / (unsigned)ow, ox = (unsigned)p0 - oy * (unsigned)ow;
+        unsigned oy, ox;
+        if (small) {
+            oy = (unsigned)((float)p0 * inv_ow);
+            int rem = p0 - __mul24((int)oy, ow);
+            if (rem < 0) {
+                --oy;
+                rem += ow;
+            } else if (rem >= ow) {
+                ++oy;
+                rem -= ow;
+            }
+            ox = (unsigned)rem;
+        } else {
+            oy = (unsigned)p0 / (unsigned)ow;
+            ox = (unsigned)p0 - oy * (unsigned)ow;
+        }
         // unsigned arithmetic == two's-complement wrap of the C int accumulation
         unsigned xx = a2 + a1 * oy + a0 * ox, yy = a5 + a4 * oy + a3 * ox;
         unsigned px[4];
@@ -286,8 +305,8 @@ __global__ __launch_bounds__(kBlock) void affine_nearest_kernel(const uint8_t* _
             unsigned v = fill * 0x010101u;
             const int xin = (int)xx >> 16, yin = (int)yy >> 16;
             if (p0 + k < total && xin >= 0 && xin < w && yin >= 0 && yin < h) {
-                const int sp = yin * w + xin;
-                const uint8_t* s = src + (size_t)sp * 3;
+                const int sp = __mul24(yin, w) + xin;  // h, w < 32768
+                const uint8_t* s = src + (unsigned)sp * 3u;
                 if (sp < last) {  // 4-byte unaligned load stays inside the image
                     v = reinterpret_cast<const Pix4*>(s)->v & 0xffffffu;
                 } else {
@@ -318,8 +337,17 @@ constexpr int kPrec = 22;
 
 __device__ __forceinline__ uint8_t clip8(int v) {
     v >>= kPrec;
+    // Keep the shift and the clamp apart: hipcc 7.2 (clang 22) folds "two clamped shifts packed
+    // into 16 bits" into gfx950's v_ashr_pk_u8_i32 and then ORs the other bytes onto its result as
+    // if the upper half of the destination were zero — the instruction leaves it unchanged, so
+    // bytes 2 and 3 of a packed dword come out as whatever the register held before.
+    asm volatile("" : "+v"(v));
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
+
+// pixel (0..255) x coefficient (22-bit fixed point, |k| < 2^23: checked on the host) as a
+// full-rate v_mad_i32_i24; a plain int multiply is a quarter-rate v_mul_lo_u32 on CDNA.
+__device__ __forceinline__ int mac24(int acc, unsigned px, int k) { return acc + __mul24((int)px, k); }
 
 // horizontal: in [n][h][w][3] -> tmp [n][h][ow][3]; one thread per (y, ox).  The taps are
 // fetched four pixels (12 bytes, one unaligned load) at a time.
@@ -346,18 +374,18 @@ __global__ __launch_bounds__(kBlock) void resample_h_kernel(const uint8_t* __res
         for (; i + 4 <= cnt; i += 4) {
             const Row12 q = *reinterpret_cast<const Row12*>(p + 3 * i);
             const int c0 = k[i], c1 = k[i + 1], c2 = k[i + 2], c3 = k[i + 3];
-            s0 += (int)(q.a & 0xff) * c0 + (int)(q.a >> 24) * c1 + (int)((q.b >> 16) & 0xff) * c2 +
-                  (int)((q.c >> 8) & 0xff) * c3;
-            s1 += (int)((q.a >> 8) & 0xff) * c0 + (int)(q.b & 0xff) * c1 + (int)(q.b >> 24) * c2 +
-                  (int)((q.c >> 16) & 0xff) * c3;
-            s2 += (int)((q.a >> 16) & 0xff) * c0 + (int)((q.b >> 8) & 0xff) * c1 +
-                  (int)(q.c & 0xff) * c2 + (int)(q.c >> 24) * c3;
+            s0 = mac24(mac24(mac24(mac24(s0, q.a & 0xff, c0), q.a >> 24, c1), (q.b >> 16) & 0xff, c2),
+                       (q.c >> 8) & 0xff, c3);
+            s1 = mac24(mac24(mac24(mac24(s1, (q.a >> 8) & 0xff, c0), q.b & 0xff, c1), q.b >> 24, c2),
+                       (q.c >> 16) & 0xff, c3);
+            s2 = mac24(mac24(mac24(mac24(s2, (q.a >> 16) & 0xff, c0), (q.b >> 8) & 0xff, c1), q.c & 0xff, c2),
+                       q.c >> 24, c3);
         }
         for (; i < cnt; ++i) {
             const int c = k[i];
-            s0 += p[3 * i] * c;
-            s1 += p[3 * i + 1] * c;
-            s2 += p[3 * i + 2] * c;
+            s0 = mac24(s0, p[3 * i], c);
+            s1 = mac24(s1, p[3 * i + 1], c);
+            s2 = mac24(s2, p[3 * i + 2], c);
         }
         uint8_t* o = dst + (size_t)t * 3;
         o[0] = clip8(s0);
@@ -404,21 +432,21 @@ __global__ __launch_bounds__(kBlock) void resample_h_strip_kernel(const uint8_t*
                     if (g < groups) {
                         const Row12 q = *reinterpret_cast<const Row12*>(p + 12 * g);
                         const int c0 = c[4 * g], c1 = c[4 * g + 1], c2 = c[4 * g + 2], c3 = c[4 * g + 3];
-                        s0 += (int)(q.a & 0xff) * c0 + (int)(q.a >> 24) * c1 + (int)((q.b >> 16) & 0xff) * c2 +
-                              (int)((q.c >> 8) & 0xff) * c3;
-                        s1 += (int)((q.a >> 8) & 0xff) * c0 + (int)(q.b & 0xff) * c1 + (int)(q.b >> 24) * c2 +
-                              (int)((q.c >> 16) & 0xff) * c3;
-                        s2 += (int)((q.a >> 16) & 0xff) * c0 + (int)((q.b >> 8) & 0xff) * c1 +
-                              (int)(q.c & 0xff) * c2 + (int)(q.c >> 24) * c3;
+                        s0 = mac24(mac24(mac24(mac24(s0, q.a & 0xff, c0), q.a >> 24, c1), (q.b >> 16) & 0xff, c2),
+                                   (q.c >> 8) & 0xff, c3);
+                        s1 = mac24(mac24(mac24(mac24(s1, (q.a >> 8) & 0xff, c0), q.b & 0xff, c1), q.b >> 24, c2),
+                                   (q.c >> 16) & 0xff, c3);
+                        s2 = mac24(mac24(mac24(mac24(s2, (q.a >> 16) & 0xff, c0), (q.b >> 8) & 0xff, c1),
+                                         q.c & 0xff, c2), q.c >> 24, c3);
                     }
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < kHMaxTaps; ++i) {
                     if (i < cnt) {
-                        s0 += p[3 * i] * c[i];
-                        s1 += p[3 * i + 1] * c[i];
-                        s2 += p[3 * i + 2] * c[i];
+                        s0 = mac24(s0, p[3 * i], c[i]);
+                        s1 = mac24(s1, p[3 * i + 1], c[i]);
+                        s2 = mac24(s2, p[3 * i + 2], c[i]);
                     }
                 }
             }
@@ -456,19 +484,130 @@ __global__ __launch_bounds__(kBlock) void resample_v_kernel(const uint8_t* __res
             for (int i = 0; i < cnt; ++i) {
                 const unsigned v = *reinterpret_cast<const uint32_t*>(p + (size_t)i * rowb);
                 const int c = k[i];
-                a0 += (int)(v & 0xff) * c;
-                a1 += (int)((v >> 8) & 0xff) * c;
-                a2 += (int)((v >> 16) & 0xff) * c;
-                a3 += (int)(v >> 24) * c;
+                a0 = mac24(a0, v & 0xff, c);
+                a1 = mac24(a1, (v >> 8) & 0xff, c);
+                a2 = mac24(a2, (v >> 16) & 0xff, c);
+                a3 = mac24(a3, v >> 24, c);
             }
             *reinterpret_cast<uint32_t*>(dst + (size_t)oy * rowb + xv * 4) =
                 (unsigned)clip8(a0) | (unsigned)clip8(a1) << 8 | (unsigned)clip8(a2) << 16 |
                 (unsigned)clip8(a3) << 24;
         } else {
             int sacc = 1 << (kPrec - 1);
-            for (int i = 0; i < cnt; ++i) sacc += p[(size_t)i * rowb] * k[i];
+            for (int i = 0; i < cnt; ++i) sacc = mac24(sacc, p[(size_t)i * rowb], k[i]);
             dst[(size_t)oy * rowb + xv] = clip8(sacc);
         }
+    }
+}
+
+// Both passes in one kernel for resamples whose windows are short (crop -> LANCZOS back to the
+// original size, mild up/down scales): one workgroup = a 32x32 output tile.  The input window of
+// the tile (<= 48 rows x 48 pixels) is copied into LDS with aligned dword loads, the horizontal
+// pass runs LDS -> LDS (8-bit intermediate, as Pillow keeps it), the vertical pass LDS -> global.
+// Against the two-kernel form this drops the HBM round trip of the intermediate image and the
+// unaligned 12-byte global loads that kept the texture addresser 84 % busy.
+constexpr int kRT = 32, kRWin = 48, kRTaps = 8;
+constexpr int kRPitch = kRWin * 3 + 8;  // bytes per window row in LDS (a row starts up to 3 bytes in)
+
+__global__ __launch_bounds__(kBlock) void resample_tile_kernel(const uint8_t* __restrict__ in,
+                                                               uint8_t* __restrict__ out, int h, int w,
+                                                               int oh, int ow,
+                                                               const int32_t* __restrict__ xbounds,
+                                                               const int32_t* __restrict__ xkk, int kx,
+                                                               const int32_t* __restrict__ ybounds,
+                                                               const int32_t* __restrict__ ykk, int ky,
+                                                               int per_image) {
+    __shared__ uint32_t win[(kRWin * kRPitch + 32) / 4];
+    __shared__ uint32_t tmpw[kRWin * kRT * 3 / 4];
+    __shared__ int kxs[kRT][kRTaps], kys[kRT][kRTaps];
+    __shared__ int xmn[kRT], xct[kRT], ymn[kRT], yct[kRT], rsh[kRWin];
+    const unsigned n = blockIdx.z;
+    const int ox0 = blockIdx.x * kRT, oy0 = blockIdx.y * kRT;
+    const int cols = min(kRT, ow - ox0), rows = min(kRT, oh - oy0);
+    const int tid = threadIdx.x;
+    if (tid < 2 * kRT) {  // tables of this tile's columns (threads 0..31) and rows (32..63)
+        const bool isx = tid < kRT;
+        const int l = tid & (kRT - 1);
+        const int cnt_axis = isx ? cols : rows, o = (isx ? ox0 : oy0) + l;
+        const int len = isx ? w : h, ks = isx ? kx : ky, on = isx ? ow : oh;
+        const int32_t* bnd = (isx ? xbounds : ybounds) + (per_image ? (size_t)n * on * 2 : 0);
+        const int32_t* kk = (isx ? xkk : ykk) + (per_image ? (size_t)n * on * ks : 0);
+        int mn = 0, ct = 0;
+        if (l < cnt_axis) {
+            mn = clampi(bnd[2 * o], 0, len);
+            ct = max(0, min(min(bnd[2 * o + 1], ks), min(len - mn, kRTaps)));
+        }
+#pragma unroll
+        for (int i = 0; i < kRTaps; ++i) {
+            const int v = i < ct ? kk[(size_t)o * ks + i] : 0;
+            if (isx) kxs[l][i] = v; else kys[l][i] = v;
+        }
+        if (isx) { xmn[l] = mn; xct[l] = ct; } else { ymn[l] = mn; yct[l] = ct; }
+    }
+    __syncthreads();
+    // windows start at the first column / row's start (the starts grow with the output index)
+    const int xlo = xmn[0], ylo = ymn[0];
+    const int wx = min(kRWin, min(w, xmn[cols - 1] + xct[cols - 1]) - xlo);
+    const int wy = min(kRWin, min(h, ymn[rows - 1] + yct[rows - 1]) - ylo);
+    const size_t img_bytes = (size_t)h * w * 3;
+    const uint8_t* img = in + (size_t)n * img_bytes;
+    const unsigned mis = (unsigned)(reinterpret_cast<size_t>(img) & 3);
+    // resource over this image, base aligned down: dwords that stick out read as zero
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(img - mis), 0, (int)((img_bytes + mis + 3) & ~(size_t)3), 0x00020000);
+    const int nd = (3 + wx * 3 + 3) / 4;  // dwords that cover a window row whatever its alignment
+    for (int it = tid; it < wy * nd; it += kBlock) {
+        const int r = it / nd, d = it - r * nd;
+        const unsigned off = ((unsigned)(ylo + r) * (unsigned)w + (unsigned)xlo) * 3u + mis;
+        win[(r * kRPitch) / 4 + d] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (off & ~3u) + 4u * d, 0, 0);
+        if (d == 0) rsh[r] = (int)(off & 3u);
+    }
+    __syncthreads();
+    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+    uint8_t* tb = reinterpret_cast<uint8_t*>(tmpw);
+    {   // horizontal pass: thread = one output column, every 8th window row
+        const int c = tid & (kRT - 1);
+        if (c < cols) {
+            int k[kRTaps];
+#pragma unroll
+            for (int i = 0; i < kRTaps; ++i) k[i] = kxs[c][i];
+            const int rel = min(xmn[c] - xlo, kRWin - 1) * 3;
+            for (int r = tid / kRT; r < wy; r += kBlock / kRT) {
+                const uint8_t* q = wb + r * kRPitch + rsh[r] + rel;
+                int s0 = 1 << (kPrec - 1), s1 = s0, s2 = s0;
+#pragma unroll
+                for (int i = 0; i < kRTaps; ++i) {  // taps past the count have k = 0
+                    s0 = mac24(s0, q[3 * i], k[i]);
+                    s1 = mac24(s1, q[3 * i + 1], k[i]);
+                    s2 = mac24(s2, q[3 * i + 2], k[i]);
+                }
+                uint8_t* o = tb + (r * kRT + c) * 3;
+                o[0] = clip8(s0);
+                o[1] = clip8(s1);
+                o[2] = clip8(s2);
+            }
+        }
+    }
+    __syncthreads();
+    // vertical pass: thread = four consecutive bytes of one output row of the tile
+    uint8_t* dst = out + (((size_t)n * oh + oy0) * ow + ox0) * 3;
+    const int rowd = cols * 3 / 4;  // cols % 4 == 0 (ow % 4 == 0)
+    for (int it = tid; it < rows * (kRT * 3 / 4); it += kBlock) {
+        const int oyl = it / (kRT * 3 / 4), dc = it - oyl * (kRT * 3 / 4);
+        if (dc >= rowd) continue;
+        const int rely = min(ymn[oyl] - ylo, kRWin - 1);
+        int a0 = 1 << (kPrec - 1), a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+        for (int i = 0; i < kRTaps; ++i) {
+            const int kv = kys[oyl][i];
+            const unsigned v = tmpw[min(rely + i, kRWin - 1) * (kRT * 3 / 4) + dc];
+            a0 = mac24(a0, v & 0xff, kv);
+            a1 = mac24(a1, (v >> 8) & 0xff, kv);
+            a2 = mac24(a2, (v >> 16) & 0xff, kv);
+            a3 = mac24(a3, v >> 24, kv);
+        }
+        *reinterpret_cast<uint32_t*>(dst + (size_t)oyl * ow * 3 + 4 * dc) =
+            (unsigned)clip8(a0) | (unsigned)clip8(a1) << 8 | (unsigned)clip8(a2) << 16 | (unsigned)clip8(a3) << 24;
     }
 }
 
@@ -507,6 +646,25 @@ int lf_affine_nearest_fixed_u8(const uint8_t* in, uint8_t* out, const int32_t* f
     affine_nearest_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, fix6, ohw, out_off, h,
                                                                       w, (unsigned)fill);
     return lf::check_launch("lf_affine_nearest_fixed");
+}
+
+int lf_resample_tile_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int oh, int ow,
+                        const int32_t* xbounds, const int32_t* xk, int kx, const int32_t* ybounds,
+                        const int32_t* yk, int ky, int per_image_coeffs, lf_stream_t stream) {
+    LF_REQUIRE(in && out && xbounds && xk && ybounds && yk, "lf_resample_tile: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "lf_resample_tile: bad dims n=%d h=%d w=%d oh=%d ow=%d",
+               n, h, w, oh, ow);
+    LF_REQUIRE(kx > 0 && kx <= kRTaps && ky > 0 && ky <= kRTaps, "lf_resample_tile: kx=%d ky=%d (1..%d)", kx,
+               ky, kRTaps);
+    LF_REQUIRE(ow % 4 == 0 && (reinterpret_cast<size_t>(out) & 3) == 0,
+               "lf_resample_tile: ow must be a multiple of 4 and out 4-byte aligned");
+    LF_REQUIRE((size_t)h * w * 3 + 3 < ((size_t)1 << 31), "lf_resample_tile: image too large");
+    LF_REQUIRE(n <= 65535, "lf_resample_tile: batch too large for grid.z");
+    LF_REQUIRE(in != out, "lf_resample_tile: in-place resample is not supported");
+    dim3 grid((ow + kRT - 1) / kRT, (oh + kRT - 1) / kRT, n);
+    resample_tile_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, h, w, oh, ow, xbounds, xk, kx,
+                                                                    ybounds, yk, ky, per_image_coeffs);
+    return lf::check_launch("lf_resample_tile");
 }
 
 int lf_resample_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int n, int h, int w, int oh,

@@ -308,9 +308,28 @@ def rotate_expand_u8(x: torch.Tensor, angles: Sequence[float], fill: int = 255):
     return [out[o:o + oh * ow * 3].view(oh, ow, 3) for o, (oh, ow) in zip(plan["offsets"], plan["sizes"])]
 
 
+TILE_OUT, TILE_WINDOW, TILE_TAPS = 32, 48, 8   # lf_resample_tile_u8's tile, window and tap limits
+
+
+def resample_tables_fit_tile(xb: np.ndarray, xk: np.ndarray, yb: np.ndarray, yk: np.ndarray, ow: int) -> bool:
+    """Host check of lf_resample_tile_u8's preconditions on the (numpy) tables: at most 8 taps,
+    ow % 4 == 0, and every run of 32 outputs reads at most 48 inputs on both axes."""
+    if xk.shape[-1] > TILE_TAPS or yk.shape[-1] > TILE_TAPS or ow % 4:
+        return False
+    for b in (xb, yb):
+        b = b.reshape(-1, b.shape[-2], 2).astype(np.int64)
+        for o0 in range(0, b.shape[1], TILE_OUT):
+            o1 = min(o0 + TILE_OUT, b.shape[1])
+            span = (b[:, o0:o1, 0] + b[:, o0:o1, 1]).max(axis=1) - b[:, o0, 0]
+            if int(span.max()) > TILE_WINDOW or (np.diff(b[:, o0:o1, 0], axis=1) < 0).any():
+                return False
+    return True
+
+
 def resample_u8(x: torch.Tensor, oh: int, ow: int, xb: torch.Tensor, xk: torch.Tensor,
-                yb: torch.Tensor, yk: torch.Tensor, per_image: bool) -> torch.Tensor:
-    """Pillow two-pass fixed-point resample with host-computed tables (int32 tensors)."""
+                yb: torch.Tensor, yk: torch.Tensor, per_image: bool, tile_ok: bool = False) -> torch.Tensor:
+    """Pillow two-pass fixed-point resample with host-computed tables (int32 tensors).
+    tile_ok: the caller checked `resample_tables_fit_tile` -> one fused kernel, no intermediate."""
     n, h, w = _hwc(x, "resample.x")
     for t, nm in ((xb, "xb"), (xk, "xk"), (yb, "yb"), (yk, "yk")):
         _chk(t, _I32, f"resample.{nm}")
@@ -319,8 +338,12 @@ def resample_u8(x: torch.Tensor, oh: int, ow: int, xb: torch.Tensor, xk: torch.T
     if (tuple(xb.shape) != lead + (ow, 2) or tuple(xk.shape) != lead + (ow, kx)
             or tuple(yb.shape) != lead + (oh, 2) or tuple(yk.shape) != lead + (oh, ky)):
         raise ValueError("resample: table shapes do not match (n, oh, ow)")
-    tmp = torch.empty((n, h, ow, 3), dtype=_U8, device=x.device)
     out = torch.empty((n, oh, ow, 3), dtype=_U8, device=x.device)
+    if tile_ok and kx <= TILE_TAPS and ky <= TILE_TAPS and ow % 4 == 0 and n <= 65535:
+        _lib.call("lf_resample_tile_u8", x.data_ptr(), out.data_ptr(), n, h, w, oh, ow, xb.data_ptr(),
+                  xk.data_ptr(), kx, yb.data_ptr(), yk.data_ptr(), ky, 1 if per_image else 0, _stream())
+        return out
+    tmp = torch.empty((n, h, ow, 3), dtype=_U8, device=x.device)
     _lib.call("lf_resample_u8", x.data_ptr(), tmp.data_ptr(), out.data_ptr(), n, h, w, oh, ow,
               xb.data_ptr(), xk.data_ptr(), kx, yb.data_ptr(), yk.data_ptr(), ky,
               1 if per_image else 0, _stream())
@@ -341,8 +364,9 @@ def resize_lanczos_u8(x: torch.Tensor, size: int) -> torch.Tensor:
     if h == size:
         yb = np.stack([np.arange(size), np.ones(size)], 1).astype(np.int32)
         yk = np.full((size, 1), 1 << _geo.PRECISION_BITS, dtype=np.int32)
+    tile_ok = resample_tables_fit_tile(xb, xk, yb, yk, size)
     t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (xb, xk, yb, yk)]
-    return resample_u8(x, size, size, t[0], t[1], t[2], t[3], per_image=False)
+    return resample_u8(x, size, size, t[0], t[1], t[2], t[3], per_image=False, tile_ok=tile_ok)
 
 
 def crop_resize_plan(w: int, h: int, boxes: Sequence[Sequence[int]], device):
@@ -352,7 +376,8 @@ def crop_resize_plan(w: int, h: int, boxes: Sequence[Sequence[int]], device):
     ky = max(t[5] for t in tabs)
     arrs = (np.stack([t[0] for t in tabs]), np.stack([_geo.pad_k(t[1], kx) for t in tabs]),
             np.stack([t[3] for t in tabs]), np.stack([_geo.pad_k(t[4], ky) for t in tabs]))
-    return [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in arrs]
+    tile_ok = resample_tables_fit_tile(arrs[0], arrs[1], arrs[2], arrs[3], w)
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in arrs] + [tile_ok]
 
 
 def crop_resize_lanczos_u8(x: torch.Tensor, boxes: Sequence[Sequence[int]]) -> torch.Tensor:
@@ -361,4 +386,4 @@ def crop_resize_lanczos_u8(x: torch.Tensor, boxes: Sequence[Sequence[int]]) -> t
     if len(boxes) != n:
         raise ValueError("crop_resize: one box per image")
     t = crop_resize_plan(w, h, boxes, x.device)
-    return resample_u8(x, h, w, t[0], t[1], t[2], t[3], per_image=True)
+    return resample_u8(x, h, w, t[0], t[1], t[2], t[3], per_image=True, tile_ok=t[4])

@@ -90,6 +90,9 @@ def lanczos_coeffs(in_size: int, in0: float, in1: float, out_size: int):
             kk[xx, x] = int(-0.5 + v * one) if v < 0 else int(0.5 + v * one)
         bounds[xx, 0] = xmin
         bounds[xx, 1] = xmax
+    # lf_resample_u8 multiplies with 24-bit operands (normalised weights stay far inside)
+    if int(np.abs(kk).max()) >= 1 << 23:
+        raise ValueError("lanczos_coeffs: coefficient outside the 24-bit range of lf_resample_u8")
     return bounds, kk, ksize
 
 

@@ -29,5 +29,5 @@ for _ in range(2):
     ops.warp_bicubic_u8(x, skew, True, True)
     ops.warp_bicubic_u8(x, shear, False)
     ops.rotate_expand_apply(x, rplan, 255, rbuf)
-    ops.resample_u8(x, S, S, ctab[0], ctab[1], ctab[2], ctab[3], True)
+    ops.resample_u8(x, S, S, ctab[0], ctab[1], ctab[2], ctab[3], True, ctab[4])
 torch.cuda.synchronize()

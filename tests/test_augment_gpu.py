@@ -241,6 +241,46 @@ def test_geometric_batch_vs_oracle(cuda):
     assert (ops.hist_u8(xd).sum(-1) == 224 * 224).all()
 
 
+@pytest.mark.parametrize("h,w", [(224, 224), (256, 256), (150, 260), (64, 48), (40, 36), (33, 20)])
+def test_fused_resample_matches_two_pass_and_oracle(cuda, h, w):
+    """lf_resample_tile_u8 (both LANCZOS passes in one kernel) == lf_resample_u8 == Pillow's
+    crop().resize(): full tiles, partial tiles (sizes that are not multiples of 32), windows at
+    every image border, per-image and shared tables, a mild down-scale."""
+    from leaffliction_amd import ops
+    from leaffliction_amd.preprocessing import geometry as G
+    n = 5
+    x = batch_inputs(n, h, w, 31)
+    xd = dev(x, cuda)
+    rng = np.random.RandomState(h * 1000 + w)
+    boxes = []
+    for i in range(n):
+        r = rng.uniform(0.8, 0.95)
+        nw, nh = max(1, int(w * r)), max(1, int(h * r))
+        left, top = [(0, 0), (w - nw, h - nh), (0, h - nh), (w - nw, 0)][i % 4] if i < 4 else \
+            (rng.randint(0, w - nw + 1), rng.randint(0, h - nh + 1))
+        boxes.append((left, top, nw, nh))
+    t = ops.crop_resize_plan(w, h, boxes, xd.device)
+    assert t[4] is True
+    fused = ops.resample_u8(xd, h, w, t[0], t[1], t[2], t[3], True, tile_ok=True).cpu().numpy()
+    two = ops.resample_u8(xd, h, w, t[0], t[1], t[2], t[3], True, tile_ok=False).cpu().numpy()
+    assert np.array_equal(fused, two)
+    for i in range(n):
+        assert np.array_equal(fused[i], P.crop_resize_lanczos(x[i], *boxes[i])), i
+    # shared tables: a mild down-scale that still fits the tile limits (8 taps need scale <= 7/6)
+    oh, ow = (h * 9 // 10) // 4 * 4, (w * 9 // 10) // 4 * 4
+    xb, xk, kx = G.lanczos_coeffs(w, 0.0, float(w), ow)
+    yb, yk, ky = G.lanczos_coeffs(h, 0.0, float(h), oh)
+    if ops.resample_tables_fit_tile(xb, xk, yb, yk, ow):
+        tt = [dev(a, cuda) for a in (xb, xk, yb, yk)]
+        a = ops.resample_u8(xd, oh, ow, tt[0], tt[1], tt[2], tt[3], False, tile_ok=True).cpu().numpy()
+        b = ops.resample_u8(xd, oh, ow, tt[0], tt[1], tt[2], tt[3], False, tile_ok=False).cpu().numpy()
+        assert np.array_equal(a, b)
+    # tables the tile kernel must refuse: 9 taps (256 -> 224), width not a multiple of 4
+    xb9, xk9, _ = G.lanczos_coeffs(256, 0.0, 256.0, 224)
+    assert not ops.resample_tables_fit_tile(xb9, xk9, xb9, xk9, 224)
+    assert not ops.resample_tables_fit_tile(xb, xk, yb, yk, ow + 1)
+
+
 def test_image_augmenter_file_interface(cuda, tmp_path):
     """ImageAugmenter(seed).<op>(src, dst) -> bool; failures return False, never raise."""
     from PIL import Image
