@@ -179,7 +179,7 @@ int lf_resample_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int n, int h, 
                    lf_stream_t stream);
 
 /* The same resample with both passes fused in one kernel (32x32 output tiles, the tile's input
- * window and the 8-bit intermediate kept in LDS; no tmp buffer).  Preconditions: kx, ky <= 8,
+ * window and the 8-bit intermediate kept in LDS; no tmp buffer).  Preconditions: kx, ky <= 10,
  * ow % 4 == 0, and the windows of any 32 consecutive outputs span at most 48 inputs on either
  * axis (crop -> resize back, scales up to ~1.25); the host checks the last one on its tables
  * before choosing this entry (ops.crop_resize_plan).  Bit-identical to lf_resample_u8. */

@@ -506,9 +506,10 @@ __global__ __launch_bounds__(kBlock) void resample_v_kernel(const uint8_t* __res
 // pass runs LDS -> LDS (8-bit intermediate, as Pillow keeps it), the vertical pass LDS -> global.
 // Against the two-kernel form this drops the HBM round trip of the intermediate image and the
 // unaligned 12-byte global loads that kept the texture addresser 84 % busy.
-constexpr int kRT = 32, kRWin = 48, kRTaps = 8;
+constexpr int kRT = 32, kRWin = 48, kRTapsMax = 10;  // kRTaps: 8 (crop, up-scales) or 10 (256 -> 224)
 constexpr int kRPitch = kRWin * 3 + 8;  // bytes per window row in LDS (a row starts up to 3 bytes in)
 
+template <int kRTaps>
 __global__ __launch_bounds__(kBlock) void resample_tile_kernel(const uint8_t* __restrict__ in,
                                                                uint8_t* __restrict__ out, int h, int w,
                                                                int oh, int ow,
@@ -517,8 +518,8 @@ __global__ __launch_bounds__(kBlock) void resample_tile_kernel(const uint8_t* __
                                                                const int32_t* __restrict__ ybounds,
                                                                const int32_t* __restrict__ ykk, int ky,
                                                                int per_image) {
-    __shared__ uint32_t win[(kRWin * kRPitch + 32) / 4];
-    __shared__ uint32_t tmpw[kRWin * kRT * 3 / 4];
+    __shared__ uint32_t win[(kRWin * kRPitch + 40) / 4];
+    __shared__ uint32_t tmpw[(kRWin + kRTaps) * kRT * 3 / 4];  // + rows that only zero taps reach
     __shared__ int kxs[kRT][kRTaps], kys[kRT][kRTaps];
     __shared__ int xmn[kRT], xct[kRT], ymn[kRT], yct[kRT], rsh[kRWin];
     const unsigned n = blockIdx.z;
@@ -555,11 +556,16 @@ __global__ __launch_bounds__(kBlock) void resample_tile_kernel(const uint8_t* __
     // resource over this image, base aligned down: dwords that stick out read as zero
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(img - mis), 0, (int)((img_bytes + mis + 3) & ~(size_t)3), 0x00020000);
-    const int nd = (3 + wx * 3 + 3) / 4;  // dwords that cover a window row whatever its alignment
-    for (int it = tid; it < wy * nd; it += kBlock) {
-        const int r = it / nd, d = it - r * nd;
+    // a window row (<= 3 + 144 + 3 bytes from its aligned start) as 19 eight-byte pieces:
+    // three rows per wave
+    constexpr int kPieces = kRPitch / 8;
+    for (int it = tid; it < wy * kPieces; it += kBlock) {
+        const int r = it / kPieces, d = it - r * kPieces;
         const unsigned off = ((unsigned)(ylo + r) * (unsigned)w + (unsigned)xlo) * 3u + mis;
-        win[(r * kRPitch) / 4 + d] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (off & ~3u) + 4u * d, 0, 0);
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (off & ~3u) + 8u * d, 0, 0));
+        win[(r * kRPitch) / 4 + 2 * d] = v.x;
+        win[(r * kRPitch) / 4 + 2 * d + 1] = v.y;
         if (d == 0) rsh[r] = (int)(off & 3u);
     }
     __syncthreads();
@@ -595,12 +601,13 @@ __global__ __launch_bounds__(kBlock) void resample_tile_kernel(const uint8_t* __
     for (int it = tid; it < rows * (kRT * 3 / 4); it += kBlock) {
         const int oyl = it / (kRT * 3 / 4), dc = it - oyl * (kRT * 3 / 4);
         if (dc >= rowd) continue;
-        const int rely = min(ymn[oyl] - ylo, kRWin - 1);
+        const int rely = min(ymn[oyl] - ylo, kRWin);  // rows past the window meet zero taps only
+        const uint32_t* col = tmpw + __mul24(rely, kRT * 3 / 4) + dc;
         int a0 = 1 << (kPrec - 1), a1 = a0, a2 = a0, a3 = a0;
 #pragma unroll
         for (int i = 0; i < kRTaps; ++i) {
             const int kv = kys[oyl][i];
-            const unsigned v = tmpw[min(rely + i, kRWin - 1) * (kRT * 3 / 4) + dc];
+            const unsigned v = col[i * (kRT * 3 / 4)];
             a0 = mac24(a0, v & 0xff, kv);
             a1 = mac24(a1, (v >> 8) & 0xff, kv);
             a2 = mac24(a2, (v >> 16) & 0xff, kv);
@@ -654,16 +661,20 @@ int lf_resample_tile_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, in
     LF_REQUIRE(in && out && xbounds && xk && ybounds && yk, "lf_resample_tile: null buffer");
     LF_REQUIRE(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "lf_resample_tile: bad dims n=%d h=%d w=%d oh=%d ow=%d",
                n, h, w, oh, ow);
-    LF_REQUIRE(kx > 0 && kx <= kRTaps && ky > 0 && ky <= kRTaps, "lf_resample_tile: kx=%d ky=%d (1..%d)", kx,
-               ky, kRTaps);
+    LF_REQUIRE(kx > 0 && kx <= kRTapsMax && ky > 0 && ky <= kRTapsMax, "lf_resample_tile: kx=%d ky=%d (1..%d)",
+               kx, ky, kRTapsMax);
     LF_REQUIRE(ow % 4 == 0 && (reinterpret_cast<size_t>(out) & 3) == 0,
                "lf_resample_tile: ow must be a multiple of 4 and out 4-byte aligned");
     LF_REQUIRE((size_t)h * w * 3 + 3 < ((size_t)1 << 31), "lf_resample_tile: image too large");
     LF_REQUIRE(n <= 65535, "lf_resample_tile: batch too large for grid.z");
     LF_REQUIRE(in != out, "lf_resample_tile: in-place resample is not supported");
     dim3 grid((ow + kRT - 1) / kRT, (oh + kRT - 1) / kRT, n);
-    resample_tile_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, h, w, oh, ow, xbounds, xk, kx,
-                                                                    ybounds, yk, ky, per_image_coeffs);
+    if (kx <= 8 && ky <= 8)
+        resample_tile_kernel<8><<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, h, w, oh, ow, xbounds, xk,
+                                                                           kx, ybounds, yk, ky, per_image_coeffs);
+    else
+        resample_tile_kernel<10><<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, h, w, oh, ow, xbounds, xk,
+                                                                            kx, ybounds, yk, ky, per_image_coeffs);
     return lf::check_launch("lf_resample_tile");
 }
 

@@ -308,11 +308,11 @@ def rotate_expand_u8(x: torch.Tensor, angles: Sequence[float], fill: int = 255):
     return [out[o:o + oh * ow * 3].view(oh, ow, 3) for o, (oh, ow) in zip(plan["offsets"], plan["sizes"])]
 
 
-TILE_OUT, TILE_WINDOW, TILE_TAPS = 32, 48, 8   # lf_resample_tile_u8's tile, window and tap limits
+TILE_OUT, TILE_WINDOW, TILE_TAPS = 32, 48, 10   # lf_resample_tile_u8's tile, window and tap limits
 
 
 def resample_tables_fit_tile(xb: np.ndarray, xk: np.ndarray, yb: np.ndarray, yk: np.ndarray, ow: int) -> bool:
-    """Host check of lf_resample_tile_u8's preconditions on the (numpy) tables: at most 8 taps,
+    """Host check of lf_resample_tile_u8's preconditions on the (numpy) tables: at most 10 taps,
     ow % 4 == 0, and every run of 32 outputs reads at most 48 inputs on both axes."""
     if xk.shape[-1] > TILE_TAPS or yk.shape[-1] > TILE_TAPS or ow % 4:
         return False

@@ -275,10 +275,27 @@ def test_fused_resample_matches_two_pass_and_oracle(cuda, h, w):
         a = ops.resample_u8(xd, oh, ow, tt[0], tt[1], tt[2], tt[3], False, tile_ok=True).cpu().numpy()
         b = ops.resample_u8(xd, oh, ow, tt[0], tt[1], tt[2], tt[3], False, tile_ok=False).cpu().numpy()
         assert np.array_equal(a, b)
-    # tables the tile kernel must refuse: 9 taps (256 -> 224), width not a multiple of 4
-    xb9, xk9, _ = G.lanczos_coeffs(256, 0.0, 256.0, 224)
-    assert not ops.resample_tables_fit_tile(xb9, xk9, xb9, xk9, 224)
+    # tables the tile kernel must refuse: 13 taps (a 2x down-scale), width not a multiple of 4
+    xb13, xk13, k13 = G.lanczos_coeffs(256, 0.0, 256.0, 128)
+    assert k13 == 13 and not ops.resample_tables_fit_tile(xb13, xk13, xb13, xk13, 128)
     assert not ops.resample_tables_fit_tile(xb, xk, yb, yk, ow + 1)
+
+
+def test_loader_resize_takes_the_fused_kernel(cuda):
+    """ImageTransforms.resize_image 256 -> 224 (9 taps, the dataset's native size): the fused
+    10-tap tile kernel equals the two-pass kernels and Pillow."""
+    from leaffliction_amd import ops
+    from leaffliction_amd.preprocessing import geometry as G
+    x = batch_inputs(3, 256, 256, 41)
+    xd = dev(x, cuda)
+    xb, xk, kx = G.lanczos_coeffs(256, 0.0, 256.0, 224)
+    assert kx == 9 and ops.resample_tables_fit_tile(xb, xk, xb, xk, 224)
+    t = [dev(a, cuda) for a in (xb, xk)]
+    two = ops.resample_u8(xd, 224, 224, t[0], t[1], t[0], t[1], False, tile_ok=False).cpu().numpy()
+    got = ops.resize_lanczos_u8(xd, 224).cpu().numpy()
+    assert np.array_equal(got, two)
+    for i in range(3):
+        assert np.array_equal(got[i], P.resize_lanczos(x[i], 224, 224))
 
 
 def test_image_augmenter_file_interface(cuda, tmp_path):
