@@ -158,8 +158,12 @@ def main(argv=None) -> None:
     np.random.seed(args.seed)
     import torch
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dp = DataParallel(device=torch.device("cuda", local_rank))
+    # LEAFFLICTION_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs
+    # than ranks (ranks share the cards); production runs are one GPU per rank over RCCL
+    backend = os.environ.get("LEAFFLICTION_DIST_BACKEND")
+    dev_index = local_rank if backend in (None, "nccl") else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dp = DataParallel(backend=backend, device=torch.device("cuda", dev_index))
     try:
         manifest_path = validate_manifest(args)
         train_items, val_items, label2idx = prepare_data(manifest_path)
