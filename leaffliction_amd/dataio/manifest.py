@@ -1,36 +1,34 @@
-"""Manifest contract (mirror of srcs/dataio/manifest.py:10-42).
+"""The manifest artifact (`manifest_*.json`) as the loaders see it.
 
-`manifest_*.json` = {"meta": {...}, "items": [{id, plant, class, label, split, src}]};
-label indices are the rank of each label among the sorted unique TRAIN labels — that
-mapping is part of the artifact contract (labels.json) and must be bit-exact.
+Schema (srcs/dataio/manifest.py:10-42): `{"meta": {...}, "items": [...]}` with
+one record per image: `id`, `plant`, `class`, `label` (= "<plant>__<class>"), `split`
+("train" / "val") and `src` (path of the JPEG).  Label indices are ranks among the sorted unique
+labels of the TRAIN items; that mapping is written to labels.json and read back by predict, so it
+has to come out identical to the reference's.
 """
 from __future__ import annotations
 
 import json
-from dataclasses import dataclass
 from pathlib import Path
-from typing import Dict, Iterable, List
+from typing import Dict, Iterable, List, NamedTuple
 
 
-@dataclass(frozen=True)
-class ManifestItem:
+class ManifestItem(NamedTuple):
     id: str
     plant: str
-    cls: str
+    cls: str      # the record's "class" key (a Python keyword)
     label: str
     split: str
     src: Path
 
+    @classmethod
+    def from_record(cls, rec: dict) -> "ManifestItem":
+        return cls(rec["id"], rec["plant"], rec["class"], rec["label"], rec["split"], Path(rec["src"]))
+
 
 def load_manifest(path: Path) -> List[ManifestItem]:
-    with Path(path).open("r", encoding="utf-8") as f:
-        doc = json.load(f)
-    out: List[ManifestItem] = []
-    for entry in doc["items"]:
-        out.append(ManifestItem(id=entry["id"], plant=entry["plant"], cls=entry["class"],
-                                label=entry["label"], split=entry["split"],
-                                src=Path(entry["src"])))
-    return out
+    records = json.loads(Path(path).read_text(encoding="utf-8"))["items"]
+    return [ManifestItem.from_record(r) for r in records]
 
 
 def select_items(items: Iterable[ManifestItem], split: str) -> List[ManifestItem]:
@@ -38,4 +36,5 @@ def select_items(items: Iterable[ManifestItem], split: str) -> List[ManifestItem
 
 
 def build_label_mapping(train_items: List[ManifestItem]) -> Dict[str, int]:
-    return {label: idx for idx, label in enumerate(sorted({it.label for it in train_items}))}
+    ordered = sorted(set(it.label for it in train_items))
+    return dict(zip(ordered, range(len(ordered))))

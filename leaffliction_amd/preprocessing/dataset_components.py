@@ -1,22 +1,37 @@
-"""Distribution analysis, augmentation plan and augmented-manifest writer.
+"""Counting, planning and manifest writing around the augmentation loop.
 
-Mirror of srcs/preprocessing/dataset_components.py:12-187.  Semantics kept, including
-the quirks SURVEY Appendix B lists: directory order is `iterdir()` order (unsorted),
-deficits are keyed by class name only, every manifest item is split="train" and
-"augmentation_seed" is the literal 42.
+Contract of srcs/preprocessing/dataset_components.py:12-187, quirks included:
+class folders are visited in `iterdir()` order (unsorted, so the plan's dict order follows the file
+system); deficits and plans are keyed by class name alone; every item of the augmented manifest is
+`split: "train"`, and its meta carries the literal `"augmentation_seed": 42`.
 """
 from __future__ import annotations
 
 import json
 from datetime import datetime, timezone
 from pathlib import Path
-from typing import Dict
+from typing import Dict, Iterator, Tuple
 
 from ..utils.common import get_logger
 
 logger = get_logger(__name__)
 
 TRANSFORMATIONS = ["flip", "rotate", "skew", "shear", "crop", "distortion"]
+Counts = Dict[str, Dict[str, int]]
+
+
+def _class_dirs(root: Path) -> Iterator[Tuple[Path, Path]]:
+    """(plant_dir, class_dir) pairs under root/PLANT/CLASS in directory order."""
+    for plant_dir in root.iterdir():
+        if plant_dir.is_dir():
+            for class_dir in plant_dir.iterdir():
+                if class_dir.is_dir():
+                    yield plant_dir, class_dir
+
+
+def _bump(counts: Counts, plant: str, cls: str, n: int) -> None:
+    row = counts.setdefault(plant, {})
+    row[cls] = row.get(cls, 0) + n
 
 
 class DistributionAnalyzer:
@@ -24,53 +39,43 @@ class DistributionAnalyzer:
 
     def __init__(self, input_path):
         self.input_path = Path(input_path)
-        self.counts: Dict[str, Dict[str, int]] = {}
+        self.counts: Counts = {}
         self.original_manifest = None
 
-    def _count_dir(self, root: Path) -> Dict[str, Dict[str, int]]:
+    def _is_image(self, f: Path) -> bool:
+        return f.is_file() and f.suffix.lower() in self.IMG_EXTS
+
+    def _count_dir(self, root: Path) -> Counts:
         if not root.exists():
             raise FileNotFoundError(f"Dataset directory not found: {root}")
-        counts: Dict[str, Dict[str, int]] = {}
-        for plant_dir in root.iterdir():
-            if not plant_dir.is_dir():
-                continue
-            for class_dir in plant_dir.iterdir():
-                if not class_dir.is_dir():
-                    continue
-                n = sum(1 for f in class_dir.iterdir()
-                        if f.is_file() and f.suffix.lower() in self.IMG_EXTS)
-                if n > 0:
-                    per_plant = counts.setdefault(plant_dir.name, {})
-                    per_plant[class_dir.name] = per_plant.get(class_dir.name, 0) + n
+        counts: Counts = {}
+        for plant_dir, class_dir in _class_dirs(root):
+            n = sum(map(self._is_image, class_dir.iterdir()))
+            if n:
+                _bump(counts, plant_dir.name, class_dir.name, n)
         return counts
 
-    def _count_manifest(self, path: Path) -> Dict[str, Dict[str, int]]:
-        with path.open("r", encoding="utf-8") as f:
-            manifest = json.load(f)
-        self.original_manifest = manifest
-        counts: Dict[str, Dict[str, int]] = {}
-        for item in manifest.get("items", []):
-            plant, cls = item.get("plant"), item.get("class")
-            if plant and cls:
-                per_plant = counts.setdefault(plant, {})
-                per_plant[cls] = per_plant.get(cls, 0) + 1
+    def _count_manifest(self, path: Path) -> Counts:
+        self.original_manifest = json.loads(path.read_text(encoding="utf-8"))
+        counts: Counts = {}
+        for rec in self.original_manifest.get("items", []):
+            if rec.get("plant") and rec.get("class"):
+                _bump(counts, rec["plant"], rec["class"], 1)
         return counts
 
     def analyze(self):
-        if not self.input_path.exists():
-            raise FileNotFoundError(f"Input not found: {self.input_path}")
-        if self.input_path.is_dir():
-            self.counts = self._count_dir(self.input_path)
-        else:
-            self.counts = self._count_manifest(self.input_path)
+        src = self.input_path
+        if not src.exists():
+            raise FileNotFoundError(f"Input not found: {src}")
+        self.counts = self._count_dir(src) if src.is_dir() else self._count_manifest(src)
         return self.counts
 
     def display_distribution(self):
         logger.info("Analyzing dataset distribution...")
-        for plant, classes in sorted(self.counts.items()):
+        for plant in sorted(self.counts):
             logger.info(f"\n[{plant}]")
-            for class_name, count in sorted(classes.items()):
-                logger.info(f"  {class_name}: {count} images")
+            for class_name in sorted(self.counts[plant]):
+                logger.info(f"  {class_name}: {self.counts[plant][class_name]} images")
 
 
 class AugmentationPlanner:
@@ -79,29 +84,25 @@ class AugmentationPlanner:
         self.plan = {}
 
     def calculate_plan(self):
-        """deficit = plant max - count; split over the six transforms, remainder to the first."""
-        deficits: Dict[str, int] = {}
-        for _plant, classes in self.counts.items():
-            plant_max = max(classes.values())
-            for class_name, count in classes.items():
-                if plant_max - count > 0:
-                    deficits[class_name] = plant_max - count
-        if not deficits:
+        """Per class: deficit to the largest class of its plant, dealt over the six transforms in
+        TRANSFORMATIONS order (`deficit // 6` each, the first `deficit % 6` get one more; zero
+        shares are left out).  Classes that need nothing do not appear."""
+        need: Dict[str, int] = {}
+        for classes in self.counts.values():
+            top = max(classes.values())
+            need.update({name: top - n for name, n in classes.items() if n < top})
+        if not need:
             logger.info("Dataset already balanced - no augmentations needed")
             return {}
-        plan: Dict[str, Dict[str, int]] = {}
-        for class_name, deficit in deficits.items():
-            base, rem = divmod(deficit, len(TRANSFORMATIONS))
-            per = {}
-            for i, name in enumerate(TRANSFORMATIONS):
-                cnt = base + (1 if i < rem else 0)
-                if cnt > 0:
-                    per[name] = cnt
-            plan[class_name] = per
-        self.plan = plan
-        for class_name, deficit in sorted(deficits.items()):
-            logger.info(f"  Class: {class_name} - {deficit} images needed")
-        return plan
+        k = len(TRANSFORMATIONS)
+        self.plan = {
+            name: {t: deficit // k + (i < deficit % k) for i, t in enumerate(TRANSFORMATIONS)
+                   if deficit // k + (i < deficit % k) > 0}
+            for name, deficit in need.items()
+        }
+        for name in sorted(need):
+            logger.info(f"  Class: {name} - {need[name]} images needed")
+        return self.plan
 
 
 class ManifestGenerator:
@@ -111,47 +112,30 @@ class ManifestGenerator:
         self.target_dir = Path(target_dir)
         self.workers = workers
 
+    def _records(self) -> Iterator[dict]:
+        for plant_dir, class_dir in _class_dirs(self.target_dir):
+            plant, cls = plant_dir.name, class_dir.name
+            for img in class_dir.iterdir():
+                if img.is_file():
+                    yield {"plant": plant, "class": cls, "label": f"{plant}__{cls}", "split": "train",
+                           "src": str(img), "id": str(img.relative_to(self.target_dir)),
+                           "augmented": "_aug_" in img.stem}
+
     def generate_augmented_manifest(self):
-        items = []
-        for plant_dir in self.target_dir.iterdir():
-            if not plant_dir.is_dir():
-                continue
-            for class_dir in plant_dir.iterdir():
-                if not class_dir.is_dir():
-                    continue
-                for img in class_dir.iterdir():
-                    if not img.is_file():
-                        continue
-                    items.append({
-                        "plant": plant_dir.name,
-                        "class": class_dir.name,
-                        "label": f"{plant_dir.name}__{class_dir.name}",
-                        "split": "train",
-                        "src": str(img),
-                        "id": str(img.relative_to(self.target_dir)),
-                        "augmented": "_aug_" in img.stem,
-                    })
-        created_at = original_seed = None
-        if isinstance(self.original_manifest, dict):
-            meta = self.original_manifest.get("meta", {})
-            created_at, original_seed = meta.get("created_at"), meta.get("seed")
-        n_aug = sum(1 for i in items if i["augmented"])
-        return {
-            "meta": {
-                "created_at": created_at,
+        items = list(self._records())
+        n_aug = sum(rec["augmented"] for rec in items)
+        upstream = self.original_manifest.get("meta", {}) if isinstance(self.original_manifest, dict) else {}
+        meta = {"created_at": upstream.get("created_at"),
                 "augmented_at": datetime.now(timezone.utc).isoformat(),
-                "original_seed": original_seed,
+                "original_seed": upstream.get("seed"),
                 "augmentation_seed": 42,
                 "workers": self.workers,
                 "src_root": str(self.target_dir),
                 "total_images": len(items),
                 "original_images": len(items) - n_aug,
-                "augmented_images": n_aug,
-            },
-            "items": items,
-        }
+                "augmented_images": n_aug}
+        return {"meta": meta, "items": items}
 
     def save_manifest(self, manifest, output_path):
-        with open(output_path, "w", encoding="utf-8") as f:
-            json.dump(manifest, f, indent=2, ensure_ascii=False)
+        Path(output_path).write_text(json.dumps(manifest, indent=2, ensure_ascii=False), encoding="utf-8")
         logger.info(f"Augmented manifest saved: {output_path}")
