@@ -135,6 +135,57 @@ def cpu_baseline(seconds_budget: float = 25.0):
                       f"(oracle/cnn_ref.py on torch CPU, {threads} threads)"}
 
 
+def cpu_augment_baseline(images: int = 24):
+    """The same six operations done by the libraries the reference calls (Pillow + numpy, the
+    calls of image_augmenter.py:20-133 on in-memory 224x224 images, no JPEG codec), one host core:
+    the CPU figure beside the augmentation-pass table.  A reported baseline, not a target."""
+    import numpy as np
+    from PIL import Image, ImageOps
+    rng = np.random.RandomState(7)
+    imgs = [Image.fromarray(rng.randint(0, 256, (IMG, IMG, 3)).astype(np.uint8)) for _ in range(images)]
+    W = H = IMG
+
+    def op_flip(im):
+        return im.transpose(Image.FLIP_LEFT_RIGHT if rng.rand() < 0.5 else Image.FLIP_TOP_BOTTOM)
+
+    def op_rotate(im):
+        return im.rotate(rng.uniform(-30, 30), expand=True, fillcolor="white")
+
+    def op_skew(im):
+        f = rng.uniform(0.05, 0.15)
+        return im.transform((W, H), Image.PERSPECTIVE, [1 + f, 0, -f * W, 0, 1 + f, -f * H, 0, 0], Image.BICUBIC)
+
+    def op_shear(im):
+        v = rng.uniform(-0.2, 0.2)
+        return im.transform((W, H), Image.AFFINE, [1, v, 0, 0, 1, 0] if rng.rand() < 0.5 else [1, 0, 0, v, 1, 0],
+                            Image.BICUBIC)
+
+    def op_crop(im):
+        r = rng.uniform(0.8, 0.95)
+        nw, nh = int(W * r), int(H * r)
+        left, top = rng.randint(0, W - nw + 1), rng.randint(0, H - nh + 1)
+        return im.crop((left, top, left + nw, top + nh)).resize((W, H), Image.LANCZOS)
+
+    def op_distortion(im):
+        a = np.array(im)
+        noisy = a + rng.normal(0, 5, a.shape).astype(np.uint8)
+        return ImageOps.autocontrast(Image.fromarray(noisy), cutoff=rng.uniform(0, 2))
+
+    per_op, inv = {}, 0.0
+    for name, fn in (("flip", op_flip), ("rotate", op_rotate), ("skew", op_skew), ("shear", op_shear),
+                     ("crop", op_crop), ("distortion", op_distortion)):
+        fn(imgs[0])
+        t0 = time.perf_counter()
+        for im in imgs:
+            fn(im)
+        sec = (time.perf_counter() - t0) / images
+        per_op[name] = round(1.0 / sec, 1)
+        inv += sec / 6.0
+    return {"mix_images_per_sec": round(1.0 / inv, 1), "per_op_images_per_sec": per_op, "cores": 1,
+            "kind": "the reference's libraries (Pillow/numpy calls of image_augmenter.py), in memory",
+            "sample": f"{images} synthetic 224x224 images per operation"}
+
+
 def augment_throughput(dev, n=4096, iters=5, only=None):
     """Second half of the headline metric: the augmentation pass on synthetic 224x224x3 images
     resident in HBM (BASELINE configs[2]; op mix 1/6 each like the balancer's plan).  Host-side
@@ -368,6 +419,8 @@ def main() -> None:
             del model
             torch.cuda.empty_cache()
             out["augment"] = augment_throughput(dev)
+            if not args.no_cpu_baseline:
+                out["augment"]["cpu_baseline"] = cpu_augment_baseline()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
