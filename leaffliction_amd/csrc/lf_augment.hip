@@ -469,8 +469,7 @@ __device__ __forceinline__ void rgb2hsv_px(int r, int g, int b, const int* sdiv,
     const int diff = v - vmin;
     const int vr = v == r ? -1 : 0;
     const int vg = v == g ? -1 : 0;
-    // operands fit 24 bits (diff <= 255, sdiv < 2^20, |h| <= 1275, hdiv < 2^17): full-rate
-    // v_mad_i32_i24 instead of the quarter-rate 32-bit multiply
+    // operands fit 24 bits (diff <= 255, sdiv < 2^20, |h| <= 1275, hdiv < 2^17): v_mad_i32_i24
     s = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
     h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
     h = (__mul24(h, hdiv[diff]) + (1 << 11)) >> 12;

@@ -346,7 +346,7 @@ __device__ __forceinline__ uint8_t clip8(int v) {
 }
 
 // pixel (0..255) x coefficient (22-bit fixed point, |k| < 2^23: checked on the host) as a
-// full-rate v_mad_i32_i24; a plain int multiply is a quarter-rate v_mul_lo_u32 on CDNA.
+// v_mad_i32_i24 / SDWA v_mul_i32_i24 (the byte extraction folds into the operand select).
 __device__ __forceinline__ int mac24(int acc, unsigned px, int k) { return acc + __mul24((int)px, k); }
 
 // horizontal: in [n][h][w][3] -> tmp [n][h][ow][3]; one thread per (y, ox).  The taps are
