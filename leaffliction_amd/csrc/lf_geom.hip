@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void affine_nearest_kernel(const uint8_t* _
     const int ng = (total + 3) / 4;       // groups of four pixels
     const int last = h * w - 1;
     // row / column of the group's first pixel: float reciprocal + one correction step while the
-    // pixel index is exact in float32 (an integer division is a run of quarter-rate multiplies)
+    // pixel index is exact in float32 (an integer division is a long multiply-and-correct sequence)
     const bool small = total < (1 << 22);  // quotient error <= 2^22 * 1.2e-7 < 1: at most one step off
     const float inv_ow = 1.0f / (float)ow;
     for (int g = blockIdx.x * kBlock + threadIdx.x; g < ng; g += gridDim.x * kBlock) {
