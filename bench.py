@@ -271,9 +271,23 @@ def inference_throughput(model, dev, batch=1024, iters=5):
         labels = model.predict_device(x).argmax(-1)
     torch.cuda.synchronize()
     sec = (time.perf_counter() - t0) / iters
-    return {"images_per_sec": round(batch / sec, 1), "batch": batch, "dtype": "f32",
-            "tflops": round(TRAIN_GFLOP_PER_IMG / 3.0 * batch / sec / 1e3, 2),
-            "labels_checksum": int(labels.sum().item())}
+    out = {"images_per_sec": round(batch / sec, 1), "batch": batch, "dtype": "f32",
+           "tflops": round(TRAIN_GFLOP_PER_IMG / 3.0 * batch / sec / 1e3, 2),
+           "labels_checksum": int(labels.sum().item())}
+    # the reduced-precision mode of BASELINE configs[4]: bf16 conv operands, fp32 accumulation
+    model.set_inference_dtype("bf16")
+    model.predict_device(x[:64])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        labels16 = model.predict_device(x).argmax(-1)
+    torch.cuda.synchronize()
+    sec16 = (time.perf_counter() - t0) / iters
+    model.set_inference_dtype("f32")
+    out["bf16"] = {"images_per_sec": round(batch / sec16, 1),
+                   "tflops": round(TRAIN_GFLOP_PER_IMG / 3.0 * batch / sec16 / 1e3, 2),
+                   "labels_equal_to_f32": float((labels16 == labels).float().mean().item())}
+    return out
 
 
 def main() -> None:

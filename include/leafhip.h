@@ -206,6 +206,22 @@ int lf_conv2d_f32(const float* x, const float* w, float* y, int n, int cin, int 
                   int ksize, const float* in_scale, const float* in_shift, int in_relu,
                   int accumulate, lf_stream_t stream);
 
+/* The same forward convolution with both operands rounded to bf16 (round to nearest even) while
+ * staging and fp32 accumulation on v_mfma_f32_32x32x16_bf16 — the reduced-precision inference mode
+ * (the reference predicts under Keras' mixed_float16 policy by default, train.py:53-117;
+ * BASELINE configs[4]).  x and y stay fp32 NCHW, so every other kernel of the forward pass is
+ * shared with the fp32 path.  Weights are packed once per model with
+ * lf_conv2d_bf16_prep_weights: fp32 IKO [cin][k*k][cout] -> bf16 [ceil(cin/16)][k*k][cout][16]
+ * (lf_conv2d_bf16_weight_elems uint16 elements, channels past cin zero).  Requires w % 4 == 0,
+ * cout % 32 == 0, ksize 1 or 3.  Tolerance vs lf_conv2d_f32: bf16 operand rounding, 2^-8
+ * relative per product (tests bound the error by 2e-2 of the output's scale). */
+size_t lf_conv2d_bf16_weight_elems(int cin, int cout, int ksize);
+int lf_conv2d_bf16_prep_weights(const float* w_iko, uint16_t* wprep, int cin, int cout, int ksize,
+                                lf_stream_t stream);
+int lf_conv2d_bf16_f32(const float* x, const uint16_t* wprep, float* y, int n, int cin, int h, int wd,
+                       int cout, int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                       lf_stream_t stream);
+
 /* Which tile variant (template instantiation) the dispatcher picks for a shape — used by
  * bench.py to attribute measured launch durations to kernel names.  (For H = 28 the 28x8
  * variant walks two images as one strip; lf_conv2d_stats_tiles accounts for that.) */

@@ -45,6 +45,9 @@ SIGNATURES = {
     "lf_resample_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int,
                        c_int, P],
     "lf_conv2d_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P],
+    "lf_conv2d_bf16_weight_elems": [c_int, c_int, c_int],
+    "lf_conv2d_bf16_prep_weights": [P, P, c_int, c_int, c_int, P],
+    "lf_conv2d_bf16_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P],
     "lf_conv2d_variant": [c_int, c_int, c_int, c_int],
     "lf_conv2d_wgrad_variant": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_stats_tiles": [c_int, c_int, c_int, c_int, c_int, c_int],
@@ -90,7 +93,7 @@ SIGNATURES = {
 _RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t,
              "lf_bn_workspace": c_size_t, "lf_se_bwd_workspace": c_size_t,
              "lf_adamw_workspace": c_size_t, "lf_conv2d_stats_tiles": C.c_longlong,
-             "lf_blur_saliency_workspace": c_size_t}
+             "lf_blur_saliency_workspace": c_size_t, "lf_conv2d_bf16_weight_elems": c_size_t}
 
 
 class LeafHipError(RuntimeError):

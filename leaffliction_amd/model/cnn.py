@@ -14,6 +14,7 @@ are stored "IKO" [Cin, k*k, Cout]; `get_weights()` converts to keras HWIO.
 from __future__ import annotations
 
 import json
+import os
 import math
 import zipfile
 from pathlib import Path
@@ -107,6 +108,9 @@ class LeafCNN:
         self.l2_reg = float(l2_reg or 0.0)
         self.augment = bool(augment)
         self.use_se = bool(use_se)
+        self.infer_dtype = os.environ.get("LEAFFLICTION_INFER_DTYPE", "f32")  # see set_inference_dtype
+        if self.infer_dtype not in ("f32", "bf16"):
+            raise ValueError("LEAFFLICTION_INFER_DTYPE must be f32 or bf16")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.norm = Normalization() if use_norm else None
         self.stop_training = False
@@ -321,8 +325,23 @@ class LeafCNN:
                                self.s[bn + ".mean"], self.s[bn + ".var"], st, pro[0], pro[1], pro[2],
                                out=out, momentum=BN_MOMENTUM, eps=BN_EPS)
             return out, st
-        y = nn.conv2d(x, P[wname], ksize, pro[0], pro[1], pro[2], out=out)
+        w = P[wname]
+        if self.infer_dtype == "bf16" and x.shape[3] % 4 == 0 and w.shape[2] % 32 == 0:
+            # reduced-precision inference: bf16 operands, fp32 accumulation (packed weights are
+            # rebuilt per call: 1.25 M parameters, microseconds)
+            y = nn.conv2d_bf16(x, nn.conv2d_bf16_weights(w, ksize), w.shape[2], ksize, pro[0], pro[1],
+                               pro[2], out=out)
+        else:
+            y = nn.conv2d(x, w, ksize, pro[0], pro[1], pro[2], out=out)
         return y, self._bn(bn, y, False)
+
+    def set_inference_dtype(self, dtype: str) -> None:
+        """"f32" (default) or "bf16": the arithmetic of the convolutions in predict / evaluate.
+        The reference runs them in half precision under its default mixed_float16 policy
+        (train.py:53-117); training here is fp32 either way."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"inference dtype must be 'f32' or 'bf16', got {dtype!r}")
+        self.infer_dtype = dtype
 
     def forward(self, x0: torch.Tensor, training: bool, y_true: Optional[torch.Tensor] = None,
                 drops: Optional[List[torch.Tensor]] = None,

@@ -61,6 +61,43 @@ def conv2d(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, in_scale=None, in_s
     return out
 
 
+def conv2d_bf16_weights(w_iko: torch.Tensor, ksize: int) -> torch.Tensor:
+    """Pack fp32 IKO weights [Cin, k*k, Cout] for conv2d_bf16 (uint16 view of bf16
+    [ceil(Cin/16), k*k, Cout, 16])."""
+    _chk(w_iko, _F32, "conv2d_bf16_weights.w", 3)
+    cin, taps, cout = w_iko.shape
+    if taps != ksize * ksize:
+        raise ValueError(f"conv2d_bf16_weights.w: expected [{cin},{ksize * ksize},Cout]")
+    n = int(_lib.load().lf_conv2d_bf16_weight_elems(cin, cout, ksize))
+    out = torch.empty(n, dtype=torch.int16, device=w_iko.device)
+    _lib.call("lf_conv2d_bf16_prep_weights", w_iko.data_ptr(), out.data_ptr(), cin, cout, ksize, _stream())
+    return out
+
+
+def conv2d_bf16(x: torch.Tensor, wprep: torch.Tensor, cout: int, ksize: int, in_scale=None, in_shift=None,
+                in_relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv2d with bf16 operands / fp32 accumulation (inference): x, y fp32 NCHW, wprep from
+    conv2d_bf16_weights."""
+    _chk(x, _F32, "conv2d_bf16.x", 4)
+    n, cin, h, w = x.shape
+    if wprep.dtype != torch.int16 or wprep.numel() != ((cin + 15) // 16) * ksize * ksize * cout * 16:
+        raise ValueError("conv2d_bf16.wprep: not the packed weights of this convolution")
+    for t, nm in ((in_scale, "in_scale"), (in_shift, "in_shift")):
+        if t is not None:
+            _chk(t, _F32, f"conv2d_bf16.{nm}", 1)
+            if t.shape[0] != cin:
+                raise ValueError(f"conv2d_bf16.{nm}: expected [{cin}]")
+    if out is None:
+        out = torch.empty((n, cout, h, w), dtype=_F32, device=x.device)
+    else:
+        _chk(out, _F32, "conv2d_bf16.out", 4)
+        if tuple(out.shape) != (n, cout, h, w):
+            raise ValueError("conv2d_bf16.out: shape mismatch")
+    _lib.call("lf_conv2d_bf16_f32", x.data_ptr(), wprep.data_ptr(), out.data_ptr(), n, cin, h, w, cout, ksize,
+              _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, _stream())
+    return out
+
+
 def conv2d_bn_stats(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, gamma, beta, mmean, mvar,
                     stats: torch.Tensor, in_scale=None, in_shift=None, in_relu: bool = False,
                     out: Optional[torch.Tensor] = None, momentum: float = 0.99,

@@ -101,6 +101,32 @@ def test_inference_and_label_indices(cuda):
     assert np.abs(probs_f - probs).max() < 1e-6
 
 
+@pytest.mark.parametrize("img", [64, 224])
+def test_bf16_inference_matches_fp32(cuda, img):
+    """Reduced-precision inference (bf16 conv operands, fp32 accumulation, everything else fp32;
+    BASELINE configs[4]): probabilities within 3e-2 of the fp32 path, identical label indices
+    wherever the fp32 top-2 margin exceeds that tolerance, same confusion counts on them."""
+    widths, classes, n = [32, 64, 128, 256], 8, 12
+    m, _ref_p, _ref_s = make_model(cuda, widths, classes, img, use_norm=False)
+    for bn, _c in m.bn_layers:
+        m.s[bn + ".mean"].normal_(0, 0.1)
+        m.s[bn + ".var"].uniform_(0.5, 1.5)
+    g = torch.Generator().manual_seed(5)
+    x_u8 = torch.randint(0, 256, (n, img, img, 3), dtype=torch.uint8, generator=g).numpy()
+    p32 = m.predict(x_u8)
+    m.set_inference_dtype("bf16")
+    p16 = m.predict(x_u8)
+    m.set_inference_dtype("f32")
+    assert np.array_equal(m.predict(x_u8), p32)           # switching back restores the fp32 bits
+    assert not np.array_equal(p16, p32)                    # the bf16 kernels did run
+    assert np.abs(p16 - p32).max() < 3e-2 and np.abs(p16.sum(-1) - 1.0).max() < 1e-5
+    top2 = np.sort(p32, -1)[:, -2:]
+    sure = (top2[:, 1] - top2[:, 0]) > 6e-2
+    assert np.array_equal(p16.argmax(-1)[sure], p32.argmax(-1)[sure])
+    with pytest.raises(ValueError):
+        m.set_inference_dtype("fp8")
+
+
 def test_adamw_clipnorm_ema_matches_oracle(cuda):
     """Three optimizer steps on synthetic gradients: per-tensor clip, decoupled decay, L2, EMA."""
     from leaffliction_amd import nn

@@ -233,3 +233,55 @@ def test_conv_bn_backward_sums_epilogue(cuda, n, cin, cout, h, w, k, acc):
     assert (res[0][1] - res[1][1]).abs().max().item() <= 2e-5 * scale
     assert (res[0][2] - res[1][2]).abs().max().item() <= 2e-5 * scale
     close(res[1][0], res[0][0], tol=2e-5)
+
+
+BF16_SHAPES = [  # n, cin, cout, h, w, k
+    (2, 3, 32, 64, 64, 3),      # stem: 3 channels padded to one 16-channel chunk
+    (2, 32, 32, 224, 224, 3),   # stage-1 geometry
+    (2, 32, 64, 112, 112, 3),   # two output-channel blocks per workgroup; 3.5 tiles wide
+    (2, 64, 128, 56, 56, 3),
+    (3, 128, 256, 28, 28, 3),   # masked 28-wide tiles
+    (2, 32, 64, 112, 112, 1),   # 1x1 projection
+    (2, 128, 256, 28, 28, 1),
+    (1, 16, 32, 12, 20, 3),     # partial tiles in both directions
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k", BF16_SHAPES)
+@pytest.mark.parametrize("prologue", [False, True])
+def test_conv2d_bf16_forward(cuda, n, cin, cout, h, w, k, prologue):
+    """bf16-operand / fp32-accumulate convolution (reduced-precision inference) against (a) the
+    exact reference of its own arithmetic — torch conv2d in float64 on operands rounded to bf16 —
+    to fp32 summation accuracy, and (b) the fp32 kernel within bf16 operand rounding."""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cin, k * k, cout), generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    sc = sh = None
+    if prologue:
+        sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    xd, wd = x.to(cuda), wt.to(cuda)
+    scd, shd = (sc.to(cuda), sh.to(cuda)) if prologue else (None, None)
+    wp = nn.conv2d_bf16_weights(wd, k)
+    got = nn.conv2d_bf16(xd, wp, cout, k, scd, shd, prologue).cpu()
+    xe = x
+    if prologue:   # the kernel's own prologue: fmaf then ReLU, in fp32
+        xe = torch.relu(torch.addcmul(sh[None, :, None, None], x, sc[None, :, None, None]))
+    xb = xe.to(torch.bfloat16).to(torch.float64)
+    wb = iko_to_oihw(wt, k).to(torch.bfloat16).to(torch.float64)
+    exact = F.conv2d(xb, wb, padding=k // 2).to(torch.float32)
+    close(got, exact, tol=2e-5)
+    fp32 = nn.conv2d(xd, wd, k, scd, shd, prologue).cpu()
+    close(got, fp32, tol=2e-2)
+
+
+def test_conv2d_bf16_rejects_unsupported_shapes(cuda):
+    from leaffliction_amd import nn
+    from leaffliction_amd._lib import LeafHipError
+    wd = torch.zeros((8, 9, 32), device=cuda)
+    wp = nn.conv2d_bf16_weights(wd, 3)
+    with pytest.raises(LeafHipError):
+        nn.conv2d_bf16(torch.zeros((1, 8, 6, 6), device=cuda), wp, 32, 3)        # width % 4 != 0
+    wd2 = torch.zeros((8, 9, 16), device=cuda)
+    with pytest.raises(LeafHipError):
+        nn.conv2d_bf16(torch.zeros((1, 8, 8, 8), device=cuda), nn.conv2d_bf16_weights(wd2, 3), 16, 3)  # cout % 32
