@@ -207,6 +207,7 @@ int lf_conv2d_bf16_f32(const float* x, const uint16_t* wprep, float* y, int n, i
                "lf_conv2d_bf16: x and wprep must be 16-byte aligned");
     Bf16ConvArgs a{x, wprep, y, n, cin, h, w, cout, (cin + 15) / 16, in_scale, in_shift, in_relu};
     const int tiles = ((w + kTW - 1) / kTW) * ((h + kTH - 1) / kTH);
+    // two 32-channel blocks per workgroup share one staged patch; four measured the same
     const int nco = cout % 64 == 0 ? 2 : 1;
     dim3 grid(tiles, cout / (32 * nco), n);
     hipStream_t s = lf::as_stream(stream);
