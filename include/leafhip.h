@@ -222,6 +222,22 @@ int lf_conv2d_bf16_f32(const float* x, const uint16_t* wprep, float* y, int n, i
                        int cout, int ksize, const float* in_scale, const float* in_shift, int in_relu,
                        lf_stream_t stream);
 
+/* The reduced-precision forward pass with bf16 ACTIVATION STORAGE as well (what mixed_float16
+ * keeps between layers): the same convolution reading and / or writing bf16 NCHW tensors
+ * (x_bf16 / y_bf16 flags; the fused prologue and the accumulation stay fp32), and the two plane
+ * kernels of the block on bf16 tensors — lf_gap_f32's mean of relu?(x*scale+shift) (no mask
+ * sums) and lf_block_tail_fwd_f32's maxpool2x2(relu(shortcut' + relu(BN(y)) * gate)) without the
+ * route bytes and dropout a backward pass would need.  hw % 4 == 0 / w % 4 == 0, h even. */
+int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y, int y_bf16, int n,
+                       int cin, int h, int wd, int cout, int ksize, const float* in_scale,
+                       const float* in_shift, int in_relu, lf_stream_t stream);
+int lf_gap_bf16(const uint16_t* x, float* out, int n, int c, int hw, const float* scale,
+                const float* shift, int relu, lf_stream_t stream);
+int lf_block_tail_fwd_bf16(const uint16_t* y, const float* a_scale, const float* a_shift,
+                           const float* s, const uint16_t* sc, const float* sc_scale,
+                           const float* sc_shift, int sc_relu, uint16_t* pooled, int n, int c, int h,
+                           int w, lf_stream_t stream);
+
 /* Which tile variant (template instantiation) the dispatcher picks for a shape — used by
  * bench.py to attribute measured launch durations to kernel names.  (For H = 28 the 28x8
  * variant walks two images as one strip; lf_conv2d_stats_tiles accounts for that.) */

@@ -28,9 +28,9 @@ constexpr int kTW = 32, kTH = 8;  // output tile
 constexpr int kPW = 40;           // patch row pitch in dwords: columns x0-4 .. x0+35
 
 struct Bf16ConvArgs {
-    const float* x;
+    const void* x;   // fp32 or bf16 NCHW (template XBF)
     const uint16_t* wprep;
-    float* y;
+    void* y;         // fp32 or bf16 NCHW (template YBF)
     int n, cin, h, w, cout, chunks;
     const float* in_scale;
     const float* in_shift;
@@ -45,7 +45,11 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int TAPS, int NCO>
+__device__ __forceinline__ float bf16_up(unsigned bits16) { return __uint_as_float(bits16 << 16); }
+
+__device__ __forceinline__ uint16_t bf16_down(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+
+template <int TAPS, int NCO, bool XBF, bool YBF>
 __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     constexpr int R = TAPS == 9 ? 1 : 0, PH = kTH + 2 * R, KS = TAPS == 9 ? 3 : 1;
     __shared__ uint32_t patch[8][PH][kPW];
@@ -57,7 +61,22 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     const int n = blockIdx.z;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, px = lane & 31, half = lane >> 5;
     const size_t hw = (size_t)p.h * p.w;
-    const float* xn = p.x + (size_t)n * p.cin * hw;
+    const float* xn = static_cast<const float*>(p.x) + (XBF ? 0 : (size_t)n * p.cin * hw);
+    const uint16_t* xb = static_cast<const uint16_t*>(p.x) + (XBF ? (size_t)n * p.cin * hw : 0);
+    auto load4 = [&](int ci, size_t off) -> f32x4v {  // four pixels of one channel as fp32
+        f32x4v v;
+        if (XBF) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 raw = *reinterpret_cast<const u32x2*>(xb + (size_t)ci * hw + off);
+            v[0] = bf16_up(raw.x & 0xffffu);
+            v[1] = bf16_up(raw.x >> 16);
+            v[2] = bf16_up(raw.y & 0xffffu);
+            v[3] = bf16_up(raw.y >> 16);
+        } else {
+            v = *reinterpret_cast<const f32x4v*>(xn + (size_t)ci * hw + off);
+        }
+        return v;
+    };
 
     f32x16 acc[2][NCO];
 #pragma unroll
@@ -80,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
             if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
                 const size_t off = (size_t)gy * p.w + gx;
                 if (ci0 < p.cin) {
-                    a = *reinterpret_cast<const f32x4v*>(xn + (size_t)ci0 * hw + off);
+                    a = load4(ci0, off);
                     if (p.in_scale) {
                         const float s = p.in_scale[ci0], t = p.in_shift[ci0];
 #pragma unroll
@@ -91,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
                         for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.0f);
                 }
                 if (ci0 + 1 < p.cin) {
-                    b = *reinterpret_cast<const f32x4v*>(xn + (size_t)(ci0 + 1) * hw + off);
+                    b = load4(ci0 + 1, off);
                     if (p.in_scale) {
                         const float s = p.in_scale[ci0 + 1], t = p.in_shift[ci0 + 1];
 #pragma unroll
@@ -141,7 +160,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
         }
     }
     // D[row = output channel][col = pixel]: register r of a lane is channel 8*(r/4) + 4*half + r%4
-    float* yn = p.y + (size_t)n * p.cout * hw;
+    float* yn = static_cast<float*>(p.y) + (YBF ? 0 : (size_t)n * p.cout * hw);
+    uint16_t* yb = static_cast<uint16_t*>(p.y) + (YBF ? (size_t)n * p.cout * hw : 0);
     const int gx = x0 + px;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -152,8 +172,90 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + cb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                yn[(size_t)co * hw + (size_t)gy * p.w + gx] = acc[nb][cb][r];
+                const size_t o = (size_t)co * hw + (size_t)gy * p.w + gx;
+                if (YBF)
+                    yb[o] = bf16_down(acc[nb][cb][r]);
+                else
+                    yn[o] = acc[nb][cb][r];
             }
+    }
+}
+
+// --- the plane kernels of the forward pass on bf16 activations (inference only) ---------------
+// Same arithmetic as gap_kernel / tail_fwd_kernel of lf_nn.hip (fp32 after widening the operands);
+// what differs is the storage type, and that nothing is kept for a backward pass.
+
+// out[n][c] = mean over the plane of relu?(x * scale[c] + shift[c]); one workgroup per plane.
+__global__ __launch_bounds__(kThreads) void gap_bf16_kernel(const uint16_t* __restrict__ x,
+                                                            float* __restrict__ out, int hw, int c,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu) {
+    __shared__ float red[kThreads / 64];
+    const size_t base = (size_t)blockIdx.x * hw;
+    const bool pro = scale != nullptr;
+    const float sc = pro ? scale[blockIdx.x % c] : 1.f, sh = pro ? shift[blockIdx.x % c] : 0.f;
+    auto one = [&](unsigned bits) {
+        float v = bf16_up(bits);
+        if (pro) v = fmaf(v, sc, sh);
+        return relu ? fmaxf(v, 0.f) : v;
+    };
+    float acc = 0.f;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2* x4 = reinterpret_cast<const u32x2*>(x + base);  // hw % 4 == 0
+    for (int i = threadIdx.x; i < hw / 4; i += kThreads) {
+        const u32x2 v = x4[i];
+        acc += (one(v.x & 0xffffu) + one(v.x >> 16)) + (one(v.y & 0xffffu) + one(v.y >> 16));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)hw;
+}
+
+struct TailBf16Args {
+    const uint16_t* y;       // second conv of the block (raw, before its BatchNorm)
+    const float* a_scale;    // its folded BatchNorm
+    const float* a_shift;
+    const float* s;          // SE gate [n][c] or null
+    const uint16_t* sc;      // shortcut tensor
+    const float* sc_scale;   // its scale / shift (+ReLU) or null when it is final already
+    const float* sc_shift;
+    int sc_relu;
+    int c, h, w;
+};
+
+// pooled = maxpool2x2(relu(shortcut + relu(BN(y)) * gate)), bf16 in, bf16 out; w % 4 == 0.
+__global__ __launch_bounds__(kThreads) void tail_fwd_bf16_kernel(TailBf16Args t, uint16_t* __restrict__ p) {
+    const int plane = blockIdx.x, ch = plane % t.c;
+    const float sv = t.s ? t.s[plane] : 1.f;
+    const float as = t.a_scale[ch], ab = t.a_shift[ch];
+    const float ks = t.sc_scale ? t.sc_scale[ch] : 1.f, kb = t.sc_scale ? t.sc_shift[ch] : 0.f;
+    const int h = t.h, w = t.w, ph = h / 2, pw = w / 2, pw2 = pw / 2;
+    const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
+    auto r = [&](unsigned yb, unsigned sb) {
+        const float a = fmaxf(fmaf(bf16_up(yb), as, ab), 0.f);
+        float shv = bf16_up(sb);
+        if (t.sc_scale) {
+            shv = fmaf(shv, ks, kb);
+            if (t.sc_relu) shv = fmaxf(shv, 0.f);
+        }
+        return fmaxf(shv + a * sv, 0.f);
+    };
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    for (int q = blockIdx.y * kThreads + threadIdx.x; q < ph * pw2; q += gridDim.y * kThreads) {
+        const int py = q / pw2, px2 = q - py * pw2;
+        float m0 = 0.f, m1 = 0.f;  // the block's output is >= 0: starting the max at 0 is exact
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const size_t o = base + (size_t)(2 * py + dy) * w + 4 * px2;
+            const u32x2 yv = *reinterpret_cast<const u32x2*>(t.y + o);
+            const u32x2 sv4 = *reinterpret_cast<const u32x2*>(t.sc + o);
+            m0 = fmaxf(m0, fmaxf(r(yv.x & 0xffffu, sv4.x & 0xffffu), r(yv.x >> 16, sv4.x >> 16)));
+            m1 = fmaxf(m1, fmaxf(r(yv.y & 0xffffu, sv4.y & 0xffffu), r(yv.y >> 16, sv4.y >> 16)));
+        }
+        *reinterpret_cast<unsigned*>(p + pbase + (size_t)py * pw + 2 * px2) =
+            (unsigned)bf16_down(m0) | (unsigned)bf16_down(m1) << 16;
     }
 }
 
@@ -170,6 +272,29 @@ __global__ void prep_weights_bf16_kernel(const float* __restrict__ w, uint16_t* 
         const int ci = c * 16 + j;
         const float v = ci < cin ? w[((size_t)ci * taps + tap) * cout + co] : 0.0f;
         out[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+    }
+}
+
+}  // namespace
+
+namespace {
+
+template <bool XBF, bool YBF>
+void launch_conv_bf16(const Bf16ConvArgs& a, int ksize, hipStream_t s) {
+    const int tiles = ((a.w + kTW - 1) / kTW) * ((a.h + kTH - 1) / kTH);
+    // two 32-channel blocks per workgroup share one staged patch; four measured the same
+    const int nco = a.cout % 64 == 0 ? 2 : 1;
+    dim3 grid(tiles, a.cout / (32 * nco), a.n);
+    if (ksize == 3) {
+        if (nco == 2)
+            conv_bf16_kernel<9, 2, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+        else
+            conv_bf16_kernel<9, 1, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+    } else {
+        if (nco == 2)
+            conv_bf16_kernel<1, 2, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+        else
+            conv_bf16_kernel<1, 1, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
     }
 }
 
@@ -193,9 +318,9 @@ int lf_conv2d_bf16_prep_weights(const float* w_iko, uint16_t* wprep, int cin, in
     return lf::check_launch("lf_conv2d_bf16_prep_weights");
 }
 
-int lf_conv2d_bf16_f32(const float* x, const uint16_t* wprep, float* y, int n, int cin, int h, int w,
-                       int cout, int ksize, const float* in_scale, const float* in_shift, int in_relu,
-                       lf_stream_t stream) {
+int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y, int y_bf16, int n, int cin,
+                       int h, int w, int cout, int ksize, const float* in_scale, const float* in_shift,
+                       int in_relu, lf_stream_t stream) {
     LF_REQUIRE(x && wprep && y, "lf_conv2d_bf16: null buffer");
     LF_REQUIRE(n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0, "lf_conv2d_bf16: bad dims");
     LF_REQUIRE(ksize == 1 || ksize == 3, "lf_conv2d_bf16: ksize must be 1 or 3");
@@ -206,23 +331,47 @@ int lf_conv2d_bf16_f32(const float* x, const uint16_t* wprep, float* y, int n, i
     LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wprep)) & 15) == 0,
                "lf_conv2d_bf16: x and wprep must be 16-byte aligned");
     Bf16ConvArgs a{x, wprep, y, n, cin, h, w, cout, (cin + 15) / 16, in_scale, in_shift, in_relu};
-    const int tiles = ((w + kTW - 1) / kTW) * ((h + kTH - 1) / kTH);
-    // two 32-channel blocks per workgroup share one staged patch; four measured the same
-    const int nco = cout % 64 == 0 ? 2 : 1;
-    dim3 grid(tiles, cout / (32 * nco), n);
     hipStream_t s = lf::as_stream(stream);
-    if (ksize == 3) {
-        if (nco == 2)
-            conv_bf16_kernel<9, 2><<<grid, kThreads, 0, s>>>(a);
-        else
-            conv_bf16_kernel<9, 1><<<grid, kThreads, 0, s>>>(a);
+    if (x_bf16) {
+        if (y_bf16) launch_conv_bf16<true, true>(a, ksize, s); else launch_conv_bf16<true, false>(a, ksize, s);
     } else {
-        if (nco == 2)
-            conv_bf16_kernel<1, 2><<<grid, kThreads, 0, s>>>(a);
-        else
-            conv_bf16_kernel<1, 1><<<grid, kThreads, 0, s>>>(a);
+        if (y_bf16) launch_conv_bf16<false, true>(a, ksize, s); else launch_conv_bf16<false, false>(a, ksize, s);
     }
     return lf::check_launch("lf_conv2d_bf16");
+}
+
+int lf_gap_bf16(const uint16_t* x, float* out, int n, int c, int hw, const float* scale, const float* shift,
+                int relu, lf_stream_t stream) {
+    LF_REQUIRE(x && out, "lf_gap_bf16: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && hw > 0 && hw % 4 == 0, "lf_gap_bf16: bad dims n=%d c=%d hw=%d (hw %% 4 == 0)", n, c,
+               hw);
+    LF_REQUIRE((scale == nullptr) == (shift == nullptr), "lf_gap_bf16: scale/shift must both be set");
+    LF_REQUIRE((reinterpret_cast<size_t>(x) & 7) == 0, "lf_gap_bf16: x must be 8-byte aligned");
+    gap_bf16_kernel<<<n * c, kThreads, 0, lf::as_stream(stream)>>>(x, out, hw, c, scale, shift, relu);
+    return lf::check_launch("lf_gap_bf16");
+}
+
+int lf_block_tail_fwd_bf16(const uint16_t* y, const float* a_scale, const float* a_shift, const float* s,
+                           const uint16_t* sc, const float* sc_scale, const float* sc_shift, int sc_relu,
+                           uint16_t* pooled, int n, int c, int h, int w, lf_stream_t stream) {
+    LF_REQUIRE(y && a_scale && a_shift && sc && pooled, "lf_block_tail_fwd_bf16: null buffer");
+    LF_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 4 == 0,
+               "lf_block_tail_fwd_bf16: bad dims n=%d c=%d h=%d w=%d (h even, w %% 4 == 0)", n, c, h, w);
+    LF_REQUIRE((sc_scale == nullptr) == (sc_shift == nullptr), "lf_block_tail_fwd_bf16: scale/shift must both be set");
+    LF_REQUIRE(((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(sc)) & 7) == 0 &&
+                   (reinterpret_cast<size_t>(pooled) & 3) == 0,
+               "lf_block_tail_fwd_bf16: buffers must be 8-byte (inputs) / 4-byte (output) aligned");
+    TailBf16Args t{y, a_scale, a_shift, s, sc, sc_scale, sc_shift, sc_relu, c, h, w};
+    const int per_plane = (h / 2) * (w / 4);
+    dim3 grid(n * c, (per_plane + kThreads - 1) / kThreads > 8 ? 8 : (per_plane + kThreads - 1) / kThreads);
+    tail_fwd_bf16_kernel<<<grid, kThreads, 0, lf::as_stream(stream)>>>(t, pooled);
+    return lf::check_launch("lf_block_tail_fwd_bf16");
+}
+
+int lf_conv2d_bf16_f32(const float* x, const uint16_t* wprep, float* y, int n, int cin, int h, int w,
+                       int cout, int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                       lf_stream_t stream) {
+    return lf_conv2d_bf16_act(x, 0, wprep, y, 0, n, cin, h, w, cout, ksize, in_scale, in_shift, in_relu, stream);
 }
 
 }  // extern "C"

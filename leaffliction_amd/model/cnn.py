@@ -335,6 +335,54 @@ class LeafCNN:
             y = nn.conv2d(x, w, ksize, pro[0], pro[1], pro[2], out=out)
         return y, self._bn(bn, y, False)
 
+    def _bf16_storage_ok(self, h: int, w: int) -> bool:
+        """The bf16-activation forward needs 4-pixel groups at every stage (conv staging, the
+        2x2-pool tail, the final mean) and 32-channel output blocks."""
+        for f in self.widths:
+            if f % 32 or w % 4 or h % 2:
+                return False
+            h, w = h // 2, w // 2
+        return (h * w) % 4 == 0
+
+    def _forward_infer_bf16(self, x0: torch.Tensor) -> torch.Tensor:
+        """Inference forward with bf16 conv operands AND bf16 activation storage (the layers'
+        outputs, as Keras' mixed_float16 keeps them); BatchNorm folding, SE gate, residual add,
+        pooling means and the dense head compute in fp32.  Returns probs [N, C] fp32."""
+        n, _c, h, w = x0.shape
+        P, bf = self.p, torch.bfloat16
+
+        def conv(x, wname, k, bn, pro):
+            wt = P[wname]
+            y = nn.conv2d_bf16(x, nn.conv2d_bf16_weights(wt, k), wt.shape[2], k, pro[0], pro[1], pro[2],
+                               out=self._buf(n, "bf16." + wname, (n, wt.shape[2], x.shape[2], x.shape[3]), bf))
+            return y, self._bn(bn, y, False)
+
+        xin, st = conv(x0, "stem.w", 3, "stem.bn", (None, None, False))
+        pro = (st[2], st[3], True)
+        cin = self.widths[0]
+        for i, f in enumerate(self.widths):
+            p = f"s{i}."
+            y1, st1 = conv(xin, p + "c1.w", 3, p + "bn1", pro)
+            y2, st2 = conv(y1, p + "c2.w", 3, p + "bn2", (st1[2], st1[3], True))
+            s = None
+            if self.use_se:
+                m = nn.gap_bf16(y2, st2[2], st2[3], True, out=self._buf(n, p + "m", (n, f)))
+                s = nn.se_fwd(m, P[p + "se.w1"], P[p + "se.b1"], P[p + "se.w2"], P[p + "se.b2"],
+                              self._buf(n, p + "z1", (n, f // 8)), self._buf(n, p + "s", (n, f)))
+            if cin != f:
+                yp, stp = conv(xin, p + "proj.w", 1, p + "bnp", pro)
+                sc, scs, scb, scr = yp, stp[2], stp[3], False
+            else:
+                sc, scs, scb, scr = xin, pro[0], pro[1], pro[2]
+            xin = nn.block_tail_fwd_bf16(y2, st2[2], st2[3], s, sc, scs, scb, scr,
+                                         out=self._buf(n, "bf16." + p + "p", (n, f, y2.shape[2] // 2,
+                                                                              y2.shape[3] // 2), bf))
+            pro, cin = (None, None, False), f
+        g = nn.gap_bf16(xin, out=self._buf(n, "g", (n, self.widths[-1])))
+        probs = self._buf(n, "probs", (n, self.num_classes))
+        nn.head_fwd(g, P["dense.w"], P["dense.b"], None, probs, None)
+        return probs
+
     def set_inference_dtype(self, dtype: str) -> None:
         """"f32" (default) or "bf16": the arithmetic of the convolutions in predict / evaluate.
         The reference runs them in half precision under its default mixed_float16 policy
@@ -629,12 +677,14 @@ class LeafCNN:
         outs = []
         for b in range(0, x.shape[0], batch_size):
             xb = x[b:b + batch_size]
-            probs, _ = self.forward(self._input(xb, False), False)
-            outs.append(probs.clone())
+            outs.append(self.predict_device(xb).clone())
         return torch.cat(outs).cpu().numpy()
 
     def predict_device(self, x) -> torch.Tensor:
-        probs, _ = self.forward(self._input(x, False), False)
+        x0 = self._input(x, False)
+        if self.infer_dtype == "bf16" and self._bf16_storage_ok(x0.shape[2], x0.shape[3]):
+            return self._forward_infer_bf16(x0)
+        probs, _ = self.forward(x0, False)
         return probs
 
     def evaluate(self, data, verbose: Any = 0, dp=None) -> List[float]:

@@ -75,10 +75,13 @@ def conv2d_bf16_weights(w_iko: torch.Tensor, ksize: int) -> torch.Tensor:
 
 
 def conv2d_bf16(x: torch.Tensor, wprep: torch.Tensor, cout: int, ksize: int, in_scale=None, in_shift=None,
-                in_relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """conv2d with bf16 operands / fp32 accumulation (inference): x, y fp32 NCHW, wprep from
-    conv2d_bf16_weights."""
-    _chk(x, _F32, "conv2d_bf16.x", 4)
+                in_relu: bool = False, out: Optional[torch.Tensor] = None,
+                out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """conv2d with bf16 operands / fp32 accumulation (inference).  x: fp32 or bf16 NCHW; the result
+    is fp32 or bf16 NCHW (`out_dtype`, or the dtype of `out`); wprep from conv2d_bf16_weights."""
+    if x.dtype not in (_F32, torch.bfloat16):
+        raise TypeError(f"conv2d_bf16.x: expected float32 or bfloat16, got {x.dtype}")
+    _chk(x, x.dtype, "conv2d_bf16.x", 4)
     n, cin, h, w = x.shape
     if wprep.dtype != torch.int16 or wprep.numel() != ((cin + 15) // 16) * ksize * ksize * cout * 16:
         raise ValueError("conv2d_bf16.wprep: not the packed weights of this convolution")
@@ -88,13 +91,46 @@ def conv2d_bf16(x: torch.Tensor, wprep: torch.Tensor, cout: int, ksize: int, in_
             if t.shape[0] != cin:
                 raise ValueError(f"conv2d_bf16.{nm}: expected [{cin}]")
     if out is None:
-        out = torch.empty((n, cout, h, w), dtype=_F32, device=x.device)
+        if out_dtype not in (_F32, torch.bfloat16):
+            raise TypeError("conv2d_bf16.out_dtype: float32 or bfloat16")
+        out = torch.empty((n, cout, h, w), dtype=out_dtype, device=x.device)
     else:
-        _chk(out, _F32, "conv2d_bf16.out", 4)
+        if out.dtype not in (_F32, torch.bfloat16):
+            raise TypeError("conv2d_bf16.out: float32 or bfloat16")
+        _chk(out, out.dtype, "conv2d_bf16.out", 4)
         if tuple(out.shape) != (n, cout, h, w):
             raise ValueError("conv2d_bf16.out: shape mismatch")
-    _lib.call("lf_conv2d_bf16_f32", x.data_ptr(), wprep.data_ptr(), out.data_ptr(), n, cin, h, w, cout, ksize,
+    _lib.call("lf_conv2d_bf16_act", x.data_ptr(), 1 if x.dtype == torch.bfloat16 else 0, wprep.data_ptr(),
+              out.data_ptr(), 1 if out.dtype == torch.bfloat16 else 0, n, cin, h, w, cout, ksize,
               _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, _stream())
+    return out
+
+
+def gap_bf16(x: torch.Tensor, scale=None, shift=None, relu: bool = False,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[N,C] fp32 plane means of relu?(x*scale[c]+shift[c]) for a bf16 NCHW tensor (inference)."""
+    _chk(x, torch.bfloat16, "gap_bf16.x", 4)
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=_F32, device=x.device)
+    _lib.call("lf_gap_bf16", x.data_ptr(), out.data_ptr(), n, c, h * w, _ptr(scale), _ptr(shift),
+              1 if relu else 0, _stream())
+    return out
+
+
+def block_tail_fwd_bf16(y, a_scale, a_shift, s, sc, sc_scale, sc_shift, sc_relu: bool,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """maxpool2x2(relu(shortcut' + relu(y*a_scale+a_shift) * s)) on bf16 NCHW tensors (inference)."""
+    _chk(y, torch.bfloat16, "block_tail_fwd_bf16.y", 4)
+    _chk(sc, torch.bfloat16, "block_tail_fwd_bf16.sc", 4)
+    n, c, h, w = y.shape
+    if tuple(sc.shape) != (n, c, h, w):
+        raise ValueError("block_tail_fwd_bf16.sc: shape mismatch")
+    if out is None:
+        out = torch.empty((n, c, h // 2, w // 2), dtype=torch.bfloat16, device=y.device)
+    _lib.call("lf_block_tail_fwd_bf16", y.data_ptr(), a_scale.data_ptr(), a_shift.data_ptr(), _ptr(s),
+              sc.data_ptr(), _ptr(sc_scale), _ptr(sc_shift), 1 if sc_relu else 0, out.data_ptr(), n, c, h, w,
+              _stream())
     return out
 
 

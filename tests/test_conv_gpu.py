@@ -285,3 +285,46 @@ def test_conv2d_bf16_rejects_unsupported_shapes(cuda):
     wd2 = torch.zeros((8, 9, 16), device=cuda)
     with pytest.raises(LeafHipError):
         nn.conv2d_bf16(torch.zeros((1, 8, 8, 8), device=cuda), nn.conv2d_bf16_weights(wd2, 3), 16, 3)  # cout % 32
+
+
+@pytest.mark.parametrize("xbf,ybf", [(True, True), (True, False), (False, True)])
+def test_conv2d_bf16_activation_storage(cuda, xbf, ybf):
+    """bf16 input and / or output storage of the reduced-precision convolution: reading a bf16
+    tensor equals reading its fp32 widening bit for bit; a bf16 result is the fp32 result rounded
+    to nearest even."""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(3)
+    n, cin, cout, h, w, k = 2, 64, 128, 56, 56, 3
+    x = torch.randn((n, cin, h, w), generator=g).to(cuda)
+    wt = (torch.randn((cin, k * k, cout), generator=g) * 0.05).to(cuda)
+    sc, sh = (torch.rand(cin, generator=g) + 0.5).to(cuda), (torch.randn(cin, generator=g) * 0.3).to(cuda)
+    wp = nn.conv2d_bf16_weights(wt, k)
+    xin = x.to(torch.bfloat16) if xbf else x
+    ref = nn.conv2d_bf16(xin.float() if xbf else x, wp, cout, k, sc, sh, True)          # fp32 in, fp32 out
+    got = nn.conv2d_bf16(xin, wp, cout, k, sc, sh, True,
+                         out_dtype=torch.bfloat16 if ybf else torch.float32)
+    assert got.dtype == (torch.bfloat16 if ybf else torch.float32)
+    assert torch.equal(got, ref.to(torch.bfloat16) if ybf else ref)
+
+
+def test_bf16_plane_kernels(cuda):
+    """gap / residual-tail on bf16 tensors == the fp32 kernels on the widened tensors (then
+    rounded for the bf16 output)."""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(4)
+    n, c, h, w = 3, 64, 28, 28
+    y = torch.randn((n, c, h, w), generator=g).to(cuda).to(torch.bfloat16)
+    sc = torch.randn((n, c, h, w), generator=g).to(cuda).to(torch.bfloat16)
+    a_s, a_b = (torch.rand(c, generator=g) + 0.5).to(cuda), (torch.randn(c, generator=g) * 0.2).to(cuda)
+    k_s, k_b = (torch.rand(c, generator=g) + 0.5).to(cuda), (torch.randn(c, generator=g) * 0.2).to(cuda)
+    gate = torch.rand((n, c), generator=g).to(cuda)
+    m16 = nn.gap_bf16(y, a_s, a_b, True)
+    m32 = nn.gap(y.float(), scale=a_s, shift=a_b, relu=True)
+    assert (m16 - m32).abs().max().item() < 1e-5
+    assert (nn.gap_bf16(y) - y.float().mean((2, 3))).abs().max().item() < 1e-5
+    for sc_scale, sc_shift, sc_relu, s in ((k_s, k_b, True, gate), (k_s, k_b, False, gate), (None, None, False, None)):
+        p16 = nn.block_tail_fwd_bf16(y, a_s, a_b, s, sc, sc_scale, sc_shift, sc_relu)
+        route = torch.empty((n, c, h // 2, w // 2), dtype=torch.uint8, device=cuda)
+        p32 = torch.empty((n, c, h // 2, w // 2), device=cuda)
+        nn.block_tail_fwd(y.float(), a_s, a_b, s, sc.float(), sc_scale, sc_shift, sc_relu, None, route, p32)
+        assert torch.equal(p16, p32.to(torch.bfloat16))
