@@ -63,20 +63,6 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     const size_t hw = (size_t)p.h * p.w;
     const float* xn = static_cast<const float*>(p.x) + (XBF ? 0 : (size_t)n * p.cin * hw);
     const uint16_t* xb = static_cast<const uint16_t*>(p.x) + (XBF ? (size_t)n * p.cin * hw : 0);
-    auto load4 = [&](int ci, size_t off) -> f32x4v {  // four pixels of one channel as fp32
-        f32x4v v;
-        if (XBF) {
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 raw = *reinterpret_cast<const u32x2*>(xb + (size_t)ci * hw + off);
-            v[0] = bf16_up(raw.x & 0xffffu);
-            v[1] = bf16_up(raw.x >> 16);
-            v[2] = bf16_up(raw.y & 0xffffu);
-            v[3] = bf16_up(raw.y >> 16);
-        } else {
-            v = *reinterpret_cast<const f32x4v*>(xn + (size_t)ci * hw + off);
-        }
-        return v;
-    };
 
     f32x16 acc[2][NCO];
 #pragma unroll
@@ -86,41 +72,92 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    for (int c = 0; c < p.chunks; ++c) {
-        __syncthreads();  // the previous chunk's reads are done
-        // input patch: item = (pair plane, patch row, group of four columns)
-        for (int it = tid; it < 8 * PH * (kPW / 4); it += kThreads) {
-            const int pl = it / (PH * (kPW / 4)), rem = it - pl * (PH * (kPW / 4));
-            const int row = rem / (kPW / 4), q = rem - row * (kPW / 4);
-            const int gy = y0 - R + row, gx = x0 - 4 + 4 * q;
+    // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued
+    // before the MFMAs of chunk c and land in LDS after them, so their latency hides behind the
+    // matrix work instead of standing between two barriers.
+    constexpr int kPatchItems = 8 * PH * (kPW / 4);
+    constexpr int NP = (kPatchItems + kThreads - 1) / kThreads;
+    constexpr int kWItems = TAPS * NCO * 64;
+    constexpr int NW = (kWItems + kThreads - 1) / kThreads;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    struct Raw {  // four pixels of one channel as loaded
+        f32x4v f;
+        u32x2 h;
+    };
+    Raw ra[NP], rb[NP];
+    lf::u32x4 rw[NW];
+
+    auto item_geo = [&](int it, int& pl, int& row, int& q, bool& inside, size_t& off) {
+        pl = it / (PH * (kPW / 4));
+        const int rem = it - pl * (PH * (kPW / 4));
+        row = rem / (kPW / 4);
+        q = rem - row * (kPW / 4);
+        const int gy = y0 - R + row, gx = x0 - 4 + 4 * q;
+        // w % 4 == 0: a group of four columns is inside the image or outside it as a whole
+        inside = gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+        off = inside ? (size_t)gy * p.w + gx : 0;
+    };
+    auto load_raw = [&](Raw& r, int ci, size_t off) {
+        if (XBF)
+            r.h = *reinterpret_cast<const u32x2*>(xb + (size_t)ci * hw + off);
+        else
+            r.f = *reinterpret_cast<const f32x4v*>(xn + (size_t)ci * hw + off);
+    };
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int it = tid + k * kThreads;
+            if (it >= kPatchItems) break;
+            int pl, row, q;
+            bool inside;
+            size_t off;
+            item_geo(it, pl, row, q, inside, off);
             const int ci0 = c * 16 + 2 * pl;
-            f32x4v a = {0.0f, 0.0f, 0.0f, 0.0f}, b = {0.0f, 0.0f, 0.0f, 0.0f};
-            // w % 4 == 0: a group of four columns is inside the image or outside it as a whole
-            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
-                const size_t off = (size_t)gy * p.w + gx;
-                if (ci0 < p.cin) {
-                    a = load4(ci0, off);
-                    if (p.in_scale) {
-                        const float s = p.in_scale[ci0], t = p.in_shift[ci0];
+            if (inside && ci0 < p.cin) load_raw(ra[k], ci0, off);
+            if (inside && ci0 + 1 < p.cin) load_raw(rb[k], ci0 + 1, off);
+        }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a[e] = fmaf(a[e], s, t);
-                    }
-                    if (p.in_relu)
+        for (int k = 0; k < NW; ++k) {
+            const int it = tid + k * kThreads;
+            if (it >= kWItems) break;
+            const int tap = it / (NCO * 64), rem = it - tap * (NCO * 64);
+            const size_t src = (((size_t)c * TAPS + tap) * p.cout + co0 + (rem >> 1)) * 16 + 8 * (rem & 1);
+            rw[k] = *reinterpret_cast<const lf::u32x4*>(p.wprep + src);
+        }
+    };
+    auto widen = [&](const Raw& r, int ci) -> f32x4v {  // fp32 values with the fused prologue applied
+        f32x4v v;
+        if (XBF) {
+            v[0] = bf16_up(r.h.x & 0xffffu);
+            v[1] = bf16_up(r.h.x >> 16);
+            v[2] = bf16_up(r.h.y & 0xffffu);
+            v[3] = bf16_up(r.h.y >> 16);
+        } else {
+            v = r.f;
+        }
+        if (p.in_scale) {
+            const float sc = p.in_scale[ci], sh = p.in_shift[ci];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.0f);
-                }
-                if (ci0 + 1 < p.cin) {
-                    b = load4(ci0 + 1, off);
-                    if (p.in_scale) {
-                        const float s = p.in_scale[ci0 + 1], t = p.in_shift[ci0 + 1];
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
+        }
+        if (p.in_relu)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) b[e] = fmaf(b[e], s, t);
-                    }
-                    if (p.in_relu)
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        return v;
+    };
+    auto commit = [&](int c) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) b[e] = fmaxf(b[e], 0.0f);
-                }
-            }
+        for (int k = 0; k < NP; ++k) {
+            const int it = tid + k * kThreads;
+            if (it >= kPatchItems) break;
+            int pl, row, q;
+            bool inside;
+            size_t off;
+            item_geo(it, pl, row, q, inside, off);
+            const int ci0 = c * 16 + 2 * pl;
+            f32x4v a = {0.0f, 0.0f, 0.0f, 0.0f}, b = {0.0f, 0.0f, 0.0f, 0.0f};  // padding stays exactly zero
+            if (inside && ci0 < p.cin) a = widen(ra[k], ci0);
+            if (inside && ci0 + 1 < p.cin) b = widen(rb[k], ci0 + 1);
             lf::u32x4 o;
             o.x = pack_bf16(a[0], b[0]);
             o.y = pack_bf16(a[1], b[1]);
@@ -128,13 +165,19 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
             o.w = pack_bf16(a[3], b[3]);
             *reinterpret_cast<lf::u32x4*>(&patch[pl][row][4 * q]) = o;
         }
-        // weights of this chunk for the workgroup's output channels: 16-byte pieces
-        for (int it = tid; it < TAPS * NCO * 64; it += kThreads) {
-            const int tap = it / (NCO * 64), rem = it - tap * (NCO * 64);
-            const int col = rem >> 1, hf = rem & 1;
-            const size_t src = (((size_t)c * TAPS + tap) * p.cout + co0 + col) * 16 + 8 * hf;
-            wl[it] = *reinterpret_cast<const lf::u32x4*>(p.wprep + src);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int it = tid + k * kThreads;
+            if (it >= kWItems) break;
+            wl[it] = rw[k];
         }
+    };
+
+    issue(0);
+    for (int c = 0; c < p.chunks; ++c) {
+        __syncthreads();  // the previous chunk's LDS reads are done
+        commit(c);
+        if (c + 1 < p.chunks) issue(c + 1);
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
