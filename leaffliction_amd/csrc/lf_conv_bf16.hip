@@ -9,7 +9,7 @@
 // not by the MFMA pipe.
 //
 // Implicit GEMM D[co][pixel] = sum_k W[co][k] X[k][pixel], K = (input channel, tap).  Workgroup =
-// 32x8 output pixels x 32*NCO output channels; per 16-channel chunk the input patch sits in LDS as
+// 32x8 output pixels x 64 output channels (32x16 x 32 when cout is an odd multiple of 32); per 16-channel chunk the input patch sits in LDS as
 // eight planes of channel PAIRS (one dword = bf16(ci), bf16(ci+1) of one pixel), so the B operand of
 // a lane (one pixel, eight consecutive channels) is four conflict-free ds_read_b32 and staging is
 // one ds_write_b128 per four pixels of a pair plane; weights are pre-packed once per model to
@@ -24,7 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int kTW = 32, kTH = 8;  // output tile
+constexpr int kTW = 32;            // output tile width; height = 4 waves x NB rows
 constexpr int kPW = 40;           // patch row pitch in dwords: columns x0-4 .. x0+35
 
 struct Bf16ConvArgs {
@@ -49,8 +49,9 @@ __device__ __forceinline__ float bf16_up(unsigned bits16) { return __uint_as_flo
 
 __device__ __forceinline__ uint16_t bf16_down(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
 
-template <int TAPS, int NCO, bool XBF, bool YBF>
+template <int TAPS, int NCO, int NB, bool XBF, bool YBF>
 __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
+    constexpr int kTH = 4 * NB;
     constexpr int R = TAPS == 9 ? 1 : 0, PH = kTH + 2 * R, KS = TAPS == 9 ? 3 : 1;
     __shared__ uint32_t patch[8][PH][kPW];
     __shared__ lf::u32x4 wl[TAPS * NCO * 32 * 2];
@@ -64,9 +65,9 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     const float* xn = static_cast<const float*>(p.x) + (XBF ? 0 : (size_t)n * p.cin * hw);
     const uint16_t* xb = static_cast<const uint16_t*>(p.x) + (XBF ? (size_t)n * p.cin * hw : 0);
 
-    f32x16 acc[2][NCO];
+    f32x16 acc[NB][NCO];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NB; ++a)
 #pragma unroll
         for (int b = 0; b < NCO; ++b)
 #pragma unroll
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
             for (int cb = 0; cb < NCO; ++cb)
                 A[cb] = __builtin_bit_cast(bf16x8, wl[((tap * NCO + cb) * 32 + px) * 2 + half]);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int row = 2 * wv + nb + dy;
+            for (int nb = 0; nb < NB; ++nb) {
+                const int row = NB * wv + nb + dy;
                 const int col = 4 + px + dx - R;
                 lf::u32x4 bv;
                 bv.x = patch[4 * half + 0][row][col];
@@ -207,8 +208,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     uint16_t* yb = static_cast<uint16_t*>(p.y) + (YBF ? (size_t)n * p.cout * hw : 0);
     const int gx = x0 + px;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int gy = y0 + 2 * wv + nb;
+    for (int nb = 0; nb < NB; ++nb) {
+        const int gy = y0 + NB * wv + nb;
         if (gy >= p.h || gx >= p.w) continue;
 #pragma unroll
         for (int cb = 0; cb < NCO; ++cb)
@@ -324,20 +325,23 @@ namespace {
 
 template <bool XBF, bool YBF>
 void launch_conv_bf16(const Bf16ConvArgs& a, int ksize, hipStream_t s) {
-    const int tiles = ((a.w + kTW - 1) / kTW) * ((a.h + kTH - 1) / kTH);
-    // two 32-channel blocks per workgroup share one staged patch; four measured the same
+    // cout % 64 == 0: two 32-channel blocks per workgroup share one staged 32x8 patch (four measured
+    // the same); cout == 32 (+64k): one block, and a 32x16 tile instead so that a staged patch
+    // still feeds 16 accumulator tiles per wave
     const int nco = a.cout % 64 == 0 ? 2 : 1;
+    const int th = nco == 2 ? 8 : 16;
+    const int tiles = ((a.w + kTW - 1) / kTW) * ((a.h + th - 1) / th);
     dim3 grid(tiles, a.cout / (32 * nco), a.n);
     if (ksize == 3) {
         if (nco == 2)
-            conv_bf16_kernel<9, 2, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+            conv_bf16_kernel<9, 2, 2, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
         else
-            conv_bf16_kernel<9, 1, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+            conv_bf16_kernel<9, 1, 4, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
     } else {
         if (nco == 2)
-            conv_bf16_kernel<1, 2, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+            conv_bf16_kernel<1, 2, 2, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
         else
-            conv_bf16_kernel<1, 1, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+            conv_bf16_kernel<1, 1, 4, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
     }
 }
 
