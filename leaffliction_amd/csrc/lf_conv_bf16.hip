@@ -180,17 +180,20 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
         commit(c);
         if (c + 1 < p.chunks) issue(c + 1);
         __syncthreads();
+        // One B operand (a patch row shifted by dx) serves every (output row, dy) pair that reads
+        // it: NB + KS - 1 LDS fetches per dx instead of NB * KS.
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int dy = tap / KS, dx = tap - dy * KS;
-            bf16x8 A[NCO];
+        for (int dx = 0; dx < KS; ++dx) {
+            bf16x8 A[KS][NCO];
 #pragma unroll
-            for (int cb = 0; cb < NCO; ++cb)
-                A[cb] = __builtin_bit_cast(bf16x8, wl[((tap * NCO + cb) * 32 + px) * 2 + half]);
+            for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int row = NB * wv + nb + dy;
-                const int col = 4 + px + dx - R;
+                for (int cb = 0; cb < NCO; ++cb)
+                    A[dy][cb] = __builtin_bit_cast(bf16x8, wl[(((dy * KS + dx) * NCO + cb) * 32 + px) * 2 + half]);
+            const int col = 4 + px + dx - R;
+#pragma unroll
+            for (int prow = 0; prow < NB + KS - 1; ++prow) {
+                const int row = NB * wv + prow;
                 lf::u32x4 bv;
                 bv.x = patch[4 * half + 0][row][col];
                 bv.y = patch[4 * half + 1][row][col];
@@ -198,8 +201,13 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
                 bv.w = patch[4 * half + 3][row][col];
                 const bf16x8 B = __builtin_bit_cast(bf16x8, bv);
 #pragma unroll
-                for (int cb = 0; cb < NCO; ++cb)
-                    acc[nb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cb], B, acc[nb][cb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int dy = prow - nb;
+                    if (dy < 0 || dy >= KS) continue;
+#pragma unroll
+                    for (int cb = 0; cb < NCO; ++cb)
+                        acc[nb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[dy][cb], B, acc[nb][cb], 0, 0, 0);
+                }
             }
         }
     }
