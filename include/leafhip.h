@@ -227,10 +227,16 @@ int lf_conv2d_bf16_f32(const float* x, const uint16_t* wprep, float* y, int n, i
  * (x_bf16 / y_bf16 flags; the fused prologue and the accumulation stay fp32), and the two plane
  * kernels of the block on bf16 tensors — lf_gap_f32's mean of relu?(x*scale+shift) (no mask
  * sums) and lf_block_tail_fwd_f32's maxpool2x2(relu(shortcut' + relu(BN(y)) * gate)) without the
- * route bytes and dropout a backward pass would need.  hw % 4 == 0 / w % 4 == 0, h even. */
+ * route bytes and dropout a backward pass would need.  hw % 4 == 0 / w % 4 == 0, h even.
+ * out_scale / out_shift / out_relu: optional epilogue v*out_scale[co]+out_shift[co] (+ReLU) on the
+ * fp32 accumulators — at inference the layer's folded BatchNorm(+ReLU), so that what is stored is
+ * the activation itself and the consumer needs no prologue (a bf16 input without prologue is staged
+ * by interleaving the stored bits, no arithmetic).  The tail's a_scale / a_shift may then be null
+ * (y holds relu(BN(.)) already). */
 int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y, int y_bf16, int n,
                        int cin, int h, int wd, int cout, int ksize, const float* in_scale,
-                       const float* in_shift, int in_relu, lf_stream_t stream);
+                       const float* in_shift, int in_relu, const float* out_scale,
+                       const float* out_shift, int out_relu, lf_stream_t stream);
 int lf_gap_bf16(const uint16_t* x, float* out, int n, int c, int hw, const float* scale,
                 const float* shift, int relu, lf_stream_t stream);
 int lf_block_tail_fwd_bf16(const uint16_t* y, const float* a_scale, const float* a_shift,

@@ -48,7 +48,8 @@ SIGNATURES = {
     "lf_conv2d_bf16_weight_elems": [c_int, c_int, c_int],
     "lf_conv2d_bf16_prep_weights": [P, P, c_int, c_int, c_int, P],
     "lf_conv2d_bf16_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P],
-    "lf_conv2d_bf16_act": [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P],
+    "lf_conv2d_bf16_act": [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int,
+                           P, P, c_int, P],
     "lf_gap_bf16": [P, P, c_int, c_int, c_int, P, P, c_int, P],
     "lf_block_tail_fwd_bf16": [P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
     "lf_conv2d_variant": [c_int, c_int, c_int, c_int],

@@ -35,6 +35,9 @@ struct Bf16ConvArgs {
     const float* in_scale;
     const float* in_shift;
     int in_relu;
+    const float* out_scale;  // optional epilogue on the fp32 accumulators: v*out_scale[co]+out_shift[co],
+    const float* out_shift;  // then ReLU if out_relu (inference: the layer's folded BatchNorm + ReLU)
+    int out_relu;
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
@@ -55,6 +58,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     constexpr int R = TAPS == 9 ? 1 : 0, PH = kTH + 2 * R, KS = TAPS == 9 ? 3 : 1;
     __shared__ uint32_t patch[8][PH][kPW];
     __shared__ lf::u32x4 wl[TAPS * NCO * 32 * 2];
+    __shared__ float eps[2][NCO * 32];  // epilogue scale / shift of this workgroup's output channels
     const int tiles_x = (p.w + kTW - 1) / kTW;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int x0 = tx * kTW, y0 = ty * kTH;
@@ -88,16 +92,25 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     Raw ra[NP], rb[NP];
     lf::u32x4 rw[NW];
 
-    auto item_geo = [&](int it, int& pl, int& row, int& q, bool& inside, size_t& off) {
-        pl = it / (PH * (kPW / 4));
-        const int rem = it - pl * (PH * (kPW / 4));
-        row = rem / (kPW / 4);
-        q = rem - row * (kPW / 4);
+    // per-item geometry does not depend on the chunk: decode it once
+    int g_pl[NP];        // pair plane, or -1 for a slot past the end / outside the image
+    unsigned g_off[NP];  // element offset of the four pixels inside a channel plane
+    unsigned g_lds[NP];  // dword index into patch[][][]
+    bool g_live[NP];     // slot exists (outside-image slots still write their zeros)
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int it = tid + k * kThreads;
+        g_live[k] = it < kPatchItems;
+        const int pl = it / (PH * (kPW / 4)), rem = it - pl * (PH * (kPW / 4));
+        const int row = rem / (kPW / 4), q = rem - row * (kPW / 4);
         const int gy = y0 - R + row, gx = x0 - 4 + 4 * q;
         // w % 4 == 0: a group of four columns is inside the image or outside it as a whole
-        inside = gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-        off = inside ? (size_t)gy * p.w + gx : 0;
-    };
+        const bool inside = g_live[k] && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+        g_pl[k] = inside ? pl : -1;
+        g_off[k] = inside ? (unsigned)gy * (unsigned)p.w + (unsigned)gx : 0u;
+        g_lds[k] = (unsigned)((pl * PH + row) * kPW + 4 * q);
+        if (!g_live[k]) g_lds[k] = 0;
+    }
     auto load_raw = [&](Raw& r, int ci, size_t off) {
         if (XBF)
             r.h = *reinterpret_cast<const u32x2*>(xb + (size_t)ci * hw + off);
@@ -107,15 +120,10 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     auto issue = [&](int c) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int it = tid + k * kThreads;
-            if (it >= kPatchItems) break;
-            int pl, row, q;
-            bool inside;
-            size_t off;
-            item_geo(it, pl, row, q, inside, off);
-            const int ci0 = c * 16 + 2 * pl;
-            if (inside && ci0 < p.cin) load_raw(ra[k], ci0, off);
-            if (inside && ci0 + 1 < p.cin) load_raw(rb[k], ci0 + 1, off);
+            if (g_pl[k] < 0) continue;
+            const int ci0 = c * 16 + 2 * g_pl[k];
+            if (ci0 < p.cin) load_raw(ra[k], ci0, g_off[k]);
+            if (ci0 + 1 < p.cin) load_raw(rb[k], ci0 + 1, g_off[k]);
         }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
@@ -146,25 +154,34 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
         return v;
     };
+    const bool passthrough = XBF && p.in_scale == nullptr && !p.in_relu;  // bf16 in, no prologue
+    uint32_t* patch_flat = &patch[0][0][0];
     auto commit = [&](int c) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int it = tid + k * kThreads;
-            if (it >= kPatchItems) break;
-            int pl, row, q;
-            bool inside;
-            size_t off;
-            item_geo(it, pl, row, q, inside, off);
-            const int ci0 = c * 16 + 2 * pl;
-            f32x4v a = {0.0f, 0.0f, 0.0f, 0.0f}, b = {0.0f, 0.0f, 0.0f, 0.0f};  // padding stays exactly zero
-            if (inside && ci0 < p.cin) a = widen(ra[k], ci0);
-            if (inside && ci0 + 1 < p.cin) b = widen(rb[k], ci0 + 1);
+            if (!g_live[k]) continue;
+            const bool inside = g_pl[k] >= 0;
+            const int ci0 = c * 16 + 2 * (inside ? g_pl[k] : 0);
             lf::u32x4 o;
-            o.x = pack_bf16(a[0], b[0]);
-            o.y = pack_bf16(a[1], b[1]);
-            o.z = pack_bf16(a[2], b[2]);
-            o.w = pack_bf16(a[3], b[3]);
-            *reinterpret_cast<lf::u32x4*>(&patch[pl][row][4 * q]) = o;
+            if (passthrough) {
+                // the stored values are the operands: interleave the two channels' bf16 pixels
+                u32x2 a = {0u, 0u}, b = {0u, 0u};  // padding stays exactly zero
+                if (inside && ci0 < p.cin) a = ra[k].h;
+                if (inside && ci0 + 1 < p.cin) b = rb[k].h;
+                o.x = (a.x & 0xffffu) | (b.x << 16);
+                o.y = (a.x >> 16) | (b.x & 0xffff0000u);
+                o.z = (a.y & 0xffffu) | (b.y << 16);
+                o.w = (a.y >> 16) | (b.y & 0xffff0000u);
+            } else {
+                f32x4v a = {0.0f, 0.0f, 0.0f, 0.0f}, b = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (inside && ci0 < p.cin) a = widen(ra[k], ci0);
+                if (inside && ci0 + 1 < p.cin) b = widen(rb[k], ci0 + 1);
+                o.x = pack_bf16(a[0], b[0]);
+                o.y = pack_bf16(a[1], b[1]);
+                o.z = pack_bf16(a[2], b[2]);
+                o.w = pack_bf16(a[3], b[3]);
+            }
+            *reinterpret_cast<lf::u32x4*>(patch_flat + g_lds[k]) = o;
         }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
@@ -174,6 +191,10 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
         }
     };
 
+    if (p.out_scale && tid < NCO * 32) {  // read back after the chunk loop's barriers
+        eps[0][tid] = p.out_scale[co0 + tid];
+        eps[1][tid] = p.out_shift[co0 + tid];
+    }
     issue(0);
     for (int c = 0; c < p.chunks; ++c) {
         __syncthreads();  // the previous chunk's LDS reads are done
@@ -223,12 +244,16 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
         for (int cb = 0; cb < NCO; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + cb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                const int col = cb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                const int co = co0 + col;
                 const size_t o = (size_t)co * hw + (size_t)gy * p.w + gx;
+                float v = acc[nb][cb][r];
+                if (p.out_scale) v = fmaf(v, eps[0][col], eps[1][col]);
+                if (p.out_relu) v = fmaxf(v, 0.0f);
                 if (YBF)
-                    yb[o] = bf16_down(acc[nb][cb][r]);
+                    yb[o] = bf16_down(v);
                 else
-                    yn[o] = acc[nb][cb][r];
+                    yn[o] = v;
             }
     }
 }
@@ -281,12 +306,12 @@ struct TailBf16Args {
 __global__ __launch_bounds__(kThreads) void tail_fwd_bf16_kernel(TailBf16Args t, uint16_t* __restrict__ p) {
     const int plane = blockIdx.x, ch = plane % t.c;
     const float sv = t.s ? t.s[plane] : 1.f;
-    const float as = t.a_scale[ch], ab = t.a_shift[ch];
+    const float as = t.a_scale ? t.a_scale[ch] : 1.f, ab = t.a_scale ? t.a_shift[ch] : 0.f;
     const float ks = t.sc_scale ? t.sc_scale[ch] : 1.f, kb = t.sc_scale ? t.sc_shift[ch] : 0.f;
     const int h = t.h, w = t.w, ph = h / 2, pw = w / 2, pw2 = pw / 2;
     const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
     auto r = [&](unsigned yb, unsigned sb) {
-        const float a = fmaxf(fmaf(bf16_up(yb), as, ab), 0.f);
+        const float a = t.a_scale ? fmaxf(fmaf(bf16_up(yb), as, ab), 0.f) : bf16_up(yb);
         float shv = bf16_up(sb);
         if (t.sc_scale) {
             shv = fmaf(shv, ks, kb);
@@ -375,17 +400,22 @@ int lf_conv2d_bf16_prep_weights(const float* w_iko, uint16_t* wprep, int cin, in
 
 int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y, int y_bf16, int n, int cin,
                        int h, int w, int cout, int ksize, const float* in_scale, const float* in_shift,
-                       int in_relu, lf_stream_t stream) {
+                       int in_relu, const float* out_scale, const float* out_shift, int out_relu,
+                       lf_stream_t stream) {
     LF_REQUIRE(x && wprep && y, "lf_conv2d_bf16: null buffer");
     LF_REQUIRE(n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0, "lf_conv2d_bf16: bad dims");
     LF_REQUIRE(ksize == 1 || ksize == 3, "lf_conv2d_bf16: ksize must be 1 or 3");
     LF_REQUIRE(w % 4 == 0, "lf_conv2d_bf16: width must be a multiple of 4 (got %d)", w);
     LF_REQUIRE(cout % 32 == 0, "lf_conv2d_bf16: cout must be a multiple of 32 (got %d)", cout);
     LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "lf_conv2d_bf16: scale/shift must both be set");
+    LF_REQUIRE((out_scale == nullptr) == (out_shift == nullptr),
+               "lf_conv2d_bf16: out_scale/out_shift must both be set");
+    LF_REQUIRE((size_t)h * w < ((size_t)1 << 32), "lf_conv2d_bf16: plane too large");
     LF_REQUIRE(n <= 65535, "lf_conv2d_bf16: batch too large for grid.z");
     LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wprep)) & 15) == 0,
                "lf_conv2d_bf16: x and wprep must be 16-byte aligned");
-    Bf16ConvArgs a{x, wprep, y, n, cin, h, w, cout, (cin + 15) / 16, in_scale, in_shift, in_relu};
+    Bf16ConvArgs a{x, wprep, y, n, cin, h, w, cout, (cin + 15) / 16, in_scale, in_shift, in_relu,
+                   out_scale, out_shift, out_relu};
     hipStream_t s = lf::as_stream(stream);
     if (x_bf16) {
         if (y_bf16) launch_conv_bf16<true, true>(a, ksize, s); else launch_conv_bf16<true, false>(a, ksize, s);
@@ -409,7 +439,8 @@ int lf_gap_bf16(const uint16_t* x, float* out, int n, int c, int hw, const float
 int lf_block_tail_fwd_bf16(const uint16_t* y, const float* a_scale, const float* a_shift, const float* s,
                            const uint16_t* sc, const float* sc_scale, const float* sc_shift, int sc_relu,
                            uint16_t* pooled, int n, int c, int h, int w, lf_stream_t stream) {
-    LF_REQUIRE(y && a_scale && a_shift && sc && pooled, "lf_block_tail_fwd_bf16: null buffer");
+    LF_REQUIRE(y && sc && pooled, "lf_block_tail_fwd_bf16: null buffer");
+    LF_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "lf_block_tail_fwd_bf16: a_scale/a_shift must both be set");
     LF_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 4 == 0,
                "lf_block_tail_fwd_bf16: bad dims n=%d c=%d h=%d w=%d (h even, w %% 4 == 0)", n, c, h, w);
     LF_REQUIRE((sc_scale == nullptr) == (sc_shift == nullptr), "lf_block_tail_fwd_bf16: scale/shift must both be set");
@@ -426,7 +457,8 @@ int lf_block_tail_fwd_bf16(const uint16_t* y, const float* a_scale, const float*
 int lf_conv2d_bf16_f32(const float* x, const uint16_t* wprep, float* y, int n, int cin, int h, int w,
                        int cout, int ksize, const float* in_scale, const float* in_shift, int in_relu,
                        lf_stream_t stream) {
-    return lf_conv2d_bf16_act(x, 0, wprep, y, 0, n, cin, h, w, cout, ksize, in_scale, in_shift, in_relu, stream);
+    return lf_conv2d_bf16_act(x, 0, wprep, y, 0, n, cin, h, w, cout, ksize, in_scale, in_shift, in_relu, nullptr,
+                              nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -346,38 +346,36 @@ class LeafCNN:
 
     def _forward_infer_bf16(self, x0: torch.Tensor) -> torch.Tensor:
         """Inference forward with bf16 conv operands AND bf16 activation storage (the layers'
-        outputs, as Keras' mixed_float16 keeps them); BatchNorm folding, SE gate, residual add,
-        pooling means and the dense head compute in fp32.  Returns probs [N, C] fp32."""
-        n, _c, h, w = x0.shape
+        outputs, as Keras' mixed_float16 keeps them).  Each convolution applies its folded
+        BatchNorm (+ReLU) to the fp32 accumulators before rounding, so what is stored IS the
+        activation and the next convolution stages the stored bits without arithmetic; SE gate,
+        residual add, pooling means and the dense head compute in fp32.  Returns probs [N, C]."""
+        n, _c, _h, _w = x0.shape
         P, bf = self.p, torch.bfloat16
 
-        def conv(x, wname, k, bn, pro):
+        def conv(x, wname, k, bn, relu):
             wt = P[wname]
-            y = nn.conv2d_bf16(x, nn.conv2d_bf16_weights(wt, k), wt.shape[2], k, pro[0], pro[1], pro[2],
-                               out=self._buf(n, "bf16." + wname, (n, wt.shape[2], x.shape[2], x.shape[3]), bf))
-            return y, self._bn(bn, y, False)
+            st = self._bn(bn, None, False)       # inference: scale / shift from the moving statistics
+            return nn.conv2d_bf16(x, nn.conv2d_bf16_weights(wt, k), wt.shape[2], k,
+                                  out=self._buf(n, "bf16." + wname, (n, wt.shape[2], x.shape[2], x.shape[3]), bf),
+                                  out_scale=st[2], out_shift=st[3], out_relu=relu)
 
-        xin, st = conv(x0, "stem.w", 3, "stem.bn", (None, None, False))
-        pro = (st[2], st[3], True)
+        xin = conv(x0, "stem.w", 3, "stem.bn", True)
         cin = self.widths[0]
         for i, f in enumerate(self.widths):
             p = f"s{i}."
-            y1, st1 = conv(xin, p + "c1.w", 3, p + "bn1", pro)
-            y2, st2 = conv(y1, p + "c2.w", 3, p + "bn2", (st1[2], st1[3], True))
+            a1 = conv(xin, p + "c1.w", 3, p + "bn1", True)
+            a2 = conv(a1, p + "c2.w", 3, p + "bn2", True)
             s = None
             if self.use_se:
-                m = nn.gap_bf16(y2, st2[2], st2[3], True, out=self._buf(n, p + "m", (n, f)))
+                m = nn.gap_bf16(a2, out=self._buf(n, p + "m", (n, f)))
                 s = nn.se_fwd(m, P[p + "se.w1"], P[p + "se.b1"], P[p + "se.w2"], P[p + "se.b2"],
                               self._buf(n, p + "z1", (n, f // 8)), self._buf(n, p + "s", (n, f)))
-            if cin != f:
-                yp, stp = conv(xin, p + "proj.w", 1, p + "bnp", pro)
-                sc, scs, scb, scr = yp, stp[2], stp[3], False
-            else:
-                sc, scs, scb, scr = xin, pro[0], pro[1], pro[2]
-            xin = nn.block_tail_fwd_bf16(y2, st2[2], st2[3], s, sc, scs, scb, scr,
-                                         out=self._buf(n, "bf16." + p + "p", (n, f, y2.shape[2] // 2,
-                                                                              y2.shape[3] // 2), bf))
-            pro, cin = (None, None, False), f
+            sc = conv(xin, p + "proj.w", 1, p + "bnp", False) if cin != f else xin
+            xin = nn.block_tail_fwd_bf16(a2, None, None, s, sc, None, None, False,
+                                         out=self._buf(n, "bf16." + p + "p", (n, f, a2.shape[2] // 2,
+                                                                              a2.shape[3] // 2), bf))
+            cin = f
         g = nn.gap_bf16(xin, out=self._buf(n, "g", (n, self.widths[-1])))
         probs = self._buf(n, "probs", (n, self.num_classes))
         nn.head_fwd(g, P["dense.w"], P["dense.b"], None, probs, None)

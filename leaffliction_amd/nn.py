@@ -76,9 +76,11 @@ def conv2d_bf16_weights(w_iko: torch.Tensor, ksize: int) -> torch.Tensor:
 
 def conv2d_bf16(x: torch.Tensor, wprep: torch.Tensor, cout: int, ksize: int, in_scale=None, in_shift=None,
                 in_relu: bool = False, out: Optional[torch.Tensor] = None,
-                out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                out_dtype: torch.dtype = torch.float32, out_scale=None, out_shift=None,
+                out_relu: bool = False) -> torch.Tensor:
     """conv2d with bf16 operands / fp32 accumulation (inference).  x: fp32 or bf16 NCHW; the result
-    is fp32 or bf16 NCHW (`out_dtype`, or the dtype of `out`); wprep from conv2d_bf16_weights."""
+    is fp32 or bf16 NCHW (`out_dtype`, or the dtype of `out`); wprep from conv2d_bf16_weights.
+    out_scale / out_shift [Cout] (+ out_relu): epilogue on the accumulators (folded BatchNorm)."""
     if x.dtype not in (_F32, torch.bfloat16):
         raise TypeError(f"conv2d_bf16.x: expected float32 or bfloat16, got {x.dtype}")
     _chk(x, x.dtype, "conv2d_bf16.x", 4)
@@ -102,7 +104,8 @@ def conv2d_bf16(x: torch.Tensor, wprep: torch.Tensor, cout: int, ksize: int, in_
             raise ValueError("conv2d_bf16.out: shape mismatch")
     _lib.call("lf_conv2d_bf16_act", x.data_ptr(), 1 if x.dtype == torch.bfloat16 else 0, wprep.data_ptr(),
               out.data_ptr(), 1 if out.dtype == torch.bfloat16 else 0, n, cin, h, w, cout, ksize,
-              _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, _stream())
+              _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, _ptr(out_scale), _ptr(out_shift),
+              1 if out_relu else 0, _stream())
     return out
 
 
@@ -128,7 +131,7 @@ def block_tail_fwd_bf16(y, a_scale, a_shift, s, sc, sc_scale, sc_shift, sc_relu:
         raise ValueError("block_tail_fwd_bf16.sc: shape mismatch")
     if out is None:
         out = torch.empty((n, c, h // 2, w // 2), dtype=torch.bfloat16, device=y.device)
-    _lib.call("lf_block_tail_fwd_bf16", y.data_ptr(), a_scale.data_ptr(), a_shift.data_ptr(), _ptr(s),
+    _lib.call("lf_block_tail_fwd_bf16", y.data_ptr(), _ptr(a_scale), _ptr(a_shift), _ptr(s),
               sc.data_ptr(), _ptr(sc_scale), _ptr(sc_shift), 1 if sc_relu else 0, out.data_ptr(), n, c, h, w,
               _stream())
     return out

@@ -307,6 +307,28 @@ def test_conv2d_bf16_activation_storage(cuda, xbf, ybf):
     assert torch.equal(got, ref.to(torch.bfloat16) if ybf else ref)
 
 
+def test_conv2d_bf16_epilogue_and_passthrough_staging(cuda):
+    """The folded-BatchNorm epilogue equals applying it to the fp32 result; a bf16 input without
+    prologue (staged by interleaving the stored bits) equals the same values fed as fp32."""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(8)
+    for (n, cin, cout, h, w, k) in ((2, 64, 128, 56, 56, 3), (2, 32, 32, 40, 64, 3), (2, 128, 256, 28, 28, 1)):
+        x = torch.randn((n, cin, h, w), generator=g).to(cuda).to(torch.bfloat16)
+        wt = (torch.randn((cin, k * k, cout), generator=g) * 0.05).to(cuda)
+        osc, osh = (torch.rand(cout, generator=g) + 0.5).to(cuda), (torch.randn(cout, generator=g) * 0.3).to(cuda)
+        wp = nn.conv2d_bf16_weights(wt, k)
+        raw = nn.conv2d_bf16(x.float(), wp, cout, k)                                   # fp32 in, fp32 out
+        want = torch.relu(torch.addcmul(osh[None, :, None, None], raw, osc[None, :, None, None]))
+        got = nn.conv2d_bf16(x, wp, cout, k, out_dtype=torch.bfloat16, out_scale=osc, out_shift=osh, out_relu=True)
+        # the kernel's epilogue is one fmaf; torch's addcmul may round the product first: allow the
+        # last fp32 bit, i.e. at most one bf16 step after rounding
+        assert torch.allclose(got.float(), want, rtol=2.0 ** -7, atol=1e-6)
+        assert (got.float() - want.to(torch.bfloat16).float()).abs().gt(0).float().mean().item() < 1e-3
+        lin = nn.conv2d_bf16(x, wp, cout, k, out_scale=osc, out_shift=osh)              # no ReLU, fp32 out
+        assert torch.allclose(lin, torch.addcmul(osh[None, :, None, None], raw, osc[None, :, None, None]),
+                              rtol=1e-6, atol=1e-6)
+
+
 def test_bf16_plane_kernels(cuda):
     """gap / residual-tail on bf16 tensors == the fp32 kernels on the widened tensors (then
     rounded for the bf16 output)."""
@@ -328,3 +350,8 @@ def test_bf16_plane_kernels(cuda):
         p32 = torch.empty((n, c, h // 2, w // 2), device=cuda)
         nn.block_tail_fwd(y.float(), a_s, a_b, s, sc.float(), sc_scale, sc_shift, sc_relu, None, route, p32)
         assert torch.equal(p16, p32.to(torch.bfloat16))
+    # already-activated input (a_scale = None): relu(shortcut + y * gate), pooled
+    ya = torch.relu(y.float()).to(torch.bfloat16)
+    p16 = nn.block_tail_fwd_bf16(ya, None, None, gate, sc, None, None, False)
+    want = torch.nn.functional.max_pool2d(torch.relu(sc.float() + ya.float() * gate[:, :, None, None]), 2)
+    assert torch.equal(p16, want.to(torch.bfloat16))
