@@ -355,3 +355,20 @@ def test_bf16_plane_kernels(cuda):
     p16 = nn.block_tail_fwd_bf16(ya, None, None, gate, sc, None, None, False)
     want = torch.nn.functional.max_pool2d(torch.relu(sc.float() + ya.float() * gate[:, :, None, None]), 2)
     assert torch.equal(p16, want.to(torch.bfloat16))
+
+
+def test_conv2d_bf16_serves_as_input_gradient(cuda):
+    """The bf16 forward kernel on the flipped / transposed weights (lf_conv2d_dgrad_weights_f32) is
+    the reduced-precision input-gradient convolution: same result as the fp32 dgrad within bf16
+    operand rounding.  (Groundwork for reduced-precision training; not used by the fp32 step.)"""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(12)
+    n, cin, cout, h, w, k = 2, 64, 128, 56, 56, 3
+    dy = torch.randn((n, cout, h, w), generator=g).to(cuda)
+    wt = (torch.randn((cin, k * k, cout), generator=g) * 0.05).to(cuda)
+    wflip = nn.conv2d_dgrad_weights(wt, k)                       # [cout][k*k][cin]
+    want = nn.conv2d(dy, wflip, k)
+    got = nn.conv2d_bf16(dy, nn.conv2d_bf16_weights(wflip, k), cin, k)
+    close(got.cpu(), want.cpu(), tol=2e-2)
+    ref = F.conv_transpose2d(dy.cpu(), iko_to_oihw(wt.cpu(), k), padding=k // 2)
+    close(got.cpu(), ref, tol=2e-2)
