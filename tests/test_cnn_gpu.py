@@ -127,6 +127,21 @@ def test_bf16_inference_matches_fp32(cuda, img):
         m.set_inference_dtype("fp8")
 
 
+def test_bf16_inference_falls_back_per_layer_on_odd_sizes(cuda):
+    """Image sizes whose later stages are not a multiple of four pixels wide (48 -> 24 -> 12 -> 6):
+    the bf16-storage forward does not apply; the convolutions that can still take bf16 operands do,
+    the rest run in fp32, and the result stays within the mode's tolerance of the fp32 path."""
+    widths, classes, n, img = [32, 64, 128, 256], 4, 6, 48
+    m, _ref_p, _ref_s = make_model(cuda, widths, classes, img, use_norm=False)
+    assert not m._bf16_storage_ok(img, img)
+    g = torch.Generator().manual_seed(6)
+    x_u8 = torch.randint(0, 256, (n, img, img, 3), dtype=torch.uint8, generator=g).numpy()
+    p32 = m.predict(x_u8)
+    m.set_inference_dtype("bf16")
+    p16 = m.predict(x_u8)
+    assert not np.array_equal(p16, p32) and np.abs(p16 - p32).max() < 3e-2
+
+
 def test_adamw_clipnorm_ema_matches_oracle(cuda):
     """Three optimizer steps on synthetic gradients: per-tensor clip, decoupled decay, L2, EMA."""
     from leaffliction_amd import nn
