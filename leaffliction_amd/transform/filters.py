@@ -87,3 +87,25 @@ def leaf_hsv_histograms(rgb: np.ndarray) -> Optional[np.ndarray]:
     """256-bin histograms of H, S, V over the leaf pixels ([3,256] int64): the data behind the
     density curves of hist.py:140-178."""
     return _stats(rgb)[1]
+
+
+def hsv_density_curves(rgb: np.ndarray, bins: int = 60):
+    """The three curves of the "Histogramme HSV Amélioré" panel (hist.py:140-167): matplotlib's
+    `ax.hist(channel[leaf], bins=60, density=True)` for H, S and V, i.e. numpy's histogram over the
+    channel's own min..max.  Computed from the 256-bin leaf histograms the GPU returns: the values
+    are integers, so weighting the 256 possible values by their counts bins exactly like the raw
+    pixels do.  Returns {"H"|"S"|"V": (density [bins], edges [bins+1])}; a channel without leaf
+    pixels is omitted."""
+    hist = leaf_hsv_histograms(rgb)
+    values = np.arange(256)
+    out = {}
+    for name, counts in zip(("H", "S", "V"), hist):
+        present = np.nonzero(counts)[0]
+        if present.size == 0:
+            continue
+        lo, hi = int(present[0]), int(present[-1])
+        dens, edges = np.histogram(values, bins=bins, range=(lo, hi) if hi > lo else None,
+                                   weights=counts.astype(np.float64), density=True) \
+            if hi > lo else np.histogram(np.full(int(counts[lo]), lo), bins=bins, density=True)
+        out[name] = (dens, edges)
+    return out

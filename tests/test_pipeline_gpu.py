@@ -266,6 +266,16 @@ def test_transform_filters_host_mirror(cuda):
         assert got[k] == (int(counts[1 + i]) / int(counts[0])) * 100
     assert hue_range_counts(img) == {k: int(counts[9 + i]) for i, k in enumerate(HUE_KEYS)}
     assert analyze_color_regions(np.zeros((8, 8, 3), np.uint8)) == {}
+    # the density curves matplotlib would draw (hist.py:153-167): numpy's histogram of the leaf
+    # pixels of each channel over its own range
+    from leaffliction_amd.transform import hsv_density_curves
+    hsv = CV.rgb2hsv(img).astype(np.int64)
+    leaf = (hsv[..., 1] > 10) & (hsv[..., 2] > 15) & (hsv[..., 2] < 245)
+    curves = hsv_density_curves(img)
+    for ci, name in enumerate("HSV"):
+        want_d, want_e = np.histogram(hsv[..., ci][leaf], bins=60, density=True)
+        got_d, got_e = curves[name]
+        assert np.array_equal(got_e, want_e) and np.allclose(got_d, want_d, rtol=1e-12, atol=0)
 
 
 def test_predict_in_bf16_mode_gives_the_same_confusion_matrix(cuda, tmp_path, monkeypatch):
