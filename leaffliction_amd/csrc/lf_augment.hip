@@ -703,7 +703,7 @@ constexpr int kFTX = 64, kFTY = 32;
 template <int CH, int KS>
 __global__ __launch_bounds__(kBlock) void gauss_blur_fast_kernel(const uint8_t* __restrict__ in,
                                                                  uint8_t* __restrict__ out, int h,
-                                                                 int w, BlurTaps taps) {
+                                                                 int w, BlurTaps taps, int n_images) {
     const uint16_t* kq = taps.k;
     constexpr int R = KS / 2, PR = kFTY + 2 * R;
     constexpr int NG = (kFTX + 2 * R + 3) / 4;  // 4-pixel groups per patch row
@@ -716,8 +716,10 @@ __global__ __launch_bounds__(kBlock) void gauss_blur_fast_kernel(const uint8_t* 
     __shared__ __attribute__((aligned(16))) unsigned midT[CH * MIDP];
     unsigned char* stage = patch;  // [CH][kFTY][kFTX], reuses the patch after the horizontal pass
 
-    const unsigned n = blockIdx.z;
-    const int x0 = blockIdx.x * kFTX, y0 = blockIdx.y * kFTY;
+    const lf::TileId tile = lf::xcd_tile((w + kFTX - 1) / kFTX, (h + kFTY - 1) / kFTY, n_images);
+    if (!tile.ok) return;
+    const unsigned n = (unsigned)tile.n;
+    const int x0 = tile.tx * kFTX, y0 = tile.ty * kFTY;
     const uint8_t* src = in + (size_t)n * h * w * CH;
     uint8_t* dst = out + (size_t)n * h * w * CH;
 
@@ -869,15 +871,15 @@ __global__ __launch_bounds__(kBlock) void gauss_blur_fast_kernel(const uint8_t* 
 template <int CH>
 bool launch_blur_fast(const uint8_t* in, uint8_t* out, int n, int h, int w, const BlurTaps& kq,
                       int ksize, hipStream_t s) {
-    dim3 grid((w + kFTX - 1) / kFTX, (h + kFTY - 1) / kFTY, n);
+    const unsigned grid = lf::xcd_grid((size_t)((w + kFTX - 1) / kFTX) * ((h + kFTY - 1) / kFTY) * n);
     switch (ksize) {
-        case 3: gauss_blur_fast_kernel<CH, 3><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
-        case 5: gauss_blur_fast_kernel<CH, 5><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
-        case 7: gauss_blur_fast_kernel<CH, 7><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
-        case 9: gauss_blur_fast_kernel<CH, 9><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
-        case 11: gauss_blur_fast_kernel<CH, 11><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
-        case 13: gauss_blur_fast_kernel<CH, 13><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
-        case 15: gauss_blur_fast_kernel<CH, 15><<<grid, kBlock, 0, s>>>(in, out, h, w, kq); return true;
+        case 3: gauss_blur_fast_kernel<CH, 3><<<grid, kBlock, 0, s>>>(in, out, h, w, kq, n); return true;
+        case 5: gauss_blur_fast_kernel<CH, 5><<<grid, kBlock, 0, s>>>(in, out, h, w, kq, n); return true;
+        case 7: gauss_blur_fast_kernel<CH, 7><<<grid, kBlock, 0, s>>>(in, out, h, w, kq, n); return true;
+        case 9: gauss_blur_fast_kernel<CH, 9><<<grid, kBlock, 0, s>>>(in, out, h, w, kq, n); return true;
+        case 11: gauss_blur_fast_kernel<CH, 11><<<grid, kBlock, 0, s>>>(in, out, h, w, kq, n); return true;
+        case 13: gauss_blur_fast_kernel<CH, 13><<<grid, kBlock, 0, s>>>(in, out, h, w, kq, n); return true;
+        case 15: gauss_blur_fast_kernel<CH, 15><<<grid, kBlock, 0, s>>>(in, out, h, w, kq, n); return true;
         default: return false;
     }
 }

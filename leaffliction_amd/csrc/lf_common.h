@@ -54,7 +54,31 @@ inline bool streaming(size_t bytes_touched) { return bytes_touched >= ((size_t)2
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Tile kernels whose neighbouring tiles share input halos: workgroups are dealt to the eight XCDs
+// round-robin in dispatch order and every XCD has its own L2, so a plain (tile_x, tile_y, image)
+// grid puts horizontally adjacent tiles under different L2s and every halo line is fetched from
+// HBM once per XCD that touches it.  These kernels launch a 1-D grid of 8*ceil(total/8) workgroups
+// and give XCD k the k-th contiguous eighth of the tiles (x fastest, then y, then image).
+inline unsigned xcd_grid(size_t total_tiles) { return (unsigned)(8 * ((total_tiles + 7) / 8)); }
+
 #if defined(__HIPCC__)
+struct TileId {
+    int tx, ty, n;
+    bool ok;
+};
+__device__ __forceinline__ TileId xcd_tile(int tiles_x, int tiles_y, int n_images) {
+    const unsigned per_image = (unsigned)(tiles_x * tiles_y), total = per_image * (unsigned)n_images;
+    const unsigned per_xcd = (total + 7) / 8, b = blockIdx.x;
+    const unsigned id = (b & 7u) * per_xcd + (b >> 3);
+    TileId t;
+    t.ok = id < total;
+    t.n = (int)(id / per_image);
+    const unsigned rem = id - (unsigned)t.n * per_image;
+    t.ty = (int)(rem / (unsigned)tiles_x);
+    t.tx = (int)(rem - (unsigned)t.ty * (unsigned)tiles_x);
+    return t;
+}
+
 template <bool NT, typename T>
 __device__ __forceinline__ T ldg(const T* p) {
     return NT ? __builtin_nontemporal_load(p) : *p;

@@ -155,19 +155,21 @@ constexpr int kTX = 32, kTY = 32, kTileRows = 48;
 __global__ __launch_bounds__(kBlock) void warp_bicubic_tile_kernel(const uint8_t* __restrict__ in,
                                                                    uint8_t* __restrict__ out,
                                                                    const double* __restrict__ coeffs,
-                                                                   int perspective, int h, int w) {
+                                                                   int perspective, int h, int w, int n_images) {
     __shared__ double Hs[kTileRows][kTX][3];
     __shared__ double sdx[kTX], sdy[kTY];
     __shared__ int sx[kTX], sy[kTY];
     __shared__ int svx[kTX], svy[kTY];
     __shared__ int srange[2];
-    const unsigned n = blockIdx.z;
+    const lf::TileId tile = lf::xcd_tile((w + kTX - 1) / kTX, (h + kTY - 1) / kTY, n_images);
+    if (!tile.ok) return;
+    const unsigned n = (unsigned)tile.n;
     const double* a = coeffs + (size_t)n * 8;
     const bool divide = perspective && !(a[6] == 0.0 && a[7] == 0.0);
     const bool axis = !divide && a[1] == 0.0 && a[3] == 0.0;
     const uint8_t* src = in + (size_t)n * h * w * 3;
     uint8_t* dst = out + (size_t)n * h * w * 3;
-    const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
+    const int x0 = tile.tx * kTX, y0 = tile.ty * kTY;
     const int tid = threadIdx.x;
     if (axis) {
         if (tid < kTX) {  // per output column: source column, dx, inside?
@@ -517,13 +519,15 @@ __global__ __launch_bounds__(kBlock) void resample_tile_kernel(const uint8_t* __
                                                                const int32_t* __restrict__ xkk, int kx,
                                                                const int32_t* __restrict__ ybounds,
                                                                const int32_t* __restrict__ ykk, int ky,
-                                                               int per_image) {
+                                                               int per_image, int n_images) {
     __shared__ uint32_t win[(kRWin * kRPitch + 40) / 4];
     __shared__ uint32_t tmpw[(kRWin + kRTaps) * kRT * 3 / 4];  // + rows that only zero taps reach
     __shared__ int kxs[kRT][kRTaps], kys[kRT][kRTaps];
     __shared__ int xmn[kRT], xct[kRT], ymn[kRT], yct[kRT], rsh[kRWin];
-    const unsigned n = blockIdx.z;
-    const int ox0 = blockIdx.x * kRT, oy0 = blockIdx.y * kRT;
+    const lf::TileId tile = lf::xcd_tile((ow + kRT - 1) / kRT, (oh + kRT - 1) / kRT, n_images);
+    if (!tile.ok) return;
+    const unsigned n = (unsigned)tile.n;
+    const int ox0 = tile.tx * kRT, oy0 = tile.ty * kRT;
     const int cols = min(kRT, ow - ox0), rows = min(kRT, oh - oy0);
     const int tid = threadIdx.x;
     if (tid < 2 * kRT) {  // tables of this tile's columns (threads 0..31) and rows (32..63)
@@ -630,9 +634,8 @@ int lf_warp_bicubic_u8(const uint8_t* in, uint8_t* out, const double* coeffs, in
     LF_REQUIRE(in != out, "lf_warp_bicubic: in-place warp is not supported");
     const int persp = perspective & 1;
     if (perspective & 2) {  // caller's hint: the maps are axis-aligned scales (verified per image)
-        LF_REQUIRE(n <= 65535, "lf_warp_bicubic: batch too large for grid.z");
-        dim3 grid((w + kTX - 1) / kTX, (h + kTY - 1) / kTY, n);
-        warp_bicubic_tile_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, coeffs, persp, h, w);
+        const unsigned grid = lf::xcd_grid((size_t)((w + kTX - 1) / kTX) * ((h + kTY - 1) / kTY) * n);
+        warp_bicubic_tile_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, coeffs, persp, h, w, n);
     } else {
         dim3 grid(lf::stream_grid((size_t)h * w, kBlock, 1024), n);
         warp_bicubic_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, coeffs, persp, h, w);
@@ -668,13 +671,13 @@ int lf_resample_tile_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, in
     LF_REQUIRE((size_t)h * w * 3 + 3 < ((size_t)1 << 31), "lf_resample_tile: image too large");
     LF_REQUIRE(n <= 65535, "lf_resample_tile: batch too large for grid.z");
     LF_REQUIRE(in != out, "lf_resample_tile: in-place resample is not supported");
-    dim3 grid((ow + kRT - 1) / kRT, (oh + kRT - 1) / kRT, n);
+    const unsigned grid = lf::xcd_grid((size_t)((ow + kRT - 1) / kRT) * ((oh + kRT - 1) / kRT) * n);
     if (kx <= 8 && ky <= 8)
-        resample_tile_kernel<8><<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, h, w, oh, ow, xbounds, xk,
-                                                                           kx, ybounds, yk, ky, per_image_coeffs);
+        resample_tile_kernel<8><<<grid, kBlock, 0, lf::as_stream(stream)>>>(
+            in, out, h, w, oh, ow, xbounds, xk, kx, ybounds, yk, ky, per_image_coeffs, n);
     else
-        resample_tile_kernel<10><<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, h, w, oh, ow, xbounds, xk,
-                                                                            kx, ybounds, yk, ky, per_image_coeffs);
+        resample_tile_kernel<10><<<grid, kBlock, 0, lf::as_stream(stream)>>>(
+            in, out, h, w, oh, ow, xbounds, xk, kx, ybounds, yk, ky, per_image_coeffs, n);
     return lf::check_launch("lf_resample_tile");
 }
 
