@@ -144,10 +144,19 @@ void conv_mfma_kernel(ConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wave_co = wid % WCO, wave_px = wid / WCO;
-    const int tile = blockIdx.x;
+    // XCD-aware order: workgroups are dealt to the eight XCDs round-robin in dispatch order (x, then
+    // y, then z), each XCD with its own L2.  XCD k takes the k-th contiguous share of the
+    // (tile, channel group, strip) space, so the tiles that share halo rows meet in one L2.
+    const unsigned gxy = gridDim.x * gridDim.y, gtotal = gxy * gridDim.z;
+    const unsigned bflat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xk = bflat & 7u, xfloor = gtotal >> 3, xrem = gtotal & 7u;
+    const unsigned wid_flat = xk * xfloor + (xk < xrem ? xk : xrem) + (bflat >> 3);
+    const int bz = (int)(wid_flat / gxy);
+    const int by = (int)((wid_flat - (unsigned)bz * gxy) / gridDim.x);
+    const int tile = (int)(wid_flat - (unsigned)bz * gxy - (unsigned)by * gridDim.x);
     const int tx0 = (tile % p.tiles_x) * TW, ty0 = (tile / p.tiles_x) * TH;
-    const int co0 = blockIdx.y * CT;
-    const int n = blockIdx.z * p.stack;  // first image of this workgroup's strip
+    const int co0 = by * CT;
+    const int n = bz * p.stack;  // first image of this workgroup's strip
     const size_t hw = (size_t)p.h * p.wd;
     const unsigned uhw = (unsigned)hw;
     const float* xin = p.x + ((LF_ABLATE & 2) ? (size_t)0 : (size_t)n * p.cin * hw);
@@ -482,7 +491,7 @@ void conv_mfma_kernel(ConvArgs p) {
     }
     if (stats) {
         __syncthreads();
-        const long long tg = (long long)blockIdx.z * (p.tiles_x * p.tiles_y) + tile;
+        const long long tg = (long long)bz * (p.tiles_x * p.tiles_y) + tile;
         for (int c = tid; c < CT; c += kThreads) {
             if (co0 + c >= p.cout) continue;
             float a = 0.f, b = 0.f;
