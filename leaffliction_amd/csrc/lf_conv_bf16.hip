@@ -61,11 +61,19 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     __shared__ uint32_t patch[8][PH][kPW];
     __shared__ lf::u32x4 wl[TAPS * NCO * 32 * 2];
     __shared__ float eps[2][NCO * 32];  // epilogue scale / shift of this workgroup's output channels
+    // XCD-aware order (see lf_conv.hip): XCD k walks the k-th contiguous share of the
+    // (tile, channel group, image) space, so tiles that share halo rows meet in one L2
+    const unsigned gxy = gridDim.x * gridDim.y, gtotal = gxy * gridDim.z;
+    const unsigned bflat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xk = bflat & 7u, xfloor = gtotal >> 3, xrem = gtotal & 7u;
+    const unsigned wflat = xk * xfloor + (xk < xrem ? xk : xrem) + (bflat >> 3);
+    const int n = (int)(wflat / gxy);
+    const int cog = (int)((wflat - (unsigned)n * gxy) / gridDim.x);
+    const int tile = (int)(wflat - (unsigned)n * gxy - (unsigned)cog * gridDim.x);
     const int tiles_x = (p.w + kTW - 1) / kTW;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int x0 = tx * kTW, y0 = ty * kTH;
-    const int co0 = blockIdx.y * (NCO * 32);
-    const int n = blockIdx.z;
+    const int co0 = cog * (NCO * 32);
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, px = lane & 31, half = lane >> 5;
     const size_t hw = (size_t)p.h * p.w;
     const float* xn = static_cast<const float*>(p.x) + (XBF ? 0 : (size_t)n * p.cin * hw);
