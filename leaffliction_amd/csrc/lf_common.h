@@ -79,6 +79,22 @@ __device__ __forceinline__ TileId xcd_tile(int tiles_x, int tiles_y, int n_image
     return t;
 }
 
+// The same for kernels on a (blocks, images) grid whose neighbouring blocks read neighbouring
+// source lines (gathers along rotated / sheared rows): the block a workgroup should act as.
+struct Block2 {
+    unsigned x, y;
+};
+__device__ __forceinline__ Block2 xcd_block2() {
+    const unsigned gx = gridDim.x, total = gx * gridDim.y;
+    const unsigned b = blockIdx.x + gx * blockIdx.y;
+    const unsigned k = b & 7u, fl = total >> 3, rm = total & 7u;
+    const unsigned id = k * fl + (k < rm ? k : rm) + (b >> 3);
+    Block2 r;
+    r.y = id / gx;
+    r.x = id - r.y * gx;
+    return r;
+}
+
 template <bool NT, typename T>
 __device__ __forceinline__ T ldg(const T* p) {
     return NT ? __builtin_nontemporal_load(p) : *p;

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(kBlock) void affine_nearest_kernel(const uint8_t* _
     // output: every pixel is computed once, the row/column split costs one integer division
     // per group (the following pixels step along the row), stores are whole dwords.
     // out_off[n] is 16-byte aligned and each image's region is padded to 16 bytes.
-    const unsigned n = blockIdx.y;
+    const lf::Block2 blk = lf::xcd_block2();  // consecutive blocks of an image under one L2
+    const unsigned n = blk.y;
     const int32_t* a = fix6 + (size_t)n * 6;
     const unsigned a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
     const int oh = ohw[2 * n], ow = ohw[2 * n + 1];
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void affine_nearest_kernel(const uint8_t* _
     // pixel index is exact in float32 (an integer division is a long multiply-and-correct sequence)
     const bool small = total < (1 << 22);  // quotient error <= 2^22 * 1.2e-7 < 1: at most one step off
     const float inv_ow = 1.0f / (float)ow;
-    for (int g = blockIdx.x * kBlock + threadIdx.x; g < ng; g += gridDim.x * kBlock) {
+    for (int g = blk.x * kBlock + threadIdx.x; g < ng; g += gridDim.x * kBlock) {
         const int p0 = 4 * g;
         unsigned oy, ox;
         if (small) {
