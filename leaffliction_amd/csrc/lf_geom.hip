@@ -132,13 +132,15 @@ __global__ __launch_bounds__(kBlock) void warp_bicubic_kernel(const uint8_t* __r
                                                               uint8_t* __restrict__ out,
                                                               const double* __restrict__ coeffs,
                                                               int perspective, int h, int w) {
-    const unsigned n = blockIdx.y;
+    // plain block order: the XCD-aware order that helps the nearest-neighbour rotate measured 2 %
+    // slower here (this kernel is bound by its double-precision arithmetic)
+    const unsigned n = blockIdx.y, bx = blockIdx.x;
     const double* a = coeffs + (size_t)n * 8;
     const bool divide = perspective && !(a[6] == 0.0 && a[7] == 0.0);
     const uint8_t* src = in + (size_t)n * h * w * 3;
     uint8_t* dst = out + (size_t)n * h * w * 3;
     const int total = h * w;
-    for (int t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
+    for (int t = bx * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
         const int oy = t / w, ox = t - oy * w;
         warp_pixel(src, dst + (size_t)t * 3, a, divide, h, w, ox, oy);
     }
@@ -553,7 +555,6 @@ __global__ __launch_bounds__(kBlock) void resample_tile_kernel(const uint8_t* __
     __syncthreads();
     // windows start at the first column / row's start (the starts grow with the output index)
     const int xlo = xmn[0], ylo = ymn[0];
-    const int wx = min(kRWin, min(w, xmn[cols - 1] + xct[cols - 1]) - xlo);
     const int wy = min(kRWin, min(h, ymn[rows - 1] + yct[rows - 1]) - ylo);
     const size_t img_bytes = (size_t)h * w * 3;
     const uint8_t* img = in + (size_t)n * img_bytes;
