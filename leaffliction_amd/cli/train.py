@@ -126,6 +126,9 @@ def build_and_compile_model(args, cfg: Dict, num_classes: int, train_seq: Any, d
         full.indexes = list(train_seq.indexes)
         adapt_normalization(norm_layer, full)
     dp.broadcast_(model.flat_p, 0)
+    if dp.active:
+        # same initial weights everywhere; independent dropout / in-model augmentation draws per shard
+        model.reseed_step_rng(args.seed + dp.rank)
     steps_per_epoch = len(train_seq)
     base_lr = CosineDecay(cfg["lr"], steps_per_epoch * args.epochs) if cfg["cosine_decay"] else cfg["lr"]
     model.compile(optimizer=build_optimizer(cfg, base_lr), loss=build_loss(cfg), metrics=["accuracy"])

@@ -542,32 +542,61 @@ class LeafCNN:
         top = host[-1].to(self.device) if self.drop_top > 0 else None
         return drops, top
 
-    def train_step(self, x, y_true: torch.Tensor, lr: float, *, weight_decay: float = 1e-4,
+    def train_step(self, x, y_true: Optional[torch.Tensor], lr: float, *, weight_decay: float = 1e-4,
                    clipnorm: float = 0.5, ema_decay: float = 0.999, adamw: bool = True,
                    grad_sync=None, global_n: Optional[int] = None):
         """One optimisation step on a batch.  y_true: f32 [N,C] (already label-smoothed).
         grad_sync(flat_g) is called between backward and the optimizer (data-parallel
         all-reduce); with global_n the local gradient is scaled by 1/global_n so that a SUM
         all-reduce yields the global-batch mean.  Returns (probs, per-sample loss) device
-        tensors (no host sync)."""
-        n = x.shape[0]
+        tensors (no host sync).
+
+        An EMPTY local batch (a data-parallel rank whose rank-strided slice of a ragged last
+        global batch holds nothing) still takes the step: it contributes a zero gradient to the
+        all-reduce and advances `opt_step`, Adam moments, weights and EMA exactly like its peers,
+        so every rank issues the same collectives and the replicas stay bit-equal.  Returns
+        (None, None) in that case."""
+        n = int(x.shape[0])
         self._global_n = global_n
+        if n == 0:
+            self.flat_g.zero_()
+            probs = loss = None
+        else:
+            probs, loss = self._forward_backward(x, y_true)
+        if grad_sync is not None:
+            grad_sync(self.flat_g)
+        self.opt_step += 1
+        self._optimizer_update(lr, weight_decay=weight_decay if adamw else 0.0, clipnorm=clipnorm,
+                               ema_decay=ema_decay)
+        return probs, loss
+
+    def _forward_backward(self, x, y_true: torch.Tensor):
+        """Forward + backward of one local batch: fills flat_g, returns (probs, loss)."""
+        n = int(x.shape[0])
         drops, top, aug4 = self.draw_step_randoms(n, self.augment)
         x0 = self._input(x, True, aug4)
         probs, loss = self.forward(x0, True, y_true, drops, top)
         self.backward()
-        if grad_sync is not None:
-            grad_sync(self.flat_g)
-        self.opt_step += 1
+        return probs, loss
+
+    def _optimizer_update(self, lr: float, *, weight_decay: float, clipnorm: float,
+                          ema_decay: float) -> None:
         nn.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v,
                       self.flat_ema if ema_decay > 0 else None, self.offsets, self.l2_vec,
-                      self.max_count, lr, self.opt_step,
-                      weight_decay=weight_decay if adamw else 0.0, clipnorm=clipnorm,
-                      ema_decay=ema_decay, ema_copy=not self.ema_started, norms=self.norms_ws)
+                      self.max_count, lr, self.opt_step, weight_decay=weight_decay,
+                      clipnorm=clipnorm, ema_decay=ema_decay, ema_copy=not self.ema_started,
+                      norms=self.norms_ws)
         if ema_decay > 0:
             nn.ema_update(self.flat_s_ema, self.flat_s, ema_decay, not self.ema_started)
             self.ema_started = True
-        return probs, loss
+
+    def reseed_step_rng(self, seed: int) -> None:
+        """Re-seed the per-step generators (SpatialDropout2D / Dropout masks, in-model
+        augmentation draws).  Data-parallel ranks call this with seed + rank AFTER the weight
+        broadcast: initial weights stay identical, the regularisation noise is independent
+        across the shards of a global batch."""
+        self.gen = torch.Generator(device="cpu").manual_seed(int(seed))
+        self.np_rng = np.random.RandomState(int(seed) & 0x7FFFFFFF)
 
     def l2_penalty(self) -> torch.Tensor:
         tot = torch.zeros((), dtype=torch.float32, device=self.device)
@@ -586,7 +615,9 @@ class LeafCNN:
         """labels (one-hot [B,C] or sparse [B]) -> (smoothed one-hot f32 on device, indices)."""
         if not isinstance(by, torch.Tensor):
             # pinned staging + asynchronous copy: a pageable upload would drain the stream
-            by = torch.as_tensor(np.ascontiguousarray(by)).pin_memory()
+            by = torch.as_tensor(np.ascontiguousarray(by))
+            if self.device.type == "cuda":
+                by = by.pin_memory()
         by = by.to(self.device, non_blocking=True)
         if by.dim() == 1:
             idx = by.long()
@@ -624,20 +655,24 @@ class LeafCNN:
             seen = 0
             for bi in order:
                 bx, by = train_seq[bi]
-                if bx.shape[0] == 0:
+                n_local = int(bx.shape[0])
+                dp_on = dp is not None and dp.active
+                if n_local == 0 and not dp_on:
                     continue
-                yt, idx = self._targets(by)
+                # data-parallel: a rank with an empty slice of a ragged last global batch still
+                # steps (zero gradient), or its peers would wait in the all-reduce forever
+                yt, idx = self._targets(by) if n_local else (None, None)
                 lr = opt["schedule"](self.opt_step) if "schedule" in opt else opt.get("lr", 1e-3)
-                gn = train_seq.global_batch_size(bi) if dp is not None and dp.active else None
+                gn = train_seq.global_batch_size(bi) if dp_on else None
                 probs, loss = self.train_step(
                     bx, yt, lr, weight_decay=opt.get("weight_decay", 0.0),
                     clipnorm=opt.get("clipnorm", 0.0), ema_decay=opt.get("ema_decay", 0.0),
                     adamw=opt.get("name", "adamw") == "adamw",
-                    grad_sync=dp.allreduce_grads if dp is not None and dp.active else None,
-                    global_n=gn)
-                acc_loss += loss.sum()
-                acc_correct += (probs.argmax(-1) == idx).sum()
-                seen += int(bx.shape[0])
+                    grad_sync=dp.allreduce_grads if dp_on else None, global_n=gn)
+                if n_local:
+                    acc_loss += loss.sum()
+                    acc_correct += (probs.argmax(-1) == idx).sum()
+                    seen += n_local
                 for cb in callbacks:
                     cb.on_train_batch_end(bi)
             tl, tc, tn = float(acc_loss), float(acc_correct), float(seen)
@@ -809,18 +844,38 @@ class LeafCNN:
 
 
 def load_model(path) -> LeafCNN:
-    """Counterpart of keras.models.load_model for files written by LeafCNN.save."""
+    """Counterpart of keras.models.load_model for files written by LeafCNN.save.  A Keras-written
+    `.keras` archive holds model.weights.h5 (HDF5; this image has no h5py) and is refused with a
+    ValueError that says so — as is anything else that is not this package's npz archive."""
     import io
+    path = Path(path)
+    if not zipfile.is_zipfile(path):
+        raise ValueError(f"{path}: not a .keras zip archive (legacy HDF5 / SavedModel files are not supported)")
     with zipfile.ZipFile(path) as z:
+        members = set(z.namelist())
+        if "model.weights.npz" not in members:
+            if "model.weights.h5" in members:
+                raise ValueError(f"{path}: Keras-written .keras archive (model.weights.h5, HDF5): not "
+                                 "readable here — this backend stores model.weights.npz; retrain or "
+                                 "convert with weight_names()/set_weights() (INTEGRATION.md)")
+            raise ValueError(f"{path}: unsupported .keras archive: expected model.weights.npz or "
+                             f"model.weights.h5, found {sorted(members)}")
+        for need in ("config.json", "metadata.json"):
+            if need not in members:
+                raise ValueError(f"{path}: unsupported .keras archive: {need} is missing")
         cfg = json.loads(z.read("config.json"))["config"]
         data = np.load(io.BytesIO(z.read("model.weights.npz")))
         meta = json.loads(z.read("metadata.json"))
+    if meta.get("weights_format") != "npz" or "weight_names" not in meta:
+        raise ValueError(f"{path}: metadata.json does not describe a leaffliction_amd npz archive "
+                         f"(weights_format={meta.get('weights_format')!r})")
     model = LeafCNN(num_classes=cfg["num_classes"], img_size=cfg["img_size"],
                     use_norm=cfg["use_norm"], widths=cfg["widths"], drop_block=cfg["drop_block"],
                     drop_top=cfg["drop_top"], l2_reg=cfg["l2_reg"], augment=cfg["augment"],
                     use_se=cfg["use_se"])
     keys = sorted(data.files)
-    assert [k.split(":", 1)[1] for k in keys] == meta["weight_names"]
+    if [k.split(":", 1)[1] for k in keys] != meta["weight_names"]:
+        raise ValueError(f"{path}: model.weights.npz does not hold the tensors metadata.json lists")
     model.set_weights([data[k] for k in keys])
     return model
 

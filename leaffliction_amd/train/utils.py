@@ -109,28 +109,48 @@ class ReduceLROnPlateau(Callback):
 
 
 class EarlyStopping(Callback):
-    """keras EarlyStopping(patience=6, restore_best_weights=True) on val_loss."""
+    """keras.callbacks.EarlyStopping(monitor="val_loss", patience=6, restore_best_weights=True)
+    with Keras 3's bookkeeping (the reference pins keras>=3; utils.py:65): the first monitored
+    epoch seeds `best_weights`; `wait` counts every epoch and is reset by an improvement; the
+    stop is only raised after epoch 0; and the best weights are put back in `on_train_end`
+    whenever they exist — also when training ran through all its epochs without stopping, so
+    the "base" variant `save_best_variant` evaluates is the best-val_loss one, as in Keras."""
 
     def __init__(self, patience: int = 6, restore_best_weights: bool = True) -> None:
         self.patience, self.restore = patience, restore_best_weights
+        self.on_train_begin()
+
+    def on_train_begin(self) -> None:
         self.best, self.wait, self.best_weights = math.inf, 0, None
+        self.best_epoch, self.stopped_epoch = 0, 0
+
+    def _snapshot(self):
+        return (self.model.flat_p.clone(), self.model.flat_s.clone())
 
     def on_epoch_end(self, epoch, logs=None) -> None:
         cur = (logs or {}).get("val_loss")
         if cur is None:
             return
-        if cur < self.best:
-            self.best, self.wait = cur, 0
-            if self.restore:
-                self.best_weights = (self.model.flat_p.clone(), self.model.flat_s.clone())
-            return
+        if self.restore and self.best_weights is None:
+            self.best_weights, self.best_epoch = self._snapshot(), epoch
         self.wait += 1
-        if self.wait >= self.patience:
+        if cur < self.best:
+            self.best, self.best_epoch, self.wait = cur, epoch, 0
+            if self.restore:
+                self.best_weights = self._snapshot()
+            return
+        if self.wait >= self.patience and epoch > 0:
+            self.stopped_epoch = epoch
             self.model.stop_training = True
-            if self.restore and self.best_weights is not None:
-                LOGGER.info("EarlyStopping: restoring best weights")
-                self.model.flat_p.copy_(self.best_weights[0])
-                self.model.flat_s.copy_(self.best_weights[1])
+
+    def on_train_end(self) -> None:
+        if self.stopped_epoch > 0:
+            LOGGER.info("EarlyStopping: stopped at epoch %d", self.stopped_epoch + 1)
+        if self.restore and self.best_weights is not None:
+            LOGGER.info("EarlyStopping: restoring the weights of epoch %d (best val_loss)",
+                        self.best_epoch + 1)
+            self.model.flat_p.copy_(self.best_weights[0])
+            self.model.flat_s.copy_(self.best_weights[1])
 
 
 class StopOnValAcc(Callback):
