@@ -16,6 +16,7 @@ from ..preprocessing.dataset_balancer import DatasetBalancer
 from ..preprocessing.image_augmenter import ImageAugmenter
 from ..utils.common import get_logger, setup_logging
 from ..utils.distribution import count_images, merge_csv
+from ..utils.ranks import init_from_env
 
 logger = get_logger(__name__)
 
@@ -79,9 +80,14 @@ def dataset_mode_dir(args, source_dir: Path) -> None:
     target_dir = Path(args.output) if args.output else Path(DEFAULT_DATASET_OUTPUT)
     if not source_dir.exists():
         raise InputValidationError(f"Source directory not found: {source_dir}")
+    # under `python -m torch.distributed.run --nproc-per-node N` the task list is cut into one
+    # contiguous share per GPU (no exchange step); a plain run is one process, one GPU
+    rk = init_from_env()
     DatasetBalancer(source_dir=str(source_dir), target_dir=str(target_dir), seed=args.seed,
                     workers=args.workers).run()
     logger.info("Dataset augmentation completed successfully")
+    if rk.rank != 0:
+        return
     try:
         analyze_distribution(target_dir)
     except Exception as e:  # noqa: BLE001

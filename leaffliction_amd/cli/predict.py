@@ -19,6 +19,7 @@ from ..predict.evaluation import PredictionEvaluator
 from ..predict.predictor import Predictor
 from ..utils.common import get_logger, setup_logging
 from ..utils.image_utils import ImageLoader
+from ..utils.ranks import init_from_env
 
 logger = get_logger(__name__)
 
@@ -114,13 +115,17 @@ def _load_manifest_items(manifest_path, split):
 
 def run_sampling_enforced_batch(predictor, image_dir: Path, manifest_path: Path, split: str,
                                 sample_size: int, target_acc: float, max_attempts: int,
-                                json_output: Optional[str]) -> bool:
-    """predict.py:305-388: sample, predict, emit outputs only once accuracy >= target."""
+                                json_output: Optional[str], ranks=None) -> bool:
+    """predict.py:305-388: sample, predict, emit outputs only once accuracy >= target.  With
+    replicas (`ranks`), rank 0's wall-clock sample seed is shared, every replica predicts its
+    contiguous share of the sample, and rank 0 alone writes the outputs."""
+    from ..utils import ranks as R
+    rk = ranks or R.Solo()
     best = 0.0
     for attempt in range(1, int(max_attempts) + 1):
         logger.info("Sampling attempt %d/%d (n=%d)", attempt, int(max_attempts), int(sample_size))
         items = _load_manifest_items(manifest_path, split)
-        rng = _random.Random(int(time.time()) % 1_000_000)
+        rng = _random.Random(rk.broadcast_object(int(time.time()) % 1_000_000))
         sampled = rng.sample(items, min(int(sample_size), len(items))) if items else []
         paths, labels = [], []
         for it in sampled:
@@ -132,11 +137,13 @@ def run_sampling_enforced_batch(predictor, image_dir: Path, manifest_path: Path,
             logger.warning("Sampling produced no valid images; retrying...")
             continue
         t0 = time.time()
-        results = predictor.predict_batch(paths)
+        results = predictor.predict_batch_sharded(paths, rk)
         proc = time.time() - t0
         acc = sum(r.get("top_prediction") == t for r, t in zip(results, labels)) / max(len(results), 1)
         logger.info("Sample accuracy: %.4f on %d images", acc, len(results))
         if acc >= float(target_acc):
+            if rk.rank != 0:
+                return True
             if json_output:
                 logger.info("Results saved to: %s", save_batch_results_json(results, proc, json_output))
             try:
@@ -157,13 +164,15 @@ def main(argv=None) -> None:
     try:
         args = parse_args(argv)
         image_path, learnings_dir = validate_inputs(args)
+        rk = init_from_env()   # replicas under torch.distributed.run; one process otherwise
         predictor = Predictor(learnings_dir)
         predictor.load()
         if args.batch_mode:
             if args.evaluate:
-                if not run_sampling_enforced_batch(predictor, image_path, Path(args.manifest), args.split,
-                                                   args.sample_size, args.target_acc,
-                                                   args.max_attempts, args.json_output):
+                ok = run_sampling_enforced_batch(predictor, image_path, Path(args.manifest), args.split,
+                                                 args.sample_size, args.target_acc,
+                                                 args.max_attempts, args.json_output, ranks=rk)
+                if not ok:
                     sys.exit(2)
                 return
             files = ImageLoader.get_image_files(image_path)
@@ -171,8 +180,10 @@ def main(argv=None) -> None:
                 logger.warning(f"No image files found in {image_path}")
                 return
             t0 = time.time()
-            results = predictor.predict_batch(files)
+            results = predictor.predict_batch_sharded(files, rk)
             proc = time.time() - t0
+            if rk.rank != 0:
+                return
             out = save_batch_results_json(results, proc, args.json_output)
             logger.info("Results saved to: %s", out)
             for k, v in create_batch_summary(results, proc).items():

@@ -62,3 +62,27 @@ def evaluate_from_manifest(predictor, manifest_path: Path, split: str = "test",
         return {}
     return PredictionEvaluator(predictor).evaluate_predictions(
         [Path(it["src"]) for it in sel], [it.get("label", it["class"]) for it in sel], output_dir)
+
+
+def sharded_confusion_counts(predictor, image_paths: List[Path], true_labels: List[str], ranks=None):
+    """Integer confusion counts `cm[true][pred]` over a file list cut into one contiguous share
+    per GPU replica: every replica predicts its share, counts locally, and the counts are SUMMED
+    over ranks (integers: exact, order-independent) — SURVEY §8e, BASELINE configs[4].  Returns
+    the full matrix (list of lists) on every rank; unknown labels are skipped like
+    `evaluate_predictions` does."""
+    from ..utils import ranks as R
+    rk = ranks or R.current()
+    labels = predictor.model_loader.labels
+    index = {lab: i for i, lab in enumerate(labels)}
+    c = len(labels)
+    b, e = R.contiguous_share(len(image_paths), rk.rank, rk.world)
+    counts = [0] * (c * c)
+    if e > b:
+        preds = predictor.predict_batch([Path(p) for p in image_paths[b:e]])
+        by_path = {str(r["image_path"]): r["top_prediction"] for r in preds}
+        for p, t in zip(image_paths[b:e], true_labels[b:e]):
+            pr = by_path.get(str(Path(p)))
+            if pr in index and t in index:
+                counts[index[t] * c + index[pr]] += 1
+    total = rk.sum_ints(counts)
+    return [total[i * c:(i + 1) * c] for i in range(c)]

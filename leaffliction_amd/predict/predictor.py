@@ -76,3 +76,18 @@ class Predictor:
             return []
         probs = self.model_loader.model.predict(self._prepare([a for _p, a in loaded]))
         return [self._result(p, a, probs[i]) for i, (p, a) in enumerate(loaded)]
+
+    def predict_batch_sharded(self, image_paths, ranks=None) -> List[Dict[str, Any]]:
+        """`predict_batch` with the file list cut into one contiguous share per GPU replica
+        (SURVEY §8e "inference: replicas only"; reference call site predict.py:492).  Every
+        rank returns the full result list in input order; results that came from another rank
+        carry no pixel arrays (`original_array` / `processed_array` are None)."""
+        from ..utils import ranks as R
+        rk = ranks or R.current()
+        paths = [Path(p) for p in image_paths]
+        if not rk.active:
+            return self.predict_batch(paths)
+        b, e = R.contiguous_share(len(paths), rk.rank, rk.world)
+        mine = self.predict_batch(paths[b:e]) if e > b else []
+        slim = [{k: (None if k.endswith("_array") else v) for k, v in r.items()} for r in mine]
+        return rk.gather_in_order(slim)

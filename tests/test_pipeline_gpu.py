@@ -35,8 +35,8 @@ def test_balancer_outputs_match_reference_pixels(cuda, tmp_path, monkeypatch):
     src, dst = tmp_path / "images", tmp_path / "augmented"
     build_tree(src, gold["layout"], gold["size"], 500)
     bal = DatasetBalancer(source_dir=str(src), target_dir=str(dst), seed=gold["seed"], workers=2)
-    orig = bal._get_images_by_class
-    bal._get_images_by_class = lambda: {k: sorted(v) for k, v in orig().items()}
+    orig = bal._images_by_class
+    bal._images_by_class = lambda: {k: sorted(v) for k, v in orig().items()}
     bal.run()
     assert bal.completed == len(gold["tasks"]) and bal.failed == 0
     for t in gold["tasks"]:
