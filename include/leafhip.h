@@ -244,6 +244,77 @@ int lf_block_tail_fwd_bf16(const uint16_t* y, const float* a_scale, const float*
                            const float* sc_shift, int sc_relu, uint16_t* pooled, int n, int c, int h,
                            int w, lf_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* A2 — the mixed-precision TRAINING step (bf16 storage, fp32 arithmetic)      */
+/* ------------------------------------------------------------------------- */
+/* The reference trains under keras.mixed_precision.set_global_policy("mixed_float16") unless
+ * --no-mixed-precision is given (srcs/cli/train.py:179-190): layer outputs and gradients are
+ * 16-bit, variables, BatchNorm statistics, softmax / loss and the optimizer are fp32.  BASELINE
+ * configs[3] asks for that step in bf16.  Here: every activation / gradient tensor in HBM is bf16
+ * NCHW, every MFMA operand is bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulators), all other
+ * arithmetic is fp32, master weights / Adam state / BatchNorm state are fp32.  A value is rounded
+ * (nearest even) exactly where it is stored or staged as an operand, and every statistic a later
+ * kernel relies on is taken over the ROUNDED values.  Tolerance vs the fp32 step: bf16 operand
+ * rounding (2^-9 relative per element); vs oracle/cnn_ref.py evaluated with the same rounding
+ * points the tests bound each gradient tensor's error norm (tests/test_train_bf16_gpu.py).
+ *
+ * lf_conv2d_bf16_train: forward convolution (Conv2D, cnn.py:27-29) or input-gradient convolution
+ * (the same call on dY with lf_conv2d_dgrad_weights_f32 -> lf_conv2d_bf16_prep_weights) writing
+ * bf16; x is fp32 (x_bf16 = 0: the normalised network input) or bf16; optional prologue
+ * relu?(x*in_scale+in_shift) = the producer's BatchNorm(+ReLU) (cnn.py:30-31); accumulate != 0:
+ * y = bf16(conv + y) (residual gradient joins).  tile_part (may be null) receives per-(channel,
+ * tile) sums, tile < lf_conv2d_bf16_stats_tiles(n,h,w,cout), layout [cout][tiles][2]:
+ *   mask_y == null: BatchNormalization forward statistics {sum (y-pivot), sum (y-pivot)^2}
+ *     (feed lf_bn_train_stats_tiles_f32; pivot = the moving mean, may be null);
+ *   mask_y != null: the backward sums of the BatchNorm this gradient feeds, {sum d, sum d*mask_y}
+ *     with d = y*[mask_y*mask_scale+mask_shift > 0 or !mask_relu] (feed lf_bn_bwd_sums_tiles_f32).
+ * Requires w % 4 == 0, cout % 32 == 0, ksize 1 or 3, 16-byte aligned x / wprep. */
+long long lf_conv2d_bf16_stats_tiles(int n, int h, int w, int cout);
+int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint16_t* y, int n, int cin,
+                         int h, int w, int cout, int ksize, const float* in_scale,
+                         const float* in_shift, int in_relu, int accumulate, float* tile_part,
+                         size_t tile_part_bytes, const float* pivot, const uint16_t* mask_y,
+                         const float* mask_scale, const float* mask_shift, int mask_relu,
+                         lf_stream_t stream);
+
+/* Conv2D weight gradient dw[cin][k*k][cout] (fp32, overwritten) from bf16 tensors, K = pixels on
+ * the bf16 MFMA with fp32 partial slabs summed in a fixed order (deterministic).  x: the conv's
+ * input as stored (bf16; fp32 when cin*9 <= 32, the stem) with the optional prologue
+ * relu?(x*in_scale+in_shift); g: dY itself, or — with bn_y — the gradient w.r.t. the output of the
+ * BatchNormalization(+ReLU) that follows the conv, in which case the BatchNorm backward is formed
+ * while staging exactly as lf_conv2d_wgrad_bn_f32 does (alpha_nc / add_nc [n][cout] optional,
+ * coef [5][cout] from lf_bn_bwd_sums*_f32) and dY is also written to dy_out (bf16, may be null)
+ * for the input-gradient convolution.  Requires w % 4 == 0, cout % 32 == 0, cin % 4 == 0 (or the
+ * stem), 8-byte aligned tensors.  workspace >= lf_conv2d_wgrad_bf16_workspace(...) bytes. */
+size_t lf_conv2d_wgrad_bf16_workspace(int n, int cin, int h, int w, int cout, int ksize);
+int lf_conv2d_wgrad_bf16(const void* x, const uint16_t* g, const uint16_t* bn_y, const float* alpha_nc,
+                         const float* add_nc, const float* coef, int bn_relu, uint16_t* dy_out,
+                         float* dw, int n, int cin, int h, int w, int cout, int ksize,
+                         const float* in_scale, const float* in_shift, int in_relu, void* workspace,
+                         size_t ws_bytes, lf_stream_t stream);
+
+/* The plane kernels of the training step on bf16 tensors — the arithmetic of lf_gap_f32 (with
+ * mask_sums), lf_block_tail_fwd_f32 (route bytes, SpatialDropout2D keep-scales),
+ * lf_block_tail_bwd_f32 and lf_bcast_planes_f32 (cnn.py:35-49,94-101), fp32 after widening;
+ * pooled / dr / out are rounded to bf16 where stored and the per-plane sums are over the rounded
+ * gradient.  hw % 4 == 0, w % 4 == 0, h even. */
+int lf_gap_stats_bf16(const uint16_t* x, float* out, float* mask_sums, int n, int c, int hw,
+                      const float* scale, const float* shift, int relu, lf_stream_t stream);
+int lf_block_tail_fwd_train_bf16(const uint16_t* y, const float* a_scale, const float* a_shift,
+                                 const float* s, const uint16_t* sc, const float* sc_scale,
+                                 const float* sc_shift, int sc_relu, const float* drop, uint8_t* route,
+                                 uint16_t* pooled, int n, int c, int h, int w, lf_stream_t stream);
+int lf_block_tail_bwd_bf16(const uint16_t* dp, const uint8_t* route, const uint16_t* y,
+                           const float* a_scale, const float* a_shift, const float* drop, uint16_t* dr,
+                           float* ds, float* plane_sums, const uint16_t* sc_y, float* sc_sums, int n,
+                           int c, int h, int w, lf_stream_t stream);
+int lf_bcast_planes_bf16(const float* v, uint16_t* out, int planes, int hw, float scale,
+                         lf_stream_t stream);
+/* fp32 <-> bf16 (round to nearest even) of a flat buffer: the data-parallel gradient bucket
+ * crosses xGMI as bf16 (2.5 MB instead of 5 MB). */
+int lf_cast_f32_bf16(const float* in, uint16_t* out, size_t count, lf_stream_t stream);
+int lf_cast_bf16_f32(const uint16_t* in, float* out, size_t count, lf_stream_t stream);
+
 /* Which tile variant (template instantiation) the dispatcher picks for a shape — used by
  * bench.py to attribute measured launch durations to kernel names.  (For H = 28 the 28x8
  * variant walks two images as one strip; lf_conv2d_stats_tiles accounts for that.) */

@@ -52,6 +52,18 @@ SIGNATURES = {
                            P, P, c_int, P],
     "lf_gap_bf16": [P, P, c_int, c_int, c_int, P, P, c_int, P],
     "lf_block_tail_fwd_bf16": [P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
+    "lf_conv2d_bf16_stats_tiles": [c_int, c_int, c_int, c_int],
+    "lf_conv2d_bf16_train": [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P,
+                             c_size_t, P, P, P, P, c_int, P],
+    "lf_conv2d_wgrad_bf16_workspace": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "lf_conv2d_wgrad_bf16": [P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P,
+                             c_int, P, c_size_t, P],
+    "lf_gap_stats_bf16": [P, P, P, c_int, c_int, c_int, P, P, c_int, P],
+    "lf_block_tail_fwd_train_bf16": [P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P],
+    "lf_block_tail_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "lf_bcast_planes_bf16": [P, P, c_int, c_int, c_float, P],
+    "lf_cast_f32_bf16": [P, P, c_size_t, P],
+    "lf_cast_bf16_f32": [P, P, c_size_t, P],
     "lf_conv2d_variant": [c_int, c_int, c_int, c_int],
     "lf_conv2d_wgrad_variant": [c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_stats_tiles": [c_int, c_int, c_int, c_int, c_int, c_int],
@@ -97,7 +109,8 @@ SIGNATURES = {
 _RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t,
              "lf_bn_workspace": c_size_t, "lf_se_bwd_workspace": c_size_t,
              "lf_adamw_workspace": c_size_t, "lf_conv2d_stats_tiles": C.c_longlong,
-             "lf_blur_saliency_workspace": c_size_t, "lf_conv2d_bf16_weight_elems": c_size_t}
+             "lf_blur_saliency_workspace": c_size_t, "lf_conv2d_bf16_weight_elems": c_size_t,
+             "lf_conv2d_bf16_stats_tiles": C.c_longlong, "lf_conv2d_wgrad_bf16_workspace": c_size_t}
 
 
 class LeafHipError(RuntimeError):

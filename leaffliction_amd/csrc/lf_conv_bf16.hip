@@ -38,7 +38,36 @@ struct Bf16ConvArgs {
     const float* out_scale;  // optional epilogue on the fp32 accumulators: v*out_scale[co]+out_shift[co],
     const float* out_shift;  // then ReLU if out_relu (inference: the layer's folded BatchNorm + ReLU)
     int out_relu;
+    // ---- training epilogue (template TR; the output is bf16 and what is summed is the ROUNDED
+    // value, i.e. exactly what later kernels read back):
+    int accumulate;            // y = bf16(conv + y_old) (input-gradient of a block with two consumers)
+    // per (output channel, workgroup tile) sums -> stat_part[(co * stat_tiles + tile) * 2 + {0,1}]:
+    //   stat_mask_y == null: BatchNorm FORWARD statistics {sum d, sum d*d}, d = y - stat_pivot[co];
+    //   else BatchNorm-BACKWARD sums of the BN this gradient feeds: d = y * [mask_y*mask_scale[co] +
+    //   mask_shift[co] > 0 or !mask_relu] -> {sum d, sum d*mask_y}
+    float* stat_part;
+    const float* stat_pivot;   // may be null (pivot 0)
+    long long stat_tiles;      // n * tiles per image
+    const uint16_t* stat_mask_y;
+    const float* mask_scale;
+    const float* mask_shift;
+    int mask_relu;
 };
+
+// sum over the 32 lanes of each wave half (DPP); the total lands in lane 31 / 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float half_sum32(float v) {
+    v += dpp_move<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_move<0x140, 0xf>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_move<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    return v;
+}
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -54,8 +83,9 @@ __device__ __forceinline__ uint16_t bf16_down(float v) { return __builtin_bit_ca
 
 // (three or four workgroups per CU would need <= 168 / 128 registers: the spills cost more than the
 // occupancy brings — 40.4 k and 24.5 k img/s against 47.3 k for the whole forward pass)
-template <int TAPS, int NCO, int NB, bool XBF, bool YBF>
+template <int TAPS, int NCO, int NB, bool XBF, bool YBF, bool TR = false>
 __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
+    static_assert(!TR || YBF, "the training epilogue stores bf16");
     constexpr int kTH = 4 * NB;
     constexpr int R = TAPS == 9 ? 1 : 0, PH = kTH + 2 * R, KS = TAPS == 9 ? 3 : 1;
     __shared__ uint32_t patch[8][PH][kPW];
@@ -243,25 +273,104 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     float* yn = static_cast<float*>(p.y) + (YBF ? 0 : (size_t)n * p.cout * hw);
     uint16_t* yb = static_cast<uint16_t*>(p.y) + (YBF ? (size_t)n * p.cout * hw : 0);
     const int gx = x0 + px;
+    if (!TR) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int gy = y0 + NB * wv + nb;
+            if (gy >= p.h || gx >= p.w) continue;
+#pragma unroll
+            for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = cb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    const int co = co0 + col;
+                    const size_t o = (size_t)co * hw + (size_t)gy * p.w + gx;
+                    float v = acc[nb][cb][r];
+                    if (p.out_scale) v = fmaf(v, eps[0][col], eps[1][col]);
+                    if (p.out_relu) v = fmaxf(v, 0.0f);
+                    if (YBF)
+                        yb[o] = bf16_down(v);
+                    else
+                        yn[o] = v;
+                }
+        }
+        return;
+    }
+    // ---- training: bf16 store (optionally on top of the old value) + per-tile channel sums of
+    // the rounded values
+    const bool stats = p.stat_part != nullptr, masked = p.stat_mask_y != nullptr;
+    const uint16_t* my = masked ? p.stat_mask_y + (size_t)n * p.cout * hw : nullptr;
+    float* red = reinterpret_cast<float*>(&patch[0][0][0]);  // [4 waves][NCO*32][2]
+    static_assert(4 * NCO * 32 * 2 <= 8 * PH * kPW, "statistics scratch must fit the patch LDS");
+    if (stats) __syncthreads();  // every wave is done with the staging LDS
+    bool ok[NB];
+    unsigned po[NB];  // pixel offset inside a channel plane (0 when outside the image)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int gy = y0 + NB * wv + nb;
-        if (gy >= p.h || gx >= p.w) continue;
+        ok[nb] = gy < p.h && gx < p.w;
+        po[nb] = ok[nb] ? (unsigned)gy * (unsigned)p.w + (unsigned)gx : 0u;
+    }
 #pragma unroll
-        for (int cb = 0; cb < NCO; ++cb)
+    for (int cb = 0; cb < NCO; ++cb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = cb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                const int co = co0 + col;
-                const size_t o = (size_t)co * hw + (size_t)gy * p.w + gx;
+        for (int r = 0; r < 16; ++r) {
+            const int col = cb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            const int co = co0 + col;
+            const size_t cbase = (size_t)co * hw;
+            float oldv[NB], yv[NB];
+            if (p.accumulate)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) oldv[nb] = bf16_up(yb[cbase + po[nb]]);
+            if (masked)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) yv[nb] = bf16_up(my[cbase + po[nb]]);
+            float s1 = 0.f, s2 = 0.f;
+            const float pv = (stats && !masked && p.stat_pivot != nullptr) ? p.stat_pivot[co] : 0.f;
+            const float msc = masked ? p.mask_scale[co] : 0.f, msh = masked ? p.mask_shift[co] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
                 float v = acc[nb][cb][r];
-                if (p.out_scale) v = fmaf(v, eps[0][col], eps[1][col]);
-                if (p.out_relu) v = fmaxf(v, 0.0f);
-                if (YBF)
-                    yb[o] = bf16_down(v);
-                else
-                    yn[o] = v;
+                if (p.accumulate) v += oldv[nb];
+                const uint16_t vb = bf16_down(v);
+                if (ok[nb]) yb[cbase + po[nb]] = vb;
+                if (!stats) continue;
+                const float vr = bf16_up(vb);
+                if (!masked) {
+                    const float d = ok[nb] ? vr - pv : 0.f;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                } else {
+                    const bool on = ok[nb] && (!p.mask_relu || fmaf(yv[nb], msc, msh) > 0.f);
+                    const float d = on ? vr : 0.f;
+                    s1 += d;
+                    s2 = fmaf(d, yv[nb], s2);
+                }
             }
+            if (stats) {
+                s1 = half_sum32(s1);
+                s2 = half_sum32(s2);
+                if (px == 31) {
+                    red[(wv * (NCO * 32) + col) * 2] = s1;
+                    red[(wv * (NCO * 32) + col) * 2 + 1] = s2;
+                }
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        const long long tg = (long long)n * gridDim.x + tile;
+        if (tid < NCO * 32) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                a += red[(w4 * (NCO * 32) + tid) * 2];
+                b += red[(w4 * (NCO * 32) + tid) * 2 + 1];
+            }
+            float* dst = p.stat_part + ((size_t)(co0 + tid) * (size_t)p.stat_tiles + (size_t)tg) * 2;
+            dst[0] = a;
+            dst[1] = b;
+        }
     }
 }
 
@@ -363,25 +472,29 @@ __global__ void prep_weights_bf16_kernel(const float* __restrict__ w, uint16_t* 
 
 namespace {
 
-template <bool XBF, bool YBF>
+// cout % 64 == 0: two 32-channel blocks per workgroup share one staged 32x8 patch (four measured
+// the same); cout == 32 (+64k): one block, and a 32x16 tile instead so that a staged patch
+// still feeds 16 accumulator tiles per wave
+inline int bf16_nco(int cout) { return cout % 64 == 0 ? 2 : 1; }
+inline int bf16_tiles(int h, int w, int cout) {
+    const int th = bf16_nco(cout) == 2 ? 8 : 16;
+    return ((w + kTW - 1) / kTW) * ((h + th - 1) / th);
+}
+
+template <bool XBF, bool YBF, bool TR>
 void launch_conv_bf16(const Bf16ConvArgs& a, int ksize, hipStream_t s) {
-    // cout % 64 == 0: two 32-channel blocks per workgroup share one staged 32x8 patch (four measured
-    // the same); cout == 32 (+64k): one block, and a 32x16 tile instead so that a staged patch
-    // still feeds 16 accumulator tiles per wave
-    const int nco = a.cout % 64 == 0 ? 2 : 1;
-    const int th = nco == 2 ? 8 : 16;
-    const int tiles = ((a.w + kTW - 1) / kTW) * ((a.h + th - 1) / th);
-    dim3 grid(tiles, a.cout / (32 * nco), a.n);
+    const int nco = bf16_nco(a.cout);
+    dim3 grid(bf16_tiles(a.h, a.w, a.cout), a.cout / (32 * nco), a.n);
     if (ksize == 3) {
         if (nco == 2)
-            conv_bf16_kernel<9, 2, 2, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+            conv_bf16_kernel<9, 2, 2, XBF, YBF, TR><<<grid, kThreads, 0, s>>>(a);
         else
-            conv_bf16_kernel<9, 1, 4, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+            conv_bf16_kernel<9, 1, 4, XBF, YBF, TR><<<grid, kThreads, 0, s>>>(a);
     } else {
         if (nco == 2)
-            conv_bf16_kernel<1, 2, 2, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+            conv_bf16_kernel<1, 2, 2, XBF, YBF, TR><<<grid, kThreads, 0, s>>>(a);
         else
-            conv_bf16_kernel<1, 1, 4, XBF, YBF><<<grid, kThreads, 0, s>>>(a);
+            conv_bf16_kernel<1, 1, 4, XBF, YBF, TR><<<grid, kThreads, 0, s>>>(a);
     }
 }
 
@@ -421,15 +534,60 @@ int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y
     LF_REQUIRE(n <= 65535, "lf_conv2d_bf16: batch too large for grid.z");
     LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wprep)) & 15) == 0,
                "lf_conv2d_bf16: x and wprep must be 16-byte aligned");
-    Bf16ConvArgs a{x, wprep, y, n, cin, h, w, cout, (cin + 15) / 16, in_scale, in_shift, in_relu,
-                   out_scale, out_shift, out_relu};
+    Bf16ConvArgs a{};
+    a.x = x; a.wprep = wprep; a.y = y; a.n = n; a.cin = cin; a.h = h; a.w = w; a.cout = cout;
+    a.chunks = (cin + 15) / 16;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+    a.out_scale = out_scale; a.out_shift = out_shift; a.out_relu = out_relu;
     hipStream_t s = lf::as_stream(stream);
     if (x_bf16) {
-        if (y_bf16) launch_conv_bf16<true, true>(a, ksize, s); else launch_conv_bf16<true, false>(a, ksize, s);
+        if (y_bf16) launch_conv_bf16<true, true, false>(a, ksize, s); else launch_conv_bf16<true, false, false>(a, ksize, s);
     } else {
-        if (y_bf16) launch_conv_bf16<false, true>(a, ksize, s); else launch_conv_bf16<false, false>(a, ksize, s);
+        if (y_bf16) launch_conv_bf16<false, true, false>(a, ksize, s); else launch_conv_bf16<false, false, false>(a, ksize, s);
     }
     return lf::check_launch("lf_conv2d_bf16");
+}
+
+long long lf_conv2d_bf16_stats_tiles(int n, int h, int w, int cout) {
+    if (n <= 0 || h <= 0 || w <= 0 || cout <= 0) return 0;
+    return (long long)n * bf16_tiles(h, w, cout);
+}
+
+int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint16_t* y, int n, int cin, int h,
+                         int w, int cout, int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                         int accumulate, float* tile_part, size_t tile_part_bytes, const float* pivot,
+                         const uint16_t* mask_y, const float* mask_scale, const float* mask_shift,
+                         int mask_relu, lf_stream_t stream) {
+    LF_REQUIRE(x && wprep && y, "lf_conv2d_bf16_train: null buffer");
+    LF_REQUIRE(n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0, "lf_conv2d_bf16_train: bad dims");
+    LF_REQUIRE(ksize == 1 || ksize == 3, "lf_conv2d_bf16_train: ksize must be 1 or 3");
+    LF_REQUIRE(w % 4 == 0, "lf_conv2d_bf16_train: width must be a multiple of 4 (got %d)", w);
+    LF_REQUIRE(cout % 32 == 0, "lf_conv2d_bf16_train: cout must be a multiple of 32 (got %d)", cout);
+    LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "lf_conv2d_bf16_train: scale/shift must both be set");
+    LF_REQUIRE((size_t)h * w < ((size_t)1 << 32), "lf_conv2d_bf16_train: plane too large");
+    LF_REQUIRE(n <= 65535, "lf_conv2d_bf16_train: batch too large for grid.z");
+    LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wprep)) & 15) == 0,
+               "lf_conv2d_bf16_train: x and wprep must be 16-byte aligned");
+    LF_REQUIRE(mask_y == nullptr || (tile_part && mask_scale && mask_shift),
+               "lf_conv2d_bf16_train: mask_y needs tile_part and mask_scale / mask_shift");
+    if (tile_part != nullptr) {
+        const size_t need = (size_t)lf_conv2d_bf16_stats_tiles(n, h, w, cout) * (size_t)cout * 2 * sizeof(float);
+        if (tile_part_bytes < need) {
+            lf::set_error("lf_conv2d_bf16_train: tile_part %zu bytes < %zu", tile_part_bytes, need);
+            return LF_ERR_WORKSPACE;
+        }
+    }
+    Bf16ConvArgs a{};
+    a.x = x; a.wprep = wprep; a.y = y; a.n = n; a.cin = cin; a.h = h; a.w = w; a.cout = cout;
+    a.chunks = (cin + 15) / 16;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+    a.accumulate = accumulate;
+    a.stat_part = tile_part; a.stat_pivot = pivot;
+    a.stat_tiles = lf_conv2d_bf16_stats_tiles(n, h, w, cout);
+    a.stat_mask_y = mask_y; a.mask_scale = mask_scale; a.mask_shift = mask_shift; a.mask_relu = mask_relu;
+    hipStream_t s = lf::as_stream(stream);
+    if (x_bf16) launch_conv_bf16<true, true, true>(a, ksize, s); else launch_conv_bf16<false, true, true>(a, ksize, s);
+    return lf::check_launch("lf_conv2d_bf16_train");
 }
 
 int lf_gap_bf16(const uint16_t* x, float* out, int n, int c, int hw, const float* scale, const float* shift,

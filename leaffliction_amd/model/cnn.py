@@ -111,6 +111,11 @@ class LeafCNN:
         self.infer_dtype = os.environ.get("LEAFFLICTION_INFER_DTYPE", "f32")  # see set_inference_dtype
         if self.infer_dtype not in ("f32", "bf16"):
             raise ValueError("LEAFFLICTION_INFER_DTYPE must be f32 or bf16")
+        self.train_dtype = os.environ.get("LEAFFLICTION_TRAIN_DTYPE", "f32")  # see set_training_dtype
+        if self.train_dtype not in ("f32", "bf16"):
+            raise ValueError("LEAFFLICTION_TRAIN_DTYPE must be f32 or bf16")
+        # data-parallel gradient bucket: "bf16" halves the bytes on xGMI (2.5 MB), "f32" keeps the sum exact
+        self.grad_bucket_dtype = os.environ.get("LEAFFLICTION_GRAD_BUCKET", "auto")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.norm = Normalization() if use_norm else None
         self.stop_training = False
@@ -389,6 +394,156 @@ class LeafCNN:
             raise ValueError(f"inference dtype must be 'f32' or 'bf16', got {dtype!r}")
         self.infer_dtype = dtype
 
+    def set_training_dtype(self, dtype: str) -> None:
+        """"f32" (default) or "bf16": the mixed-precision training step (the reference's default
+        policy is mixed_float16, train.py:179-190; `--no-mixed-precision` selects f32).  bf16:
+        activations and gradients are STORED as bf16 and every convolution operand is bf16
+        (fp32 accumulation); master weights, Adam state, BatchNorm statistics, SE, softmax and the
+        loss stay fp32.  Needs widths that are multiples of 32 and an image size that keeps every
+        stage a multiple of four pixels wide (224, 64, 32 do)."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"training dtype must be 'f32' or 'bf16', got {dtype!r}")
+        if dtype == "bf16" and not (self.use_se and self._bf16_storage_ok(self.img_size, self.img_size)):
+            raise ValueError("bf16 training needs use_se, widths % 32 == 0 and every stage a multiple "
+                             f"of 4 pixels wide (img_size {self.img_size}, widths {self.widths})")
+        self.train_dtype = dtype
+
+    # ------------------------------------------------- mixed-precision step (bf16 storage)
+    def _prep_bf16_weights(self) -> None:
+        """bf16 copies of the convolution kernels in MFMA operand order, for the forward and the
+        input-gradient convolutions: rebuilt from the fp32 masters every step (1.25 M values)."""
+        for name, shape, kind in self.specs:
+            if len(shape) != 3:
+                continue
+            k = 3 if shape[1] == 9 else 1
+            self._wt["f:" + name] = nn.conv2d_bf16_weights(self.p[name], k)
+            if name != "stem.w":
+                self._wt["d:" + name] = nn.conv2d_bf16_dgrad_weights(self.p[name], k)
+
+    def _forward_train_bf16(self, x0: torch.Tensor, y_true: torch.Tensor, drops, top_drop):
+        """The training forward pass on bf16 storage; everything backward needs goes to self._saved."""
+        n, _c, h, w = x0.shape
+        P, bf = self.p, torch.bfloat16
+        B = lambda k, shape, dt=bf: self._buf(n, "t16." + k, shape, dt)  # noqa: E731
+        F32 = torch.float32
+        sv: Dict[str, Any] = {"x0": x0, "n": n}
+        self._prep_bf16_weights()
+
+        def conv_bn(x, wname, k, bn, pro, out):
+            cout = P[wname].shape[2]
+            st = self.stats[bn]
+            nn.conv2d_bn_stats_bf16(x, self._wt["f:" + wname], cout, k, P[bn + ".gamma"], P[bn + ".beta"],
+                                    self.s[bn + ".mean"], self.s[bn + ".var"], st, pro[0], pro[1], pro[2],
+                                    out=out, momentum=BN_MOMENTUM, eps=BN_EPS)
+            return out, st
+
+        y, st = conv_bn(x0, "stem.w", 3, "stem.bn", (None, None, False), B("stem.y", (n, self.widths[0], h, w)))
+        sv["stem.y"] = y
+        xin, xin_st, cin = y, st, self.widths[0]
+        for i, f in enumerate(self.widths):
+            p = f"s{i}."
+            pro = (xin_st[2], xin_st[3], True) if xin_st is not None else (None, None, False)
+            y1, st1 = conv_bn(xin, p + "c1.w", 3, p + "bn1", pro, B(p + "y1", (n, f, h, w)))
+            y2, st2 = conv_bn(y1, p + "c2.w", 3, p + "bn2", (st1[2], st1[3], True), B(p + "y2", (n, f, h, w)))
+            msum = B(p + "msum", (n, f, 2), F32)
+            m = nn.gap_stats_bf16(y2, out=B(p + "m", (n, f), F32), scale=st2[2], shift=st2[3], relu=True,
+                                  mask_sums=msum)
+            z1 = B(p + "z1", (n, f // 8), F32)
+            s = nn.se_fwd(m, P[p + "se.w1"], P[p + "se.b1"], P[p + "se.w2"], P[p + "se.b2"], z1,
+                          B(p + "s", (n, f), F32))
+            sv[p + "msum"], sv[p + "m"], sv[p + "z1"] = msum, m, z1
+            if cin != f:
+                yp, stp = conv_bn(xin, p + "proj.w", 1, p + "bnp", pro, B(p + "yp", (n, f, h, w)))
+                sc, scs, scb, scr = yp, stp[2], stp[3], False
+                sv[p + "yp"] = yp
+            else:
+                sc, scs, scb, scr = xin, pro[0], pro[1], pro[2]
+            drop = drops[i] if drops is not None else None
+            pooled = B(p + "p", (n, f, h // 2, w // 2))
+            route = B(p + "route", pooled.shape, torch.uint8)
+            nn.block_tail_fwd_train_bf16(y2, st2[2], st2[3], s, sc, scs, scb, scr, drop, route, pooled)
+            sv.update({p + "xin": xin, p + "xin_st": xin_st, p + "y1": y1, p + "y2": y2, p + "s": s,
+                       p + "route": route, p + "drop": drop, p + "hw": (h, w)})
+            xin, xin_st, cin, h, w = pooled, None, f, h // 2, w // 2
+        g = nn.gap_stats_bf16(xin, out=B("g", (n, self.widths[-1]), F32))
+        feat = g
+        if top_drop is not None:
+            feat = nn.mul(g, top_drop, B("feat", g.shape, F32))
+        probs = B("probs", (n, self.num_classes), F32)
+        loss = B("loss", (n,), F32)
+        nn.head_fwd(feat, P["dense.w"], P["dense.b"], y_true, probs, loss)
+        sv.update({"feat": feat, "top_drop": top_drop, "probs": probs, "y_true": y_true, "last_hw": (h, w)})
+        self._saved = sv
+        return probs, loss
+
+    def _backward_bf16(self) -> None:
+        """Fills flat_g (fp32) from the tensors of the last _forward_train_bf16."""
+        sv, P, G = self._saved, self.p, self.g
+        n = sv["n"]
+        bf, F32 = torch.bfloat16, torch.float32
+        B = lambda k, shape, dt=bf: self._buf(n, "t16." + k, shape, dt)  # noqa: E731
+        f_last = self.widths[-1]
+        dlogits = B("dlogits", (n, self.num_classes), F32)
+        dfeat = B("dfeat", (n, f_last), F32)
+        nn.head_bwd(sv["feat"], P["dense.w"], sv["probs"], sv["y_true"], dlogits, dfeat,
+                    G["dense.w"], G["dense.b"], 1.0 / (self._global_n or n))
+        dg = dfeat
+        if sv["top_drop"] is not None:
+            dg = nn.mul(dfeat, sv["top_drop"], B("dg", dfeat.shape, F32))
+        h, w = sv["last_hw"]
+        dp = nn.bcast_planes_bf16(dg, h, w, 1.0 / (h * w), B("dp_last", (n, f_last, h, w)))
+        for i in reversed(range(len(self.widths))):
+            f = self.widths[i]
+            cin = self.widths[i - 1] if i > 0 else self.widths[0]
+            p = f"s{i}."
+            h, w = sv[p + "hw"]
+            xin, xin_st, y1, y2 = (sv[p + k] for k in ("xin", "xin_st", "y1", "y2"))
+            pro = (xin_st[2], xin_st[3], True) if xin_st is not None else (None, None, False)
+            s, route, drop = sv[p + "s"], sv[p + "route"], sv[p + "drop"]
+            st1, st2 = self.stats[p + "bn1"], self.stats[p + "bn2"]
+            gA, gB, gC = B(p + "gA", y1.shape), B(p + "gB", y1.shape), B(p + "gC", y1.shape)
+            ds = B(p + "ds", (n, f), F32)
+            psum = B(p + "psum", (n, f, 2), F32)
+            yp = sv.get(p + "yp")
+            psum_p = B(p + "psum_p", (n, f, 2), F32) if yp is not None else None
+            # dr (-> gA), the SE gate gradient and BN2's per-plane backward sums in one pass
+            nn.block_tail_bwd_bf16(dp, route, y2, st2[2], st2[3], drop, gA, ds, psum, yp, psum_p)
+            dm = B(p + "dm", (n, f), F32)
+            nn.se_bwd(ds, sv[p + "m"], sv[p + "z1"], s, P[p + "se.w1"], P[p + "se.w2"], dm,
+                      G[p + "se.w1"], G[p + "se.b1"], G[p + "se.w2"], G[p + "se.b2"], dm_scale=1.0 / (h * w))
+            # BN2 backward + conv2 weight gradient; dy2 -> gB
+            nn.bn_bwd_wgrad_bf16(y1, gA, y2, st2, P[p + "bn2.gamma"], G[p + "bn2.gamma"], G[p + "bn2.beta"],
+                                 True, 3, G[p + "c2.w"], gB, st1[2], st1[3], True, alpha_nc=s, add_nc=dm,
+                                 plane_g=psum, plane_m=sv[p + "msum"])
+            # da1 -> gC; the epilogue leaves BN1's backward sums
+            _, tsum = nn.conv2d_bf16_train(gB, self._wt["d:" + p + "c2.w"], f, 3, gC, mask_y=y1,
+                                           mask_scale=st1[2], mask_shift=st1[3], mask_relu=True)
+            # BN1 backward + conv1 weight gradient; dy1 -> gB
+            nn.bn_bwd_wgrad_bf16(xin, gC, y1, st1, P[p + "bn1.gamma"], G[p + "bn1.gamma"], G[p + "bn1.beta"],
+                                 True, 3, G[p + "c1.w"], gB, pro[0], pro[1], pro[2], tile_sums=tsum)
+            if cin != f:
+                stp = self.stats[p + "bnp"]
+                # projection BN backward + 1x1 weight gradient; dyp -> gC
+                nn.bn_bwd_wgrad_bf16(xin, gA, yp, stp, P[p + "bnp.gamma"], G[p + "bnp.gamma"],
+                                     G[p + "bnp.beta"], False, 1, G[p + "proj.w"], gC, pro[0], pro[1], pro[2],
+                                     plane_g=psum_p)
+                dx = B(p + "dx", xin.shape)
+                nn.conv2d_bf16_train(gC, self._wt["d:" + p + "proj.w"], cin, 1, dx)
+            else:
+                dx = gA  # identity shortcut: dx starts as dr
+            stem_sums = None
+            if i == 0:  # dx feeds the stem's BN backward: gather its sums in this epilogue
+                _, stem_sums = nn.conv2d_bf16_train(gB, self._wt["d:" + p + "c1.w"], cin, 3, dx, accumulate=True,
+                                                    mask_y=sv["stem.y"], mask_scale=self.stats["stem.bn"][2],
+                                                    mask_shift=self.stats["stem.bn"][3], mask_relu=True)
+            else:
+                nn.conv2d_bf16_train(gB, self._wt["d:" + p + "c1.w"], cin, 3, dx, accumulate=True)
+            dp = dx
+        # the stem has no input gradient: its BN backward exists only inside the wgrad kernel
+        nn.bn_bwd_wgrad_bf16(sv["x0"], dp, sv["stem.y"], self.stats["stem.bn"], P["stem.bn.gamma"],
+                             G["stem.bn.gamma"], G["stem.bn.beta"], True, 3, G["stem.w"], None,
+                             tile_sums=stem_sums)
+
     def forward(self, x0: torch.Tensor, training: bool, y_true: Optional[torch.Tensor] = None,
                 drops: Optional[List[torch.Tensor]] = None,
                 top_drop: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
@@ -575,8 +730,14 @@ class LeafCNN:
         n = int(x.shape[0])
         drops, top, aug4 = self.draw_step_randoms(n, self.augment)
         x0 = self._input(x, True, aug4)
-        probs, loss = self.forward(x0, True, y_true, drops, top)
-        self.backward()
+        if self.train_dtype == "bf16":
+            if not (self.use_se and self._bf16_storage_ok(x0.shape[2], x0.shape[3])):
+                raise ValueError("bf16 training: unsupported shape (see set_training_dtype)")
+            probs, loss = self._forward_train_bf16(x0, y_true, drops, top)
+            self._backward_bf16()
+        else:
+            probs, loss = self.forward(x0, True, y_true, drops, top)
+            self.backward()
         return probs, loss
 
     def _optimizer_update(self, lr: float, *, weight_decay: float, clipnorm: float,

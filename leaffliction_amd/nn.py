@@ -137,6 +137,194 @@ def block_tail_fwd_bf16(y, a_scale, a_shift, s, sc, sc_scale, sc_shift, sc_relu:
     return out
 
 
+# ---------------------------------------------------------------------------
+# mixed-precision training step: bf16 storage, fp32 arithmetic (lf_*_bf16 / *_train_bf16)
+# ---------------------------------------------------------------------------
+_BF16 = torch.bfloat16
+
+
+def conv2d_bf16_dgrad_weights(w_iko: torch.Tensor, ksize: int) -> torch.Tensor:
+    """Packed bf16 weights of the input-gradient convolution of a conv with fp32 IKO weights w."""
+    return conv2d_bf16_weights(conv2d_dgrad_weights(w_iko, ksize), ksize)
+
+
+def conv2d_bf16_train(x: torch.Tensor, wprep: torch.Tensor, cout: int, ksize: int, out: torch.Tensor,
+                      in_scale=None, in_shift=None, in_relu: bool = False, accumulate: bool = False,
+                      stats: bool = False, pivot=None, mask_y=None, mask_scale=None, mask_shift=None,
+                      mask_relu: bool = False):
+    """Forward / input-gradient convolution of the bf16 training step: out (bf16 NCHW) = conv(x')
+    (+ out when accumulate).  With stats=True returns (out, (tile_part, tiles)) — BatchNorm forward
+    statistics about `pivot`, or (mask_y given) the backward sums of the BatchNorm out feeds."""
+    if x.dtype not in (_F32, _BF16):
+        raise TypeError(f"conv2d_bf16_train.x: expected float32 or bfloat16, got {x.dtype}")
+    _chk(x, x.dtype, "conv2d_bf16_train.x", 4)
+    _chk(out, _BF16, "conv2d_bf16_train.out", 4)
+    n, cin, h, w = x.shape
+    if wprep.dtype != torch.int16 or wprep.numel() != ((cin + 15) // 16) * ksize * ksize * cout * 16:
+        raise ValueError("conv2d_bf16_train.wprep: not the packed weights of this convolution")
+    if tuple(out.shape) != (n, cout, h, w):
+        raise ValueError("conv2d_bf16_train.out: shape mismatch")
+    for t, nm in ((in_scale, "in_scale"), (in_shift, "in_shift")):
+        if t is not None:
+            _chk(t, _F32, f"conv2d_bf16_train.{nm}", 1)
+            if t.shape[0] != cin:
+                raise ValueError(f"conv2d_bf16_train.{nm}: expected [{cin}]")
+    tp, tiles = None, 0
+    if mask_y is not None:
+        _chk(mask_y, _BF16, "conv2d_bf16_train.mask_y", 4)
+        if mask_y.shape != out.shape or mask_scale.shape[0] != cout or mask_shift.shape[0] != cout:
+            raise ValueError("conv2d_bf16_train: mask shape mismatch")
+        stats = True
+    if stats:
+        tiles = int(_lib.load().lf_conv2d_bf16_stats_tiles(n, h, w, cout))
+        tp = _workspace(tiles * cout * 8, x.device, slot=1)
+    _lib.call("lf_conv2d_bf16_train", x.data_ptr(), 1 if x.dtype == _BF16 else 0, wprep.data_ptr(),
+              out.data_ptr(), n, cin, h, w, cout, ksize, _ptr(in_scale), _ptr(in_shift),
+              1 if in_relu else 0, 1 if accumulate else 0, _ptr(tp), tp.numel() if tp is not None else 0,
+              _ptr(pivot), _ptr(mask_y), _ptr(mask_scale), _ptr(mask_shift), 1 if mask_relu else 0,
+              _stream())
+    return (out, (tp, tiles)) if stats else out
+
+
+def conv2d_bn_stats_bf16(x, wprep, cout: int, ksize: int, gamma, beta, mmean, mvar, stats: torch.Tensor,
+                         in_scale=None, in_shift=None, in_relu: bool = False, out=None,
+                         momentum: float = 0.99, eps: float = 1e-3) -> torch.Tensor:
+    """Conv2D + training-mode BatchNormalization statistics on bf16 storage: the statistics are
+    those of the ROUNDED output (what the next kernels read)."""
+    n, _cin, h, w = x.shape
+    out, (tp, tiles) = conv2d_bf16_train(x, wprep, cout, ksize, out, in_scale, in_shift, in_relu,
+                                         stats=True, pivot=mmean)
+    ws = _workspace(_lib.load().lf_bn_workspace(cout), x.device)
+    _lib.call("lf_bn_train_stats_tiles_f32", tp.data_ptr(), tiles, n, cout, h * w, gamma.data_ptr(),
+              beta.data_ptr(), mmean.data_ptr(), mvar.data_ptr(), float(momentum), float(eps),
+              stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+              ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def bn_bwd_wgrad_bf16(x: torch.Tensor, g: torch.Tensor, y_bn: torch.Tensor, stats: torch.Tensor, gamma,
+                      dgamma, dbeta, relu: bool, ksize: int, dw_out: torch.Tensor, dy_out,
+                      in_scale=None, in_shift=None, in_relu: bool = False, alpha_nc=None, add_nc=None,
+                      plane_g=None, plane_m=None, tile_sums=None):
+    """bn_bwd_wgrad on bf16 tensors: the BatchNorm-backward sums come from per-plane sums
+    (block_tail_bwd_bf16 / gap_stats_bf16) or per-tile sums (conv2d_bf16_train's epilogue) — never
+    from another pass over g and y — and dY = BN'(g) is formed inside the weight-gradient kernel."""
+    if x.dtype not in (_F32, _BF16):
+        raise TypeError("bn_bwd_wgrad_bf16.x: float32 (stem) or bfloat16")
+    _chk(x, x.dtype, "bn_bwd_wgrad_bf16.x", 4)
+    _chk(g, _BF16, "bn_bwd_wgrad_bf16.g", 4)
+    _chk(y_bn, _BF16, "bn_bwd_wgrad_bf16.y", 4)
+    _chk(dw_out, _F32, "bn_bwd_wgrad_bf16.dw_out", 3)
+    if dy_out is not None:
+        _chk(dy_out, _BF16, "bn_bwd_wgrad_bf16.dy_out", 4)
+    n, cin, h, w = x.shape
+    cout = g.shape[1]
+    if g.shape != y_bn.shape or (dy_out is not None and dy_out.shape != g.shape) or g.shape[0] != n \
+            or tuple(g.shape[2:]) != (h, w) or tuple(dw_out.shape) != (cin, ksize * ksize, cout):
+        raise ValueError("bn_bwd_wgrad_bf16: shape mismatch")
+    if (tile_sums is None) == (plane_g is None):
+        raise ValueError("bn_bwd_wgrad_bf16: exactly one of tile_sums / plane_g must be given")
+    lib = _lib.load()
+    coef = _workspace(5 * cout * 4, x.device, slot=2)
+    ws = _workspace(lib.lf_bn_workspace(cout), x.device)
+    if tile_sums is not None:
+        if alpha_nc is not None or add_nc is not None:
+            raise ValueError("bn_bwd_wgrad_bf16: tile_sums excludes alpha/add")
+        tp, tiles = tile_sums
+        _lib.call("lf_bn_bwd_sums_tiles_f32", tp.data_ptr(), tiles, stats[0].data_ptr(),
+                  stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), gamma.data_ptr(),
+                  dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), n, cout, h * w,
+                  ws.data_ptr(), ws.numel(), _stream())
+    else:
+        _lib.call("lf_bn_bwd_sums_f32", None, _ptr(alpha_nc), _ptr(add_nc), None,
+                  stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                  1 if relu else 0, gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                  coef.data_ptr(), _ptr(plane_g), _ptr(plane_m), n, cout, h * w, ws.data_ptr(),
+                  ws.numel(), _stream())
+    ws = _workspace(lib.lf_conv2d_wgrad_bf16_workspace(n, cin, h, w, cout, ksize), x.device)
+    _lib.call("lf_conv2d_wgrad_bf16", x.data_ptr(), g.data_ptr(), y_bn.data_ptr(), _ptr(alpha_nc),
+              _ptr(add_nc), coef.data_ptr(), 1 if relu else 0, _ptr(dy_out), dw_out.data_ptr(), n, cin,
+              h, w, cout, ksize, _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, ws.data_ptr(),
+              ws.numel(), _stream())
+    return dy_out
+
+
+def conv2d_wgrad_bf16(x: torch.Tensor, dy: torch.Tensor, ksize: int, in_scale=None, in_shift=None,
+                      in_relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dw [Cin,k*k,Cout] (fp32) = sum x'[n,ci,y+ky-1,x+kx-1] * dy[n,co,y,x] from bf16 tensors."""
+    _chk(dy, _BF16, "wgrad_bf16.dy", 4)
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    if out is None:
+        out = torch.empty((cin, ksize * ksize, cout), dtype=_F32, device=x.device)
+    ws = _workspace(_lib.load().lf_conv2d_wgrad_bf16_workspace(n, cin, h, w, cout, ksize), x.device)
+    _lib.call("lf_conv2d_wgrad_bf16", x.data_ptr(), dy.data_ptr(), None, None, None, None, 0, None,
+              out.data_ptr(), n, cin, h, w, cout, ksize, _ptr(in_scale), _ptr(in_shift),
+              1 if in_relu else 0, ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def gap_stats_bf16(x: torch.Tensor, out=None, scale=None, shift=None, relu: bool = False, mask_sums=None):
+    _chk(x, _BF16, "gap_stats_bf16.x", 4)
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=_F32, device=x.device)
+    if mask_sums is not None and tuple(mask_sums.shape) != (n, c, 2):
+        raise ValueError("gap_stats_bf16.mask_sums: expected [N,C,2]")
+    _lib.call("lf_gap_stats_bf16", x.data_ptr(), out.data_ptr(), _ptr(mask_sums), n, c, h * w, _ptr(scale),
+              _ptr(shift), 1 if relu else 0, _stream())
+    return out
+
+
+def block_tail_fwd_train_bf16(y, a_scale, a_shift, s, sc, sc_scale, sc_shift, sc_relu, drop, route, p):
+    _chk(y, _BF16, "block_tail_fwd_train_bf16.y", 4)
+    _chk(sc, _BF16, "block_tail_fwd_train_bf16.sc", 4)
+    _chk(p, _BF16, "block_tail_fwd_train_bf16.p", 4)
+    _chk(route, torch.uint8, "block_tail_fwd_train_bf16.route", 4)
+    n, c, h, w = y.shape
+    if sc.shape != y.shape or tuple(p.shape) != (n, c, h // 2, w // 2) or route.shape != p.shape:
+        raise ValueError("block_tail_fwd_train_bf16: shape mismatch")
+    _lib.call("lf_block_tail_fwd_train_bf16", y.data_ptr(), _ptr(a_scale), _ptr(a_shift), _ptr(s),
+              sc.data_ptr(), _ptr(sc_scale), _ptr(sc_shift), 1 if sc_relu else 0, _ptr(drop),
+              route.data_ptr(), p.data_ptr(), n, c, h, w, _stream())
+    return route, p
+
+
+def block_tail_bwd_bf16(dp, route, y, a_scale, a_shift, drop, dr, ds, plane_sums=None, sc_y=None,
+                        sc_sums=None):
+    _chk(dr, _BF16, "block_tail_bwd_bf16.dr", 4)
+    _chk(dp, _BF16, "block_tail_bwd_bf16.dp", 4)
+    _chk(route, torch.uint8, "block_tail_bwd_bf16.route", 4)
+    n, c, h, w = dr.shape
+    if tuple(dp.shape) != (n, c, h // 2, w // 2) or route.shape != dp.shape:
+        raise ValueError("block_tail_bwd_bf16: shape mismatch")
+    for t in (plane_sums, sc_sums):
+        if t is not None and tuple(t.shape) != (n, c, 2):
+            raise ValueError("block_tail_bwd_bf16 plane sums: expected [N,C,2]")
+    _lib.call("lf_block_tail_bwd_bf16", dp.data_ptr(), route.data_ptr(), _ptr(y), _ptr(a_scale),
+              _ptr(a_shift), _ptr(drop), dr.data_ptr(), _ptr(ds), _ptr(plane_sums), _ptr(sc_y),
+              _ptr(sc_sums), n, c, h, w, _stream())
+    return dr, ds
+
+
+def bcast_planes_bf16(v, h, w, scale, out):
+    _chk(v, _F32, "bcast_planes_bf16.v", 2)
+    _chk(out, _BF16, "bcast_planes_bf16.out", 4)
+    n, c = v.shape
+    _lib.call("lf_bcast_planes_bf16", v.data_ptr(), out.data_ptr(), n * c, h * w, float(scale), _stream())
+    return out
+
+
+def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    _lib.call("lf_cast_f32_bf16", src.data_ptr(), dst.data_ptr(), src.numel(), _stream())
+    return dst
+
+
+def cast_bf16_f32(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    _lib.call("lf_cast_bf16_f32", src.data_ptr(), dst.data_ptr(), src.numel(), _stream())
+    return dst
+
+
 def conv2d_bn_stats(x: torch.Tensor, w_iko: torch.Tensor, ksize: int, gamma, beta, mmean, mvar,
                     stats: torch.Tensor, in_scale=None, in_shift=None, in_relu: bool = False,
                     out: Optional[torch.Tensor] = None, momentum: float = 0.99,

@@ -168,36 +168,70 @@ def input_stage(x_u8: torch.Tensor, aug: Optional[torch.Tensor], mean=None, deno
     return x.permute(0, 3, 1, 2).contiguous()
 
 
-def forward(params, state, x, widths, training, drops=None, top_drop=None, collect=None):
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    """fp32 -> nearest-even bf16 -> fp32 (what a bf16 store followed by a load yields)."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _q(t: torch.Tensor, round_grad: bool = True) -> torch.Tensor:
+    """Value rounded to bf16 in the forward pass (straight-through); with round_grad the gradient
+    that arrives at the rounded tensor is rounded to bf16 too (a bf16 gradient store)."""
+    out = t + (bf16_round(t) - t).detach()
+    if round_grad and out.requires_grad:
+        out.register_hook(bf16_round)
+    return out
+
+
+def forward(params, state, x, widths, training, drops=None, top_drop=None, collect=None, lowp=False):
     """x [N,3,H,W] f32 (already normalised) -> probabilities [N,C].
 
     drops[i] [N,C_i] SpatialDropout2D keep-scales (0 or 1/(1-p)); top_drop [N,F] likewise.
+
+    lowp=True restates the MIXED-PRECISION step (the reference's default policy is Keras'
+    mixed_float16, srcs/cli/train.py:179-190; BASELINE configs[3] names bf16): 16-bit storage of
+    every layer output and gradient, 16-bit matrix operands, fp32 variables / BatchNorm statistics
+    / SE / softmax / loss.  The rounding points are the ones the HIP step has (include/leafhip.h,
+    "mixed-precision TRAINING step"): convolution operands (activation and kernel) and outputs,
+    pooled block outputs; in the backward pass the gradient w.r.t. every convolution output and
+    input, the pooled gradient after the dropout factor, and the head's gradient w.r.t. the last
+    pooled map.  BatchNorm statistics are those of the rounded convolution output.
     """
     P = params
-    a = torch.relu(batchnorm(conv(x, P["stem.w"], 3), P["stem.bn.gamma"], P["stem.bn.beta"], state,
-                             "stem.bn", training))
+    rnd = (lambda t: _q(t)) if lowp else (lambda t: t)           # value + its gradient
+    opd = (lambda t: _q(t, False)) if lowp else (lambda t: t)    # operand rounding only
+    wq = {k: opd(v) for k, v in P.items() if k.endswith(".w") and v.dim() == 3} if lowp else P
+
+    def cbn(inp, wname, k, bn):
+        y = rnd(conv(inp, wq[wname], k))                         # stored conv output; dY rounded
+        return batchnorm(y, P[bn + ".gamma"], P[bn + ".beta"], state, bn, training)
+
+    a = torch.relu(cbn(opd(x), "stem.w", 3, "stem.bn"))
     cin = widths[0]
     for i, f in enumerate(widths):
         p = f"s{i}."
+        if lowp and a.requires_grad:
+            a.register_hook(bf16_round)        # the block's input gradient (all consumers summed)
         sc = a
-        y = torch.relu(batchnorm(conv(a, P[p + "c1.w"], 3), P[p + "bn1.gamma"], P[p + "bn1.beta"],
-                                 state, p + "bn1", training))
-        y = torch.relu(batchnorm(conv(y, P[p + "c2.w"], 3), P[p + "bn2.gamma"], P[p + "bn2.beta"],
-                                 state, p + "bn2", training))
+        y = torch.relu(cbn(rnd(a) if cin != f else opd(a), p + "c1.w", 3, p + "bn1"))
+        y = torch.relu(cbn(rnd(y), p + "c2.w", 3, p + "bn2"))
         m = y.mean(dim=(2, 3))
         z = torch.relu(m @ P[p + "se.w1"] + P[p + "se.b1"])
         s = torch.sigmoid(z @ P[p + "se.w2"] + P[p + "se.b2"])
         y = y * s.view(s.shape[0], s.shape[1], 1, 1)
         if cin != f:
-            sc = batchnorm(conv(sc, P[p + "proj.w"], 1), P[p + "bnp.gamma"], P[p + "bnp.beta"], state,
-                           p + "bnp", training)
+            sc = cbn(rnd(sc), p + "proj.w", 1, p + "bnp")
         r = torch.relu(sc + y)
+        mp = F.max_pool2d(r, 2)
+        if lowp and mp.requires_grad:
+            mp.register_hook(bf16_round)       # dr = bf16(dp * drop), then routed
         if training and drops is not None:
-            r = r * drops[i].view(r.shape[0], r.shape[1], 1, 1)
-        a = F.max_pool2d(r, 2)
+            mp = mp * drops[i].view(r.shape[0], r.shape[1], 1, 1)
+        a = opd(mp)                            # stored pooled output
         if collect is not None:
             collect[p + "out"] = a
         cin = f
+    if lowp and a.requires_grad:
+        a.register_hook(bf16_round)            # head gradient spread over the last pooled map
     g = a.mean(dim=(2, 3))
     if training and top_drop is not None:
         g = g * top_drop
@@ -248,13 +282,13 @@ def adamw_step(params, grads, m, v, step, lr, wd=1e-4, clipnorm=0.5, b1=0.9, b2=
 
 
 def train_step(params, state, x, y_onehot, widths, drops, top_drop, l2=1e-4, smoothing=0.02,
-               grads_include_l2=True):
+               grads_include_l2=True, lowp=False):
     """One forward/backward: returns (loss incl. L2, data_loss, probs, grads dict).
 
     With grads_include_l2=False the gradients are those of the data loss alone (the HIP path
-    adds the regulariser's 2*l2*w inside its optimizer kernel)."""
+    adds the regulariser's 2*l2*w inside its optimizer kernel).  lowp: see forward()."""
     leaf = {k: t.clone().requires_grad_(True) for k, t in params.items()}
-    probs = forward(leaf, state, x, widths, True, drops, top_drop)
+    probs = forward(leaf, state, x, widths, True, drops, top_drop, lowp=lowp)
     yt = smooth_labels(y_onehot, smoothing) if smoothing > 0 else y_onehot
     data_loss = cce_loss(probs, yt).mean()
     loss = data_loss + l2_penalty(leaf, widths, y_onehot.shape[-1], l2)

@@ -1,0 +1,271 @@
+"""The mixed-precision (bf16 storage, fp32 arithmetic) training step on the GPU.
+
+Kernel level: each new kernel against a float64 restatement of the same arithmetic on the same
+bf16-rounded operands.  Values that are ROUNDED on store (conv outputs, dY, pooled maps) may
+differ from the restatement by one bf16 step where the fp32 value sits next to a rounding
+boundary and the two evaluation orders fall on different sides of it; the tests therefore bound
+(a) the error by one bf16 step (2^-8 relative) and (b) the fraction of elements that differ at
+all.  Sums (BatchNorm statistics, weight gradients) are checked against float64 sums over the
+kernel's OWN rounded outputs, so they are exact up to fp32 accumulation (1e-4 relative).
+
+Step level: one full forward/backward against oracle/cnn_ref.py run with lowp=True — the oracle
+evaluated with bf16 rounding at the same points (tolerances stated in the test).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def q(t):
+    return t.to(BF).to(torch.float64)
+
+
+def conv_ref(a, w_iko, k):
+    cin, taps, cout = w_iko.shape
+    w = w_iko.permute(2, 0, 1).reshape(cout, cin, k, k)
+    return F.conv2d(a, w, padding=k // 2)
+
+
+def close_bf16(got, ref, max_frac, terms=None):
+    """got: bf16 tensor; ref: float64 unrounded reference.  |got - ref| within one bf16 step of ref
+    (plus the half-step of got's own rounding; `terms` = magnitude of the fp32 terms ref is a sum
+    of, for sums that cancel), and almost all elements equal the rounded ref."""
+    got64 = got.to(torch.float64).cpu()
+    tol = ref.abs() * 2.0 ** -7 + 1e-30
+    if terms is not None:
+        tol = tol + terms * 2.0 ** -22
+    assert bool(((got64 - ref).abs() <= tol).all()), float(((got64 - ref).abs() / tol).max())
+    frac = float((got64 != ref.to(BF).to(torch.float64)).double().mean())
+    assert frac <= max_frac, frac
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,xbf,pro,acc,stat", [
+    (2, 32, 32, 16, 32, 3, True, True, False, "fwd"),
+    (2, 3, 32, 16, 32, 3, False, False, False, "fwd"),
+    (2, 64, 64, 8, 56, 3, True, False, True, "bwd"),
+    (3, 64, 32, 8, 8, 3, True, False, False, "bwd"),
+    (2, 32, 64, 12, 20, 1, True, True, False, "fwd"),
+    (2, 64, 32, 28, 28, 1, True, False, True, None),
+])
+def test_conv2d_bf16_train(cuda, n, cin, cout, h, w, k, xbf, pro, acc, stat):
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(n * 1000 + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    x = x.to(BF) if xbf else x
+    wt = torch.randn(cin, k * k, cout, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.3
+    old = (torch.randn(n, cout, h, w, generator=g) * 0.5).to(BF)
+    my = torch.randn(n, cout, h, w, generator=g).to(BF)
+    msc, msh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    pivot = torch.randn(cout, generator=g) * 0.1
+    dev = cuda
+    out = old.clone().to(dev)
+    wp = nn.conv2d_bf16_weights(wt.to(dev), k)
+    kw = {}
+    if pro:
+        kw.update(in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True)
+    if stat == "fwd":
+        kw.update(stats=True, pivot=pivot.to(dev))
+    if stat == "bwd":
+        kw.update(mask_y=my.to(dev), mask_scale=msc.to(dev), mask_shift=msh.to(dev), mask_relu=True)
+    res = nn.conv2d_bf16_train(x.to(dev), wp, cout, k, out, accumulate=acc, **kw)
+    torch.cuda.synchronize()
+    # float64 restatement on the rounded operands
+    a = x.to(torch.float64)
+    if pro:
+        a = torch.relu((x.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))).to(torch.float64)
+    ref = conv_ref(q(a), q(wt), k)
+    if acc:
+        ref = ref + old.to(torch.float64)
+    close_bf16(out, ref, 0.02)
+    if stat is None:
+        return
+    _, (tp, tiles) = res
+    part = tp[:tiles * cout * 8].view(torch.float32)[:cout * tiles * 2].view(cout, tiles, 2).double().sum(1).cpu()
+    y = out.to(torch.float64).cpu()     # sums are over the kernel's own rounded output
+    if stat == "fwd":
+        d = y - pivot.double().view(1, -1, 1, 1)
+        s1, s2 = d.sum((0, 2, 3)), (d * d).sum((0, 2, 3))
+    else:
+        on = (my.float() * msc.view(1, -1, 1, 1) + msh.view(1, -1, 1, 1)) > 0
+        d = y * on
+        s1, s2 = d.sum((0, 2, 3)), (d * my.double()).sum((0, 2, 3))
+    scale = d.abs().sum((0, 2, 3)) + 1e-9
+    assert float(((part[:, 0] - s1).abs() / scale).max()) < 1e-5
+    assert float(((part[:, 1] - s2).abs() / ((d * d).sum((0, 2, 3)) + scale)).max()) < 1e-4
+
+
+WG_SHAPES = [
+    # n, cin, cout, h, w, k
+    (2, 32, 32, 16, 32, 3),     # 32x8 tile, one block
+    (2, 32, 64, 8, 56, 3),      # 56x4, two output blocks in the workgroup
+    (2, 64, 64, 8, 56, 3),      # 56x4, 2x2 blocks
+    (2, 128, 256, 28, 28, 3),   # 28x4, 2x2 blocks, grid over channel blocks
+    (3, 3, 32, 16, 32, 3),      # the stem (fp32 input, im2col rows)
+    (2, 32, 64, 8, 56, 1),      # 1x1 projection
+    (2, 64, 128, 28, 28, 1),
+    (2, 32, 32, 12, 20, 3),     # ragged: partial tiles in x and y
+    (1, 64, 32, 8, 8, 3),       # cin blocks on the grid
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k", WG_SHAPES)
+@pytest.mark.parametrize("bn", [False, True])
+def test_conv2d_wgrad_bf16(cuda, n, cin, cout, h, w, k, bn):
+    from leaffliction_amd import nn
+    stem = cin * 9 <= 32 and k == 3
+    g = torch.Generator().manual_seed(cin * 7 + cout + h + (1 if bn else 0))
+    x = torch.randn(n, cin, h, w, generator=g)
+    x = x if stem else x.to(BF)
+    gg = torch.randn(n, cout, h, w, generator=g).to(BF)
+    yb = torch.randn(n, cout, h, w, generator=g).to(BF)
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    dev = cuda
+    pro = not stem
+    a = x.float()
+    if pro:
+        a = torch.relu(a * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    a = q(a)
+    kw = dict(in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True) if pro else {}
+    if not bn:
+        dw = nn.conv2d_wgrad_bf16(x.to(dev), gg.to(dev), k, **kw)
+        dy = gg.to(torch.float64)
+    else:
+        # BatchNorm backward formed inside the kernel from (g, y, coef, alpha, add)
+        coef = torch.randn(5, cout, generator=g) * 0.5
+        al, ad = torch.rand(n, cout, generator=g) + 0.5, torch.randn(n, cout, generator=g) * 0.1
+        dy_out = torch.empty(n, cout, h, w, dtype=BF, device=dev)
+        dw = torch.empty(cin, k * k, cout, device=dev)
+        from leaffliction_amd import _lib
+        ws = nn._workspace(_lib.load().lf_conv2d_wgrad_bf16_workspace(n, cin, h, w, cout, k), dev)
+        xd, gd, yd, cd, ald, add = (t.to(dev) for t in (x, gg, yb, coef, al, ad))
+        _lib.call("lf_conv2d_wgrad_bf16", xd.data_ptr(), gd.data_ptr(), yd.data_ptr(), ald.data_ptr(),
+                  add.data_ptr(), cd.data_ptr(), 1, dy_out.data_ptr(), dw.data_ptr(), n, cin, h, w, cout, k,
+                  kw["in_scale"].data_ptr() if pro else None, kw["in_shift"].data_ptr() if pro else None,
+                  1 if pro else 0, ws.data_ptr(), ws.numel(), None)
+        torch.cuda.synchronize()
+        c = coef.view(5, 1, cout, 1, 1)
+        dz = gg.float() * al.view(n, cout, 1, 1) + ad.view(n, cout, 1, 1)
+        dz = torch.where((yb.float() * c[0] + c[1]) > 0, dz, torch.zeros(()))
+        dy_ref = (c[2].double() * dz.double() + (c[3].double() * yb.double() + c[4].double()))
+        terms = (c[2] * dz).abs().double() + (c[3] * yb.float()).abs().double() + c[4].abs().double()
+        close_bf16(dy_out, dy_ref, 0.02, terms)
+        dy = dy_out.to(torch.float64).cpu()   # the weight gradient is over the kernel's own rounded dY
+    torch.cuda.synchronize()
+    # dw[ci][tap][co] = sum a[n,ci,y+dy-1,x+dx-1] * dY[n,co,y,x]
+    ap = F.pad(a, (k // 2,) * 4)
+    ref = torch.empty(cin, k * k, cout, dtype=torch.float64)
+    for t in range(k * k):
+        ty, tx = t // k, t % k
+        ref[:, t, :] = torch.einsum("nchw,ndhw->cd", ap[:, :, ty:ty + h, tx:tx + w], dy)
+    err = (dw.double().cpu() - ref).abs().max().item()
+    # fp32 accumulation of exact bf16 products, plus rare one-step flips of the recomputed operand A
+    assert err <= 2e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+def test_plane_kernels_bf16(cuda):
+    """gap (with mask sums), residual tail forward / backward, broadcast: bf16 storage vs float64."""
+    from leaffliction_amd import nn
+    n, c, h, w = 3, 32, 8, 12
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn(n, c, h, w, generator=g).to(BF)
+    sc_t = torch.randn(n, c, h, w, generator=g).to(BF)
+    a_s, a_b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    k_s, k_b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    s = torch.rand(n, c, generator=g)
+    drop = (torch.rand(n, c, generator=g) > 0.2).float() / 0.8
+    dev = cuda
+    d = lambda t: t.to(dev)  # noqa: E731
+    # gap + mask sums
+    msum = torch.empty(n, c, 2, device=dev)
+    m = nn.gap_stats_bf16(d(y), scale=d(a_s), shift=d(a_b), relu=True, mask_sums=msum)
+    v = y.float() * a_s.view(1, -1, 1, 1) + a_b.view(1, -1, 1, 1)
+    assert torch.allclose(m.cpu(), torch.relu(v).mean((2, 3)), atol=1e-5)
+    assert torch.equal(msum[..., 0].cpu(), (v > 0).float().sum((2, 3)))
+    assert torch.allclose(msum[..., 1].cpu(), (y.float() * (v > 0)).sum((2, 3)), atol=1e-4)
+    # tail forward
+    pooled = torch.empty(n, c, h // 2, w // 2, dtype=BF, device=dev)
+    route = torch.empty(n, c, h // 2, w // 2, dtype=torch.uint8, device=dev)
+    nn.block_tail_fwd_train_bf16(d(y), d(a_s), d(a_b), d(s), d(sc_t), d(k_s), d(k_b), True, d(drop), route, pooled)
+    a2 = torch.relu(v)
+    shc = torch.relu(sc_t.float() * k_s.view(1, -1, 1, 1) + k_b.view(1, -1, 1, 1))
+    r = torch.relu(shc + a2 * s.view(n, c, 1, 1))
+    mp, idx = F.max_pool2d(r, 2, return_indices=True)
+    ref_p = (mp * drop.view(n, c, 1, 1)).double()
+    close_bf16(pooled, ref_p, 0.01)
+    # tail backward
+    dp = torch.randn(n, c, h // 2, w // 2, generator=g).to(BF)
+    dr = torch.empty(n, c, h, w, dtype=BF, device=dev)
+    ds = torch.empty(n, c, device=dev)
+    psum = torch.empty(n, c, 2, device=dev)
+    ssum = torch.empty(n, c, 2, device=dev)
+    nn.block_tail_bwd_bf16(d(dp), route, d(y), d(a_s), d(a_b), d(drop), dr, ds, psum, d(sc_t), ssum)
+    gq = (dp.float() * drop.view(n, c, 1, 1)).to(BF).float() * (mp > 0)
+    dr_ref = F.max_unpool2d(gq, idx, 2, output_size=(h, w))
+    assert torch.equal(dr.float().cpu(), dr_ref)          # routing + rounding: exact
+    assert torch.allclose(ds.cpu(), (dr_ref * a2).sum((2, 3)), atol=1e-4, rtol=1e-4)
+    on = (v > 0).float()
+    assert torch.allclose(psum[..., 0].cpu(), (dr_ref * on).sum((2, 3)), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(psum[..., 1].cpu(), (dr_ref * on * y.float()).sum((2, 3)), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(ssum[..., 0].cpu(), dr_ref.sum((2, 3)), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(ssum[..., 1].cpu(), (dr_ref * sc_t.float()).sum((2, 3)), atol=1e-4, rtol=1e-4)
+    # broadcast + casts
+    vv = torch.randn(n, c, generator=g)
+    out = torch.empty(n, c, 4, 4, dtype=BF, device=dev)
+    nn.bcast_planes_bf16(d(vv), 4, 4, 1.0 / 16, out)
+    assert torch.equal(out.float().cpu(), (vv / 16).to(BF).float().view(n, c, 1, 1).expand(n, c, 4, 4))
+    f = torch.randn(1000, generator=g)
+    b16 = nn.cast_f32_bf16(d(f), torch.empty(1000, dtype=BF, device=dev))
+    assert torch.equal(b16.cpu(), f.to(BF))
+    assert torch.equal(nn.cast_bf16_f32(b16, torch.empty(1000, device=dev)).cpu(), f.to(BF).float())
+
+
+@pytest.mark.parametrize("size,n,widths,classes", [(32, 8, [32, 64], 4), (64, 4, [32, 64, 128], 3)])
+def test_train_step_bf16_matches_lowp_oracle(cuda, size, n, widths, classes):
+    """One forward/backward of the bf16 step vs the oracle evaluated with bf16 rounding at the same
+    points (cnn_ref.train_step(lowp=True)).  What remains between the two is (1) fp32 accumulation
+    order and (2) one-step bf16 flips of values next to a rounding boundary, each a 2^-9 relative
+    perturbation of one element that the following layers average out; the bounds below are
+    ~4x what these produce at this size (measured), and 10-30x below the distance between the
+    bf16 step and the fp32 step, which the test also reports as the scale of comparison."""
+    from leaffliction_amd import ops
+    from leaffliction_amd.model.cnn import LeafCNN
+    from oracle import cnn_ref as R
+    dev = cuda
+    m = LeafCNN(num_classes=classes, img_size=size, widths=widths, l2_reg=1e-4, use_norm=False, seed=3,
+                device=dev)
+    m.set_training_dtype("bf16")
+    ref_p = {name: m.p[name].detach().cpu().clone() for name, _s, _k in m.specs}
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(0, 256, (n, size, size, 3), dtype=torch.uint8, generator=g)
+    labels = torch.randint(0, classes, (n,), generator=g)
+    onehot = F.one_hot(labels, classes).float()
+    y = R.smooth_labels(onehot, 0.02).to(dev)
+    drops, top = m.draw_dropout(n)
+    x0 = ops.pack_hwc_u8_to_nchw_f32(x.to(dev))
+    probs, loss = m._forward_train_bf16(x0, y, drops, top)
+    m._backward_bf16()
+    torch.cuda.synchronize()
+    args = (x0.cpu(), onehot, widths, [t.cpu() for t in drops], top.cpu())
+    _t, dl_lo, p_lo, g_lo = R.train_step(ref_p, R.init_state(widths), *args, grads_include_l2=False, lowp=True)
+    _t, dl_32, p_32, g_32 = R.train_step(ref_p, R.init_state(widths), *args, grads_include_l2=False)
+    assert (probs.cpu() - p_lo).abs().max().item() < 5e-3
+    assert abs(loss.mean().item() - dl_lo) < 5e-3 * max(1.0, abs(dl_lo))
+    worst = 0.0
+    for name, _s, _k in m.specs:
+        ref = g_lo[name]
+        err = (m.g[name].cpu() - ref).norm().item() / (ref.norm().item() + 1e-12)
+        gap = (g_32[name] - ref).norm().item() / (ref.norm().item() + 1e-12)
+        worst = max(worst, err)
+        # the HIP step must sit much closer to the rounded oracle than the rounded oracle to fp32
+        assert err < max(0.05, 0.5 * gap), (name, err, gap)
+    assert worst < 0.2
+    # and the optimizer step on top of it runs
+    m.train_step(x, y, lr=1e-3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(m.flat_p).all()
