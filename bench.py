@@ -64,7 +64,8 @@ class KernelTimer:
 
         def call(name, *args):
             if not timer.enabled or name not in ("lf_conv2d_f32", "lf_conv2d_stats_f32", "lf_conv2d_bnbwd_f32",
-                                                 "lf_conv2d_wgrad_f32", "lf_conv2d_wgrad_bn_f32"):
+                                                 "lf_conv2d_wgrad_f32", "lf_conv2d_wgrad_bn_f32",
+                                                 "lf_conv2d_bf16_train", "lf_conv2d_wgrad_bf16"):
                 return timer._orig(name, *args)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -72,6 +73,22 @@ class KernelTimer:
             rc = timer._orig(name, *args)
             e1.record()
             lib = timer.lib_mod.load()
+            if name == "lf_conv2d_bf16_train":
+                n, cin, h, w, cout, k = args[4:10]
+                px = n * h * w
+                kname = f"conv_bf16_kernel<{k * k},{'2,2' if cout % 64 == 0 else '1,4'}> {cin}->{cout}@{h}"
+                nbytes = px * ((2.0 if args[1] else 4.0) * cin + 2.0 * cout) + 2.0 * cin * cout * k * k
+                nbytes += 2.0 * px * cout * ((1 if args[13] else 0) + (1 if args[17] else 0))
+                timer.records.append((kname, 2.0 * px * cin * cout * k * k, e0, e1, nbytes))
+                return rc
+            if name == "lf_conv2d_wgrad_bf16":
+                n, cin, h, w, cout, k = args[9:15]
+                px = n * h * w
+                kname = f"wgrad_bf16_kernel<{k * k}> {cin}->{cout}@{h}"
+                nbytes = px * ((4.0 if cin * 9 <= 32 and k == 3 else 2.0) * cin + 2.0 * cout) + 4.0 * cin * cout * k * k
+                nbytes += 2.0 * px * cout * ((1 if args[2] else 0) + (1 if args[7] else 0))
+                timer.records.append((kname, 2.0 * px * cin * cout * k * k, e0, e1, nbytes))
+                return rc
             if name in ("lf_conv2d_f32", "lf_conv2d_stats_f32", "lf_conv2d_bnbwd_f32"):
                 n, cin, h, w, cout, k = args[3:9]
                 kname = FWD_NAMES[lib.lf_conv2d_variant(h, w, cout, k)].replace("T", str(k * k))
@@ -296,6 +313,10 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (the headline line, with the bf16 step as a second mode "
+                         "inside it); bf16 = the mixed-precision step as the headline (configs[3] per-GPU work)")
+    ap.add_argument("--no-bf16", action="store_true", help="f32 run: skip the second (bf16) training mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-augment", action="store_true", help="skip the augmentation-pass measurement")
     ap.add_argument("--no-inference", action="store_true", help="skip the forward-only measurement")
@@ -357,33 +378,99 @@ def main() -> None:
     def lr_at(step):
         return 2e-3 * 0.5 * (1.0 + math.cos(math.pi * min(step, total) / total))
 
-    step = 0
-    for _ in range(args.warmup):
-        model.train_step(x, y, lr_at(step), grad_sync=grad_sync)
-        step += 1
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _probs, loss = model.train_step(x, y, lr_at(step), grad_sync=grad_sync)
-        step += 1
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final_loss = float(loss.mean())
-    if not math.isfinite(final_loss):
-        sys.exit(f"bench.py: non-finite loss {final_loss}")
+    def timed_train(steps, warmup):
+        """`warmup` untimed + exactly `steps` timed training steps between barrier + synchronize
+        pairs; returns (seconds, max over ranks; final mean loss)."""
+        nonlocal step
+        for _ in range(warmup):
+            model.train_step(x, y, lr_at(step), grad_sync=grad_sync)
+            step += 1
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _probs, loss = model.train_step(x, y, lr_at(step), grad_sync=grad_sync)
+            step += 1
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        sec = time.perf_counter() - t0
+        timer.enabled = False
+        if dist is not None:
+            t = torch.tensor([sec], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sec = float(t.item())
+        fl = float(loss.mean())
+        if not math.isfinite(fl):
+            sys.exit(f"bench.py: non-finite loss {fl}")
+        return sec, fl
 
-    if rank == 0:
+    def bf16_report(sec, steps, fl):
+        """The mixed-precision step (BASELINE configs[3]'s per-GPU work): whole-step rate, and for
+        the dominant kernel the HBM roofline (bf16 tensors make every convolution of this network
+        bandwidth-bound: 72 FLOP per algorithmic byte at 224x224 / 32->32 against a ridge of ~310)."""
         kern = timer.summary()
+        timer.records.clear()
+        dname, dk = max(kern.items(), key=lambda kv: kv[1]["seconds"])
+        conv_s = sum(v["seconds"] for v in kern.values())
+        conv_b = sum(v["bytes"] for v in kern.values())
+        conv_f = sum(v["flop"] for v in kern.values())
+        gbs = dk["bytes"] / dk["seconds"] / 1e9
+        return {"images_per_sec": round(world * n * steps / sec, 2), "ms_per_step": round(sec / steps * 1e3, 3),
+                "steps": steps, "dtype": "bf16 storage + bf16 MFMA operands, fp32 accumulate / BN / SE / softmax / "
+                                         "master weights",
+                "step_tflops": round(TRAIN_GFLOP_PER_IMG * n * steps / sec / 1e3, 2),
+                "frac_of_bf16_mfma_peak_2500TF": round(TRAIN_GFLOP_PER_IMG * n * steps / sec / 1e3 / 2500.0, 4),
+                "final_loss": round(fl, 4),
+                "roofline": {"bound": "hbm", "kernel": dname, "achieved": round(gbs, 1), "peak": 8000.0,
+                             "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                             "algorithmic_bytes_per_launch": round(dk["bytes"] / dk["launches"]),
+                             "launches_per_step": dk["launches"] / steps,
+                             "avg_launch_ms": round(dk["seconds"] / dk["launches"] * 1e3, 4),
+                             "tflops": round(dk["flop"] / dk["seconds"] / 1e12, 1)},
+                "conv_all": {"GB_s": round(conv_b / conv_s / 1e9, 1), "tflops": round(conv_f / conv_s / 1e12, 1),
+                             "share_of_step_time": round(conv_s / sec, 4)},
+                "per_kernel": {k: {"ms": round(v["seconds"] / v["launches"] * 1e3, 4),
+                                   "launches_per_step": v["launches"] / steps,
+                                   "GB_s": round(v["bytes"] / v["seconds"] / 1e9, 1),
+                                   "tflops": round(v["flop"] / v["seconds"] / 1e12, 1)}
+                               for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["seconds"])}}
+
+    step = 0
+    bf16 = None
+    if args.dtype == "bf16":
+        model.set_training_dtype("bf16")
+    elapsed, final_loss = timed_train(args.steps, args.warmup)
+    if args.dtype == "bf16":
+        bf16 = bf16_report(elapsed, args.steps, final_loss)
+    elif not args.no_bf16:
+        # second mode: the same step on bf16 storage (its own warm-up: other kernels, other buffers)
+        kern_f32 = timer.summary()
+        timer.records.clear()
+        model.set_training_dtype("bf16")
+        sec16, fl16 = timed_train(args.steps, min(args.warmup, 5))
+        bf16 = bf16_report(sec16, args.steps, fl16)
+        model.set_training_dtype("f32")
+        timer.records.clear()
+
+    if rank == 0 and args.dtype == "bf16":
+        out = {"metric": "224x224 images/sec train", "value": bf16["images_per_sec"], "unit": "images/sec",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": bf16["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic",
+               "config": {"workload": "leaf_cnn base train step, mixed precision (configs[3] per-GPU work: img 224, "
+                                      "batch 256/GPU, bf16, 8 classes, AdamW+clipnorm+EMA, in-model augmentation)",
+                          "per_gpu_batch": n, "global_batch": world * n, "img_size": IMG,
+                          "parallelism": f"dp{world}", "grad_bucket": model.grad_bucket_dtype},
+               "roofline": bf16["roofline"], "conv_all": bf16["conv_all"], "step_tflops": bf16["step_tflops"],
+               "final_loss": bf16["final_loss"], "per_kernel": bf16["per_kernel"]}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    elif rank == 0:
+        kern = kern_f32 if bf16 is not None else timer.summary()
         dom_name, dom = max(kern.items(), key=lambda kv: kv[1]["seconds"])
         achieved = dom["flop"] / dom["seconds"] / 1e12
         conv_s = sum(v["seconds"] for v in kern.values())
@@ -427,6 +514,8 @@ def main() -> None:
             "step_tflops": round(TRAIN_GFLOP_PER_IMG * n * args.steps / elapsed / 1e3, 2),
             "final_loss": round(final_loss, 4),
         }
+        if bf16 is not None:
+            out["train_bf16"] = bf16
         if world == 1 and not args.no_inference:
             out["inference"] = inference_throughput(model, dev)
         if not args.no_augment and world == 1:

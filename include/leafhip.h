@@ -263,13 +263,14 @@ int lf_block_tail_fwd_bf16(const uint16_t* y, const float* a_scale, const float*
  * bf16; x is fp32 (x_bf16 = 0: the normalised network input) or bf16; optional prologue
  * relu?(x*in_scale+in_shift) = the producer's BatchNorm(+ReLU) (cnn.py:30-31); accumulate != 0:
  * y = bf16(conv + y) (residual gradient joins).  tile_part (may be null) receives per-(channel,
- * tile) sums, tile < lf_conv2d_bf16_stats_tiles(n,h,w,cout), layout [cout][tiles][2]:
+ * part) sums, part < lf_conv2d_bf16_stats_tiles(...) — one per tile, or one per workgroup on the
+ * streaming path that serves Cin, Cout <= 64 —, layout [cout][parts][2]:
  *   mask_y == null: BatchNormalization forward statistics {sum (y-pivot), sum (y-pivot)^2}
  *     (feed lf_bn_train_stats_tiles_f32; pivot = the moving mean, may be null);
  *   mask_y != null: the backward sums of the BatchNorm this gradient feeds, {sum d, sum d*mask_y}
  *     with d = y*[mask_y*mask_scale+mask_shift > 0 or !mask_relu] (feed lf_bn_bwd_sums_tiles_f32).
  * Requires w % 4 == 0, cout % 32 == 0, ksize 1 or 3, 16-byte aligned x / wprep. */
-long long lf_conv2d_bf16_stats_tiles(int n, int h, int w, int cout);
+long long lf_conv2d_bf16_stats_tiles(int n, int cin, int h, int w, int cout, int ksize, int x_bf16);
 int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint16_t* y, int n, int cin,
                          int h, int w, int cout, int ksize, const float* in_scale,
                          const float* in_shift, int in_relu, int accumulate, float* tile_part,

@@ -52,7 +52,7 @@ SIGNATURES = {
                            P, P, c_int, P],
     "lf_gap_bf16": [P, P, c_int, c_int, c_int, P, P, c_int, P],
     "lf_block_tail_fwd_bf16": [P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
-    "lf_conv2d_bf16_stats_tiles": [c_int, c_int, c_int, c_int],
+    "lf_conv2d_bf16_stats_tiles": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "lf_conv2d_bf16_train": [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P,
                              c_size_t, P, P, P, P, c_int, P],
     "lf_conv2d_wgrad_bf16_workspace": [c_int, c_int, c_int, c_int, c_int, c_int],

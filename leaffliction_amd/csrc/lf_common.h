@@ -54,6 +54,30 @@ inline bool streaming(size_t bytes_touched) { return bytes_touched >= ((size_t)2
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// lf_conv2d_bf16_train is served by two kernels: the streaming one (lf_conv_bf16s.hip: Cin, Cout <= 64,
+// filter bank resident in LDS, one statistics partial per workgroup) and the K-chunked one
+// (lf_conv_bf16.hip: everything else, one partial per tile).
+struct ConvBf16TrainArgs {
+    const void* x;            // fp32 or bf16 NCHW
+    const uint16_t* wprep;    // bf16 [ceil(cin/16)][taps][cout][16]
+    uint16_t* y;              // bf16 NCHW
+    int n, cin, h, w, cout;
+    const float* in_scale;    // optional prologue relu?(x*scale+shift)
+    const float* in_shift;
+    int in_relu;
+    int accumulate;
+    float* stat_part;         // [cout][stat_tiles][2] or null
+    const float* stat_pivot;
+    long long stat_tiles;
+    const uint16_t* stat_mask_y;
+    const float* mask_scale;
+    const float* mask_shift;
+    int mask_relu;
+    int tiles_x, tiles_y, items, items_per_wg;  // filled by the streaming launcher
+};
+long long conv_bf16s_parts(int n, int cin, int h, int w, int cout, int ksize, int x_bf16);  // 0 = shape not covered
+int conv_bf16s_launch(ConvBf16TrainArgs a, int ksize, int x_bf16, hipStream_t s);
+
 // Tile kernels whose neighbouring tiles share input halos: workgroups are dealt to the eight XCDs
 // round-robin in dispatch order and every XCD has its own L2, so a plain (tile_x, tile_y, image)
 // grid puts horizontally adjacent tiles under different L2s and every halo line is fetched from

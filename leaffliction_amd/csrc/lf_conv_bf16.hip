@@ -548,9 +548,10 @@ int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y
     return lf::check_launch("lf_conv2d_bf16");
 }
 
-long long lf_conv2d_bf16_stats_tiles(int n, int h, int w, int cout) {
-    if (n <= 0 || h <= 0 || w <= 0 || cout <= 0) return 0;
-    return (long long)n * bf16_tiles(h, w, cout);
+long long lf_conv2d_bf16_stats_tiles(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
+    if (n <= 0 || cin <= 0 || h <= 0 || w <= 0 || cout <= 0) return 0;
+    const long long parts = lf::conv_bf16s_parts(n, cin, h, w, cout, ksize, x_bf16);
+    return parts > 0 ? parts : (long long)n * bf16_tiles(h, w, cout);
 }
 
 int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint16_t* y, int n, int cin, int h,
@@ -570,12 +571,24 @@ int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint1
                "lf_conv2d_bf16_train: x and wprep must be 16-byte aligned");
     LF_REQUIRE(mask_y == nullptr || (tile_part && mask_scale && mask_shift),
                "lf_conv2d_bf16_train: mask_y needs tile_part and mask_scale / mask_shift");
+    const long long tiles = lf_conv2d_bf16_stats_tiles(n, cin, h, w, cout, ksize, x_bf16);
     if (tile_part != nullptr) {
-        const size_t need = (size_t)lf_conv2d_bf16_stats_tiles(n, h, w, cout) * (size_t)cout * 2 * sizeof(float);
+        const size_t need = (size_t)tiles * (size_t)cout * 2 * sizeof(float);
         if (tile_part_bytes < need) {
             lf::set_error("lf_conv2d_bf16_train: tile_part %zu bytes < %zu", tile_part_bytes, need);
             return LF_ERR_WORKSPACE;
         }
+    }
+    hipStream_t s = lf::as_stream(stream);
+    if (lf::conv_bf16s_parts(n, cin, h, w, cout, ksize, x_bf16) > 0) {
+        lf::ConvBf16TrainArgs t{};
+        t.x = x; t.wprep = wprep; t.y = y; t.n = n; t.cin = cin; t.h = h; t.w = w; t.cout = cout;
+        t.in_scale = in_scale; t.in_shift = in_shift; t.in_relu = in_relu; t.accumulate = accumulate;
+        t.stat_part = tile_part; t.stat_pivot = pivot; t.stat_mask_y = mask_y;
+        t.mask_scale = mask_scale; t.mask_shift = mask_shift; t.mask_relu = mask_relu;
+        const int rc = lf::conv_bf16s_launch(t, ksize, x_bf16, s);
+        if (rc != LF_OK) return rc;
+        return lf::check_launch("lf_conv2d_bf16_train");
     }
     Bf16ConvArgs a{};
     a.x = x; a.wprep = wprep; a.y = y; a.n = n; a.cin = cin; a.h = h; a.w = w; a.cout = cout;
@@ -583,9 +596,8 @@ int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint1
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
     a.accumulate = accumulate;
     a.stat_part = tile_part; a.stat_pivot = pivot;
-    a.stat_tiles = lf_conv2d_bf16_stats_tiles(n, h, w, cout);
+    a.stat_tiles = tiles;
     a.stat_mask_y = mask_y; a.mask_scale = mask_scale; a.mask_shift = mask_shift; a.mask_relu = mask_relu;
-    hipStream_t s = lf::as_stream(stream);
     if (x_bf16) launch_conv_bf16<true, true, true>(a, ksize, s); else launch_conv_bf16<false, true, true>(a, ksize, s);
     return lf::check_launch("lf_conv2d_bf16_train");
 }

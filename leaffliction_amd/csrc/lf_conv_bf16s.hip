@@ -1,0 +1,476 @@
+// libleafhip — streaming bf16 convolution for the layers that dominate the mixed-precision
+// training step: the 224x224 and 112x112 stages, where Cin and Cout are at most 64 and the
+// tensors are 0.8 - 1.6 GB per batch.  With bf16 storage these convolutions are HBM-bound (72
+// FLOP per byte at 32->32 against a ridge of ~310), so the kernel is organised around the
+// memory stream, not around the MFMA:
+//
+//   * the whole filter bank (<= 36 KB of bf16) is copied into LDS ONCE per workgroup and stays
+//     there; a workgroup then walks a contiguous range of (image, tile) items, so neighbouring
+//     tiles' halo rows are re-read from the XCD's own L2;
+//   * the input patch of the NEXT tile is in flight in registers while the current tile's MFMAs
+//     and epilogue run (all input channels at once: no K-chunk loop, no barrier per chunk);
+//   * the patch sits in LDS as [pixel][channel] rows (64 B per pixel at 32 channels) with the
+//     16-byte channel groups XOR-swizzled by the pixel index: the B operand of a lane (one pixel,
+//     eight consecutive channels) is ONE aligned ds_read_b128 whatever the tap offset, and the
+//     A operand (one output channel, eight input channels of one tap) is one ds_read_b128 of the
+//     resident weights — 3 LDS reads per 2 MFMAs;
+//   * the producer's BatchNorm+ReLU is applied in fp32 while staging (the f32 -> bf16 packing
+//     pairs channels of a pixel, which is the transposition);
+//   * BatchNorm statistics / BatchNorm-backward sums of the rounded output are accumulated per
+//     lane across ALL tiles of the workgroup and reduced once at the end: one partial per
+//     workgroup instead of one per tile.
+//
+// D[row = output channel][col = pixel] on v_mfma_f32_32x32x16_bf16; a lane's two pixel blocks are
+// horizontally ADJACENT pixels (lane l: pixels 2l and 2l+1 of the wave's 64), so every epilogue
+// access is one dword per lane and 128 contiguous bytes per half-wave, and the read-modify-write
+// operands of the epilogue (old value when accumulating, the BatchNorm input for the backward
+// sums) are fetched BEFORE the MFMAs, so no store waits behind a dependent load.  Replaces Conv2D forward and its
+// input-gradient (srcs/model/cnn.py:27-29 under the mixed_float16 policy of train.py:179-190).
+#include "lf_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ float up(unsigned bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ uint16_t down(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v.x = (__bf16)lo;
+    v.y = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+// sum over the 32 lanes of each wave half; the total lands in lane 31 / 63
+__device__ __forceinline__ float half_sum32(float v) {
+    v += dpp_move<0xB1, 0xf>(v);
+    v += dpp_move<0x4E, 0xf>(v);
+    v += dpp_move<0x141, 0xf>(v);
+    v += dpp_move<0x140, 0xf>(v);
+    v += dpp_move<0x142, 0xa>(v);
+    return v;
+}
+
+template <int TAPS, int CI, int NCO, int TW, int TH>
+struct SShape {
+    static constexpr int HALO = TAPS == 9 ? 1 : 0;
+    static constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO, PPIX = PW * PH;
+    static constexpr int ROWB = CI * 2;                     // bytes per pixel row of the patch image
+    static constexpr int R = 256 / ROWB, C = ROWB / 16;    // rows per 256-byte bank window, 16-byte groups per row
+    static constexpr int COUT = 32 * NCO, CH = CI / 16;
+    static constexpr int WBYTES = CH * TAPS * 2 * COUT * 16;
+    static constexpr int PBYTES = PPIX * ROWB;
+    static constexpr int RED = 4 * COUT * 2 * 4;
+    static constexpr int LDS = WBYTES + (PBYTES > RED ? PBYTES : RED);
+};
+
+template <int TAPS, int CI, int NCO, int TW, int TH, bool XBF>
+__global__ __launch_bounds__(kT, 2) void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
+    using S = SShape<TAPS, CI, NCO, TW, TH>;
+    static_assert(TW * TH == 256 && TW % 4 == 0, "tile = 4 waves x 64 pixels, whole 4-pixel groups");
+    static_assert(XBF || CI == 16, "fp32 input: the stem only (3 channels padded to one 16-channel group)");
+    constexpr int HALO = S::HALO, PW = S::PW, PH = S::PH, ROWB = S::ROWB, COUT = S::COUT, CH = S::CH;
+    constexpr int PGS = TW / 4, NB = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* lw = lds;
+    unsigned char* lp = lds + S::WBYTES;
+    __shared__ float lsc[2 * CI];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 31, kh = lane >> 5;
+    const size_t hw = (size_t)p.h * p.w;
+    const bool pro = p.in_scale != nullptr;
+    const int tiles = p.tiles_x * p.tiles_y;
+    const int first = blockIdx.x * p.items_per_wg;
+    const int last = min(first + p.items_per_wg, p.items);
+
+    // ---- one-time: filter bank -> LDS as [chunk][tap][k half][cout][8 channels] (16 B per entry)
+    {
+        constexpr int NW = CH * TAPS * COUT * 2;
+        for (int e = tid; e < NW; e += kT) {
+            const int h2 = e & 1, co = (e >> 1) % COUT, ct = (e >> 1) / COUT;  // ct = chunk * TAPS + tap
+            const lf::u32x4 v = *reinterpret_cast<const lf::u32x4*>(p.wprep + ((size_t)ct * p.cout + co) * 16 + 8 * h2);
+            *reinterpret_cast<lf::u32x4*>(lw + ((ct * 2 + h2) * COUT + co) * 16) = v;
+        }
+        if (pro)
+            for (int c = tid; c < CI; c += kT) {
+                lsc[c] = c < p.cin ? p.in_scale[c] : 1.f;
+                lsc[CI + c] = c < p.cin ? p.in_shift[c] : 0.f;
+            }
+        if (!XBF)  // channels 4..15 of the stem's rows are never written by the staging: zero them once
+            for (int e = tid; e < S::PBYTES / 16; e += kT)
+                *reinterpret_cast<lf::u32x4*>(lp + 16 * e) = lf::u32x4{0u, 0u, 0u, 0u};
+    }
+
+    auto poff = [&](unsigned pp, unsigned c16) -> unsigned {  // byte offset of 16-byte group c16 of patch pixel pp
+        return pp * ROWB + ((c16 ^ ((pp / S::R) % S::C)) << 4);
+    };
+
+    // ---- staging units: 4 channels x 4 pixels (interior), 4 channels x 1 pixel (halo columns)
+    constexpr int QD = XBF ? CI / 4 : 1;  // channel quads that carry data
+    constexpr int NXU = QD * PH * PGS, XPT = (NXU + kT - 1) / kT;
+    constexpr int NHU = QD * PH * 2 * HALO, HPT = (NHU + kT - 1) / kT;
+    u32x2 rx[XBF ? XPT : 1][4];
+    f32x4v rf[XBF ? 1 : XPT][3];
+    unsigned rh[HPT > 0 ? HPT : 1][XBF ? 2 : 3];
+    unsigned xmask = 0, hmask = 0;
+
+    auto tile_of = [&](int item, int& n, int& tx0, int& ty0) {
+        n = item / tiles;
+        const int t = item - n * tiles;
+        tx0 = (t % p.tiles_x) * TW;
+        ty0 = (t / p.tiles_x) * TH;
+    };
+
+    auto issue = [&](int item) {
+        int n, tx0, ty0;
+        tile_of(item, n, tx0, ty0);
+        xmask = hmask = 0;
+        const uint16_t* xb = static_cast<const uint16_t*>(p.x) + (XBF ? (size_t)n * p.cin * hw : 0);
+        const float* xf = static_cast<const float*>(p.x) + (XBF ? 0 : (size_t)n * p.cin * hw);
+#pragma unroll
+        for (int k = 0; k < XPT; ++k) {
+            const int u = tid + k * kT;
+            const int pg = u % PGS, t1 = u / PGS, quad = t1 % QD, pr = t1 / QD;
+            const int gy = ty0 - HALO + pr, gx = tx0 + 4 * pg;
+            const bool ok = u < NXU && gy >= 0 && gy < p.h && gx < p.w && 4 * quad < p.cin;
+            xmask |= (ok ? 1u : 0u) << k;
+            if (!ok) continue;
+            const size_t o = (size_t)(4 * quad) * hw + (size_t)gy * p.w + gx;
+            if (XBF) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rx[k][i] = *reinterpret_cast<const u32x2*>(xb + o + (size_t)i * hw);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (i < p.cin) rf[k][i] = *reinterpret_cast<const f32x4v*>(xf + o + (size_t)i * hw);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) {
+            const int u = tid + k * kT;
+            const int side = u & 1, t1 = u >> 1, quad = t1 % QD, pr = t1 / QD;
+            const int gy = ty0 - HALO + pr, gx = side ? tx0 + TW : tx0 - 1;
+            const bool ok = u < NHU && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w && 4 * quad < p.cin;
+            hmask |= (ok ? 1u : 0u) << k;
+            if (!ok) continue;
+            const size_t o = (size_t)(4 * quad) * hw + (size_t)gy * p.w + gx;
+            if (XBF) {
+                rh[k][0] = (unsigned)xb[o] | (unsigned)xb[o + hw] << 16;
+                rh[k][1] = (unsigned)xb[o + 2 * hw] | (unsigned)xb[o + 3 * hw] << 16;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) rh[k][i] = i < p.cin ? __float_as_uint(xf[o + (size_t)i * hw]) : 0u;
+            }
+        }
+    };
+
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < XPT; ++k) {
+            const int u = tid + k * kT;
+            if (u >= NXU) continue;
+            const int pg = u % PGS, t1 = u / PGS, quad = t1 % QD, pr = t1 / QD;
+            const bool ok = xmask >> k & 1u;
+            float f[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};  // zero padding stays exactly zero
+                if (ok) {
+                    if (XBF) {
+                        v[0] = up(rx[k][i].x & 0xffffu);
+                        v[1] = up(rx[k][i].x >> 16);
+                        v[2] = up(rx[k][i].y & 0xffffu);
+                        v[3] = up(rx[k][i].y >> 16);
+                    } else if (i < 3 && i < p.cin) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = rf[k][i][e];
+                    }
+                    if (pro) {
+                        const float sc = lsc[4 * quad + i], sh = lsc[CI + 4 * quad + i];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = fmaf(v[e], sc, sh);
+                            if (p.in_relu) v[e] = fmaxf(v[e], 0.f);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[i][e] = v[e];
+            }
+            const unsigned pi = (unsigned)(pr * PW + HALO + 4 * pg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32x2 o;
+                o.x = pack2(f[0][e], f[1][e]);
+                o.y = pack2(f[2][e], f[3][e]);
+                *reinterpret_cast<u32x2*>(lp + poff(pi + e, (unsigned)quad >> 1) + 8 * (quad & 1)) = o;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) {
+            const int u = tid + k * kT;
+            if (u >= NHU) continue;
+            const int side = u & 1, t1 = u >> 1, quad = t1 % QD, pr = t1 / QD;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (hmask >> k & 1u) {
+                if (XBF) {
+                    v[0] = up(rh[k][0] & 0xffffu);
+                    v[1] = up(rh[k][0] >> 16);
+                    v[2] = up(rh[k][1] & 0xffffu);
+                    v[3] = up(rh[k][1] >> 16);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) v[i] = __uint_as_float(rh[k][i]);
+                }
+                if (pro)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = fmaf(v[i], lsc[4 * quad + i], lsc[CI + 4 * quad + i]);
+                        if (p.in_relu) v[i] = fmaxf(v[i], 0.f);
+                    }
+                if (!XBF) v[3] = 0.f;
+            }
+            u32x2 o;
+            o.x = pack2(v[0], v[1]);
+            o.y = pack2(v[2], v[3]);
+            const unsigned pi = (unsigned)(pr * PW + (side ? PW - 1 : 0));
+            *reinterpret_cast<u32x2*>(lp + poff(pi, (unsigned)quad >> 1) + 8 * (quad & 1)) = o;
+        }
+    };
+
+    // per-lane geometry: the wave owns 64 consecutive flat tile positions; lane px holds positions
+    // 2*px (block 0) and 2*px + 1 (block 1): the same row, adjacent columns
+    const int f0 = 64 * wv + 2 * px;
+    const int prow = f0 / TW, pcol = f0 - prow * TW;
+    const unsigned pp0 = (unsigned)(prow * PW + pcol);
+
+    // per-channel epilogue constants in LDS (pivot | mask scale, mask shift)
+    __shared__ float lst[2 * COUT];
+    const bool stats = p.stat_part != nullptr, masked = p.stat_mask_y != nullptr;
+    for (int c = tid; c < COUT; c += kT) {
+        lst[c] = masked ? p.mask_scale[c] : ((stats && p.stat_pivot != nullptr) ? p.stat_pivot[c] : 0.f);
+        lst[COUT + c] = masked ? p.mask_shift[c] : 0.f;
+    }
+
+    f32x16 acc[NB][NCO];
+    float s1[NCO][16], s2[NCO][16];  // running channel sums of this lane over all its pixels and tiles
+#pragma unroll
+    for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1[cb][r] = s2[cb][r] = 0.f;
+    unsigned rold[NCO][16], rmask[NCO][16];  // the lane's pixel pair of each channel, as stored
+
+    if (first < last) issue(first);
+    for (int item = first; item < last; ++item) {
+        __syncthreads();  // the previous tile's operand reads are done (first pass: weights / lsc / lst staged)
+        commit();
+        if (item + 1 < last) issue(item + 1);  // in flight during the MFMAs and the epilogue
+        // the epilogue's read-modify-write operands: requested now, consumed after the MFMAs
+        int n, tx0, ty0;
+        tile_of(item, n, tx0, ty0);
+        uint16_t* yb = p.y + (size_t)n * p.cout * hw;
+        const int gy = ty0 + prow, gx = tx0 + pcol;
+        const bool ok = gy < p.h && gx < p.w;  // the pair is inside or outside as a whole (w % 4 == 0, gx even)
+        const unsigned po = ok ? (unsigned)gy * (unsigned)p.w + (unsigned)gx : 0u;
+        if (p.accumulate) {
+#pragma unroll
+            for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    rold[cb][r] = *reinterpret_cast<const unsigned*>(yb + (size_t)co * hw + po);
+                }
+        }
+        if (masked) {
+            const uint16_t* my = p.stat_mask_y + (size_t)n * p.cout * hw;
+#pragma unroll
+            for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    rmask[cb][r] = *reinterpret_cast<const unsigned*>(my + (size_t)co * hw + po);
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][cb][r] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int dy = TAPS == 9 ? t / 3 : 0, dx = TAPS == 9 ? t % 3 : 0;
+                bf16x8 A[NCO], B[NB];
+#pragma unroll
+                for (int cb = 0; cb < NCO; ++cb)
+                    A[cb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const lf::u32x4*>(
+                        lw + ((((ch * TAPS + t) * 2 + kh) * COUT) + cb * 32 + px) * 16));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    B[nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const lf::u32x4*>(
+                        lp + poff(pp0 + (unsigned)(dy * PW + dx + nb), (unsigned)(2 * ch + kh))));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int cb = 0; cb < NCO; ++cb)
+                        acc[nb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cb], B[nb], acc[nb][cb], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: bf16 pair store (optionally on top of the old values) + sums of the rounded values
+#pragma unroll
+        for (int cb = 0; cb < NCO; ++cb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                float v0 = acc[0][cb][r], v1 = acc[1][cb][r];
+                if (p.accumulate) {
+                    v0 += up(rold[cb][r] & 0xffffu);
+                    v1 += up(rold[cb][r] >> 16);
+                }
+                const unsigned vb = pack2(v0, v1);
+                if (ok) *reinterpret_cast<unsigned*>(yb + (size_t)co * hw + po) = vb;
+                if (!stats) continue;
+                const float r0 = up(vb & 0xffffu), r1 = up(vb >> 16);
+                if (!masked) {
+                    const float pv = lst[co];
+                    const float d0 = ok ? r0 - pv : 0.f, d1 = ok ? r1 - pv : 0.f;
+                    s1[cb][r] += d0 + d1;
+                    s2[cb][r] = fmaf(d1, d1, fmaf(d0, d0, s2[cb][r]));
+                } else {
+                    const float msc = lst[co], msh = lst[COUT + co];
+                    const float y0 = up(rmask[cb][r] & 0xffffu), y1 = up(rmask[cb][r] >> 16);
+                    const float d0 = (ok && (!p.mask_relu || fmaf(y0, msc, msh) > 0.f)) ? r0 : 0.f;
+                    const float d1 = (ok && (!p.mask_relu || fmaf(y1, msc, msh) > 0.f)) ? r1 : 0.f;
+                    s1[cb][r] += d0 + d1;
+                    s2[cb][r] = fmaf(d1, y1, fmaf(d0, y0, s2[cb][r]));
+                }
+            }
+        }
+    }
+    if (stats) {
+        // one partial per workgroup: lanes -> half-wave sums -> the four waves through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lp);  // [4 waves][COUT][2]
+#pragma unroll
+        for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = half_sum32(s1[cb][r]), b = half_sum32(s2[cb][r]);
+                if (px == 31) {
+                    const int col = cb * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    red[(wv * COUT + col) * 2] = a;
+                    red[(wv * COUT + col) * 2 + 1] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < COUT) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                a += red[(w4 * COUT + tid) * 2];
+                b += red[(w4 * COUT + tid) * 2 + 1];
+            }
+            float* dst = p.stat_part + ((size_t)tid * (size_t)p.stat_tiles + blockIdx.x) * 2;
+            dst[0] = a;
+            dst[1] = b;
+        }
+    }
+}
+
+struct SPlan {
+    bool ok;
+    int ci, nco, tw, th, tiles_x, tiles_y, items, wgs, items_per_wg;
+};
+
+SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
+    SPlan pl{};
+    pl.ok = false;
+    if (cout != 32 && cout != 64) return pl;
+    if (!x_bf16) {
+        if (cin > 3 || ksize != 3 || cout != 32) return pl;
+        pl.ci = 16;
+    } else {
+        if (cin != 32 && cin != 64) return pl;
+        pl.ci = cin;
+    }
+    pl.nco = cout / 32;
+    if (pl.ci == 64 && pl.nco == 2) return pl;             // 74 KB of weights: not resident (old kernel)
+    if (ksize == 1 && !(pl.ci == 32 && pl.nco == 2) && !(pl.ci == 64 && pl.nco == 1)) return pl;
+    if (w % 32 == 0 || w > 128) { pl.tw = 32; pl.th = 8; } else { pl.tw = 16; pl.th = 16; }
+    pl.tiles_x = (w + pl.tw - 1) / pl.tw;
+    pl.tiles_y = (h + pl.th - 1) / pl.th;
+    pl.items = n * pl.tiles_x * pl.tiles_y;
+    int wgs = 256 * 2;
+    if (wgs > pl.items) wgs = pl.items;
+    pl.items_per_wg = (pl.items + wgs - 1) / wgs;
+    pl.wgs = (pl.items + pl.items_per_wg - 1) / pl.items_per_wg;
+    pl.ok = true;
+    return pl;
+}
+
+template <int TAPS, int CI, int NCO, int TW, int TH, bool XBF>
+int launch_s(const lf::ConvBf16TrainArgs& a, int wgs, hipStream_t s) {
+    using S = SShape<TAPS, CI, NCO, TW, TH>;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s_kernel<TAPS, CI, NCO, TW, TH, XBF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess) {
+            lf::set_error("lf_conv2d_bf16_train: cannot reserve %d bytes of LDS", S::LDS);
+            return LF_ERR_LAUNCH;
+        }
+        raised = true;
+    }
+    conv_bf16s_kernel<TAPS, CI, NCO, TW, TH, XBF><<<wgs, kT, S::LDS, s>>>(a);
+    return LF_OK;
+}
+
+template <int TW, int TH>
+int dispatch_s(const SPlan& pl, int ksize, const lf::ConvBf16TrainArgs& a, hipStream_t s) {
+    if (pl.ci == 16) return launch_s<9, 16, 1, TW, TH, false>(a, pl.wgs, s);
+    if (ksize == 3) {
+        if (pl.ci == 32 && pl.nco == 1) return launch_s<9, 32, 1, TW, TH, true>(a, pl.wgs, s);
+        if (pl.ci == 32 && pl.nco == 2) return launch_s<9, 32, 2, TW, TH, true>(a, pl.wgs, s);
+        if (pl.ci == 64 && pl.nco == 1) return launch_s<9, 64, 1, TW, TH, true>(a, pl.wgs, s);
+    } else {
+        if (pl.ci == 32 && pl.nco == 2) return launch_s<1, 32, 2, TW, TH, true>(a, pl.wgs, s);
+        if (pl.ci == 64 && pl.nco == 1) return launch_s<1, 64, 1, TW, TH, true>(a, pl.wgs, s);
+    }
+    lf::set_error("lf_conv2d_bf16_train: no streaming kernel for cin %d nco %d ksize %d", pl.ci, pl.nco, ksize);
+    return LF_ERR_INVALID;
+}
+
+}  // namespace
+
+namespace lf {
+
+long long conv_bf16s_parts(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
+    const SPlan pl = plan_s(n, cin, h, w, cout, ksize, x_bf16);
+    return pl.ok ? pl.wgs : 0;
+}
+
+int conv_bf16s_launch(ConvBf16TrainArgs a, int ksize, int x_bf16, hipStream_t s) {
+    const SPlan pl = plan_s(a.n, a.cin, a.h, a.w, a.cout, ksize, x_bf16);
+    if (!pl.ok) {
+        set_error("lf_conv2d_bf16_train: shape not covered by the streaming kernel");
+        return LF_ERR_INVALID;
+    }
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.items = pl.items; a.items_per_wg = pl.items_per_wg;
+    a.stat_tiles = pl.wgs;
+    return pl.tw == 32 ? dispatch_s<32, 8>(pl, ksize, a, s) : dispatch_s<16, 16>(pl, ksize, a, s);
+}
+
+}  // namespace lf

@@ -176,7 +176,7 @@ def conv2d_bf16_train(x: torch.Tensor, wprep: torch.Tensor, cout: int, ksize: in
             raise ValueError("conv2d_bf16_train: mask shape mismatch")
         stats = True
     if stats:
-        tiles = int(_lib.load().lf_conv2d_bf16_stats_tiles(n, h, w, cout))
+        tiles = int(_lib.load().lf_conv2d_bf16_stats_tiles(n, cin, h, w, cout, ksize, 1 if x.dtype == _BF16 else 0))
         tp = _workspace(tiles * cout * 8, x.device, slot=1)
     _lib.call("lf_conv2d_bf16_train", x.data_ptr(), 1 if x.dtype == _BF16 else 0, wprep.data_ptr(),
               out.data_ptr(), n, cin, h, w, cout, ksize, _ptr(in_scale), _ptr(in_shift),

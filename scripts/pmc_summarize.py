@@ -32,8 +32,12 @@ def main() -> None:
     args = sys.argv[1:]
     out_csv = Path(args.pop(0))
     js = None
+    source = None
     if args and args[0] == "--json":
         js = Path(args[1])
+        args = args[2:]
+    if args and args[0] == "--source":   # recorded in the JSON: the command the counters come from
+        source = args[1]
         args = args[2:]
     agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     dur = defaultdict(lambda: [0.0, 0])
@@ -68,6 +72,16 @@ def main() -> None:
                 f = agg[k]["FETCH_SIZE"][0] / agg[k]["FETCH_SIZE"][1]
                 wv = agg[k]["WRITE_SIZE"][0] / agg[k]["WRITE_SIZE"][1]
                 traffic[k] = round((2.0 * f + wv) * 1024.0)
+        if source is not None:
+            import subprocess
+            try:
+                head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                      timeout=10).stdout.strip() or "unknown (no .git on the GPU box)"
+            except Exception:
+                head = "unknown"
+            traffic["_source"] = {"command": source, "git_head": head,
+                                  "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch (gfx950 FETCH_SIZE "
+                                             "correction, MI355X_MICROARCH.md HBM section); separate --pmc passes"}
         js.write_text(json.dumps(traffic, indent=1, sort_keys=True) + "\n")
 
 
