@@ -20,9 +20,10 @@
 // The step is HBM-bound, not MFMA-bound (bf16 tensors: 72 FLOP per byte moved at 224x224 /
 // 32->32): the kernel reads A, the upstream gradient g and the BatchNorm input y once, writes
 // dY once, and keeps two tiles ahead of the MFMAs: LDS is double-buffered (one barrier per tile)
-// and the loads of the tile after next are in flight in registers.  A 3x3 workgroup is 12 waves,
-// wave (filter row, sub-block / K share): 48 accumulator registers per wave instead of 144, which
-// is what leaves room for the loads in flight.
+// and the loads of the tile after next are in flight in registers.  A 3x3 workgroup is 6 waves,
+// wave (filter row, sub-block / K share): 48-96 accumulator registers per wave instead of 144-576,
+// and at most two waves per SIMD, which is what leaves room for the loads in flight (48 registers
+// of raw bf16 per thread with 16-byte accesses).
 //
 // Partial sums: every workgroup owns a (32*CIB x 32*COB) weight block and a range of (image,
 // tile) items and writes one fp32 slab; lf_slab_reduce_f32 adds the slabs in a fixed order
@@ -85,18 +86,28 @@ struct WgShape {
     static constexpr int RED = TAPS * 16 * 64 * 4;    // the accumulators of one sub-block's waves
     static constexpr int LDS = 2 * BUF > RED ? 2 * BUF : RED;
     static constexpr int ROWS = TAPS == 9 ? 3 : 1;    // filter rows spread over waves
-    static constexpr int NT = 64 * 4 * ROWS;
+    // waves per filter row (they split the sub-blocks / K): 3x3 with one or two sub-blocks runs 6
+    // waves (<= 2 per SIMD: 256 registers each), 2x2 sub-blocks 12 waves (one sub-block each)
+    static constexpr int WPR = TAPS == 9 ? (CIB * COB == 4 ? 4 : 2) : 4;
+    static constexpr int NT = 64 * WPR * ROWS;
 };
 
-template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM>
+// G = pixels per staging unit: 8 (16-byte global accesses: the vector memory pipe moves ~5.3 TB/s
+// with 16-byte lanes, ~3 TB/s with 8-byte lanes, ~1.5 TB/s with 4-byte lanes —
+// scripts/microbench/seg_bw.hip) when rows are 16-byte aligned (w % 8 == 0), else 4.
+template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM, int G>
 __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) void wgrad_bf16_kernel(WgBf16Args p) {
     using S = WgShape<TAPS, TW, TH, CIB, COB, STEM>;
+    static_assert((G == 4 || G == 8) && TW % G == 0, "staging groups of 4 or 8 pixels");
+    typedef unsigned uvec __attribute__((ext_vector_type(G / 2)));   // G bf16
     constexpr int kT = S::NT, ROWS = S::ROWS, TPW = TAPS / ROWS;  // taps per wave
     static_assert(TW % 4 == 0 && (TW * TH) % 16 == 0, "tile: whole 4-pixel groups, whole 16-pixel k-steps");
     static_assert(!STEM || (TAPS == 1 && CIB == 1 && TW * TH == kT), "stem: one thread per pixel");
     constexpr int HALO = S::HALO, PW = S::PW, PH = S::PH;
-    constexpr int PGS = TW / 4;
-    constexpr int NQ = CIB * COB, KSPL = 4 / NQ;
+    constexpr int PGS = TW / G;
+    constexpr int NQ = CIB * COB, WPR = S::WPR;
+    constexpr int SBW = NQ > WPR ? NQ / WPR : 1;   // sub-blocks per wave
+    constexpr int KSPL = WPR > NQ ? WPR / NQ : 1;  // K shares per sub-block
     static_assert(NQ == 1 || NQ == 2 || NQ == 4, "wave decomposition");
     constexpr int NS = TW * TH / 16;  // k-steps per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -105,8 +116,8 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) voi
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tr = wv % ROWS, wrest = wv / ROWS;  // filter row of this wave; its (sub-block, K share)
-    const int q = wrest % NQ, ks = wrest / NQ;
-    const int cib = q % CIB, cob = q / CIB;
+    const int q0 = NQ >= WPR ? wrest * SBW : wrest % NQ;  // first sub-block of this wave
+    const int ks = NQ >= WPR ? 0 : wrest / NQ;
     const int ci0 = blockIdx.y * (32 * CIB), co0 = blockIdx.z * (32 * COB);
     const size_t hw = (size_t)p.h * p.w;
     const bool bn = p.bn_y != nullptr;
@@ -124,18 +135,20 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) voi
             lsc[32 * CIB + c] = in ? p.in_shift[ci0 + c] : 0.f;
         }
 
-    f32x16 acc[TPW];
+    f32x16 acc[SBW][TPW];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
+    for (int b = 0; b < SBW; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
 
-    // ---- staging units: 4 channels x 4 pixels (8-byte loads per channel, 8-byte LDS stores per pixel)
+    // ---- staging units: 4 channels x G pixels (one 2G-byte load per channel, 8-byte LDS stores per pixel)
     constexpr int NDU = COB * 8 * TH * PGS, DPT = (NDU + kT - 1) / kT;
     constexpr int NXU = STEM ? 0 : CIB * 8 * PH * PGS, XPT = (NXU + kT - 1) / kT;
     constexpr int NHU = STEM ? 0 : CIB * 8 * PH * 2 * HALO, HPT = (NHU + kT - 1) / kT;
-    u32x2 rg[DPT][4], ry[DPT][4];
-    u32x2 rx[XPT > 0 ? XPT : 1][4];
+    uvec rg[DPT][4], ry[DPT][4];
+    uvec rx[XPT > 0 ? XPT : 1][4];
     unsigned rh[HPT > 0 ? HPT : 1][2];
     float rs[STEM ? 27 : 1];
     unsigned dmask = 0, xmask = 0, hmask = 0;  // bit k: unit k lies inside the image
@@ -161,16 +174,16 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) voi
         for (int k = 0; k < DPT; ++k) {
             const int u = tid + k * kT;
             const int pg = u % PGS, t1 = u / PGS, quad = t1 % (8 * COB), row = t1 / (8 * COB);
-            const int gy = ty0 + row, gx = tx0 + 4 * pg;
+            const int gy = ty0 + row, gx = tx0 + G * pg;
             const bool ok = u < NDU && gy < p.h && gx < p.w;
             dmask |= (ok ? 1u : 0u) << k;
             if (!ok) continue;
             const size_t o = (size_t)(co0 + 4 * quad) * hw + (size_t)gy * p.w + gx;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rg[k][i] = *reinterpret_cast<const u32x2*>(gn + o + (size_t)i * hw);
+            for (int i = 0; i < 4; ++i) rg[k][i] = *reinterpret_cast<const uvec*>(gn + o + (size_t)i * hw);
             if (bn)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ry[k][i] = *reinterpret_cast<const u32x2*>(yn + o + (size_t)i * hw);
+                for (int i = 0; i < 4; ++i) ry[k][i] = *reinterpret_cast<const uvec*>(yn + o + (size_t)i * hw);
         }
         if (STEM) {
             // one thread per pixel: its 3x3 neighbourhood in every input channel (fp32 input)
@@ -190,13 +203,13 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) voi
             for (int k = 0; k < XPT; ++k) {
                 const int u = tid + k * kT;
                 const int pg = u % PGS, t1 = u / PGS, quad = t1 % (8 * CIB), pr = t1 / (8 * CIB);
-                const int gy = ty0 - HALO + pr, gx = tx0 + 4 * pg;
+                const int gy = ty0 - HALO + pr, gx = tx0 + G * pg;
                 const bool ok = u < NXU && gy >= 0 && gy < p.h && gx < p.w && ci0 + 4 * quad < p.cin;
                 xmask |= (ok ? 1u : 0u) << k;
                 if (!ok) continue;
                 const size_t o = (size_t)(ci0 + 4 * quad) * hw + (size_t)gy * p.w + gx;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rx[k][i] = *reinterpret_cast<const u32x2*>(xn + o + (size_t)i * hw);
+                for (int i = 0; i < 4; ++i) rx[k][i] = *reinterpret_cast<const uvec*>(xn + o + (size_t)i * hw);
             }
 #pragma unroll
             for (int k = 0; k < HPT; ++k) {
@@ -225,53 +238,54 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) voi
             if (u >= NDU) continue;
             const int pg = u % PGS, t1 = u / PGS, quad = t1 % (8 * COB), row = t1 / (8 * COB);
             const bool ok = dmask >> k & 1u;
-            float f[4][4];
+            // channel by channel (few live registers): dY of the channel's G pixels -> dy_out as it
+            // stands; every second channel the pair (c-1, c) goes to LDS, one dword per pixel
+            unsigned char* img = ld + (quad >> 3) * (S::DPIX * 64);
+            const unsigned pd = (unsigned)(row * TW + G * pg);
+            float prev[G];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = 4 * quad + i;  // channel inside the workgroup's block
-                float gv[4] = {0.f, 0.f, 0.f, 0.f};
+                float gv[G];
+#pragma unroll
+                for (int e = 0; e < G; ++e) gv[e] = 0.f;
                 if (ok) {
-                    gv[0] = up(rg[k][i].x & 0xffffu);
-                    gv[1] = up(rg[k][i].x >> 16);
-                    gv[2] = up(rg[k][i].y & 0xffffu);
-                    gv[3] = up(rg[k][i].y >> 16);
+#pragma unroll
+                    for (int e = 0; e < G; e += 2) {
+                        gv[e] = up(rg[k][i][e / 2] & 0xffffu);
+                        gv[e + 1] = up(rg[k][i][e / 2] >> 16);
+                    }
                     if (bn) {
-                        const float yv[4] = {up(ry[k][i].x & 0xffffu), up(ry[k][i].x >> 16),
-                                             up(ry[k][i].y & 0xffffu), up(ry[k][i].y >> 16)};
                         const float c0 = lbn[c], c1 = lbn[32 * COB + c], c2 = lbn[64 * COB + c],
                                     c3 = lbn[96 * COB + c], c4 = lbn[128 * COB + c];
                         const float al = p.bn_alpha ? p.bn_alpha[(size_t)n * p.cout + co0 + c] : 1.f;
                         const float ad = p.bn_add ? p.bn_add[(size_t)n * p.cout + co0 + c] : 0.f;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
+                        for (int e = 0; e < G; ++e) {
+                            const unsigned yw = ry[k][i][e / 2];
+                            const float yv = up((e & 1) ? yw >> 16 : yw & 0xffffu);
                             float dz = fmaf(gv[e], al, ad);
-                            if (p.bn_relu && !(fmaf(yv[e], c0, c1) > 0.f)) dz = 0.f;
-                            gv[e] = fmaf(c2, dz, fmaf(c3, yv[e], c4));
+                            if (p.bn_relu && !(fmaf(yv, c0, c1) > 0.f)) dz = 0.f;
+                            gv[e] = fmaf(c2, dz, fmaf(c3, yv, c4));
+                        }
+                        if (p.dy_out != nullptr && blockIdx.y == 0) {
+                            uvec o;
+#pragma unroll
+                            for (int e = 0; e < G; e += 2) o[e / 2] = pack2(gv[e], gv[e + 1]);
+                            *reinterpret_cast<uvec*>(p.dy_out + ((size_t)n * p.cout + co0 + c) * hw +
+                                                     (size_t)(ty0 + row) * p.w + tx0 + G * pg) = o;
                         }
                     }
                 }
+                if (i & 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f[i][e] = gv[e];
-            }
-            if (bn && ok && p.dy_out != nullptr && blockIdx.y == 0) {
-                uint16_t* dst = p.dy_out + ((size_t)n * p.cout + co0 + 4 * quad) * hw +
-                                (size_t)(ty0 + row) * p.w + tx0 + 4 * pg;
+                    for (int e = 0; e < G; ++e)
+                        *reinterpret_cast<unsigned*>(img + img_off(pd + e, quad & 7) + 4 * (i >> 1)) =
+                            pack2(prev[e], gv[e]);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    u32x2 o;
-                    o.x = pack2(f[i][0], f[i][1]);
-                    o.y = pack2(f[i][2], f[i][3]);
-                    *reinterpret_cast<u32x2*>(dst + (size_t)i * hw) = o;
+                    for (int e = 0; e < G; ++e) prev[e] = gv[e];
                 }
-            }
-            unsigned char* img = ld + (quad >> 3) * (S::DPIX * 64);
-            const unsigned pd = (unsigned)(row * TW + 4 * pg);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u32x2 o;
-                o.x = pack2(f[0][e], f[1][e]);
-                o.y = pack2(f[2][e], f[3][e]);
-                *reinterpret_cast<u32x2*>(img + img_off(pd + e, quad & 7)) = o;
             }
         }
         if (STEM) {
@@ -294,35 +308,38 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) voi
                 if (u >= NXU) continue;
                 const int pg = u % PGS, t1 = u / PGS, quad = t1 % (8 * CIB), pr = t1 / (8 * CIB);
                 const bool ok = xmask >> k & 1u;
-                float f[4][4];
+                unsigned char* img = lx + (quad >> 3) * (S::XPIX * 64);
+                const unsigned pi = (unsigned)(pr * PW + HALO + G * pg);
+                float prev[G];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};  // zero padding stays zero
+                    float v[G];
+#pragma unroll
+                    for (int e = 0; e < G; ++e) v[e] = 0.f;  // zero padding stays zero
                     if (ok) {
-                        v[0] = up(rx[k][i].x & 0xffffu);
-                        v[1] = up(rx[k][i].x >> 16);
-                        v[2] = up(rx[k][i].y & 0xffffu);
-                        v[3] = up(rx[k][i].y >> 16);
+#pragma unroll
+                        for (int e = 0; e < G; e += 2) {
+                            v[e] = up(rx[k][i][e / 2] & 0xffffu);
+                            v[e + 1] = up(rx[k][i][e / 2] >> 16);
+                        }
                         if (pro) {
                             const float sc = lsc[4 * quad + i], sh = lsc[32 * CIB + 4 * quad + i];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
+                            for (int e = 0; e < G; ++e) {
                                 v[e] = fmaf(v[e], sc, sh);
                                 if (p.in_relu) v[e] = fmaxf(v[e], 0.f);
                             }
                         }
                     }
+                    if (i & 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) f[i][e] = v[e];
-                }
-                unsigned char* img = lx + (quad >> 3) * (S::XPIX * 64);
-                const unsigned pi = (unsigned)(pr * PW + HALO + 4 * pg);
+                        for (int e = 0; e < G; ++e)
+                            *reinterpret_cast<unsigned*>(img + img_off(pi + e, quad & 7) + 4 * (i >> 1)) =
+                                pack2(prev[e], v[e]);
+                    } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    u32x2 o;
-                    o.x = pack2(f[0][e], f[1][e]);
-                    o.y = pack2(f[2][e], f[3][e]);
-                    *reinterpret_cast<u32x2*>(img + img_off(pi + e, quad & 7)) = o;
+                        for (int e = 0; e < G; ++e) prev[e] = v[e];
+                    }
                 }
             }
 #pragma unroll
@@ -369,19 +386,31 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) voi
         return __builtin_bit_cast(bf16x8, v);
     };
     auto compute = [&](int buf) {
-        const unsigned char* ximg = lds + buf * S::BUF + cib * (S::XPIX * 64);
-        const unsigned char* dimg = lds + buf * S::BUF + S::XBYTES + cob * (S::DPIX * 64);
+        const unsigned char* xb = lds + buf * S::BUF;
+        const unsigned char* db = xb + S::XBYTES;
 #pragma unroll 1
         for (int s = ks; s < NS; s += KSPL) {
             const int f0 = 16 * s + 8 * kh, f1 = f0 + 4;  // flat tile positions of the lane's two groups
             const int r0 = f0 / TW, c0 = f0 - r0 * TW, r1 = f1 / TW, c1 = f1 - r1 * TW;
-            const bf16x8 B = frag(dimg, (unsigned)f0, (unsigned)f1);
+            // the wave's sub-blocks q0 .. q0+SBW-1 = (cib, cob) pairs, cib fastest: with SBW = 2 they
+            // share cob (one B operand) when CIB = 2
+            bf16x8 B[SBW];
+#pragma unroll
+            for (int b = 0; b < SBW; ++b) {
+                const int cob = (q0 + b) / CIB;
+                if (b == 0 || CIB == 1) B[b] = frag(db + cob * (S::DPIX * 64), (unsigned)f0, (unsigned)f1);
+                else B[b] = B[0];
+            }
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int dy = TAPS == 9 ? tr : 0, dx = t;
-                const bf16x8 A = frag(ximg, (unsigned)((r0 + dy) * PW + c0 + dx),
-                                      (unsigned)((r1 + dy) * PW + c1 + dx));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < SBW; ++b) {
+                    const int cib = (q0 + b) % CIB;
+                    const bf16x8 A = frag(xb + cib * (S::XPIX * 64), (unsigned)((r0 + dy) * PW + c0 + dx),
+                                          (unsigned)((r1 + dy) * PW + c1 + dx));
+                    acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[b], acc[b][t], 0, 0, 0);
+                }
             }
         }
     };
@@ -407,48 +436,53 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) voi
         cur ^= 1;
     }
 
-    // K-split partner waves fold into k = 0 through LDS, one (ci, co) sub-block per round (fixed order)
+    // K-split partner waves (only when a sub-block has several: SBW == 1) fold into k = 0 through
+    // LDS, one (ci, co) sub-block per round (fixed order)
     float* red = reinterpret_cast<float*>(lds);
 #pragma unroll 1
     for (int k = 1; k < KSPL; ++k) {
 #pragma unroll 1
         for (int qq = 0; qq < NQ; ++qq) {
             __syncthreads();
-            if (ks == k && q == qq) {
+            if (ks == k && q0 == qq) {
 #pragma unroll
                 for (int t = 0; t < TPW; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) red[((tr * TPW + t) * 16 + r) * 64 + lane] = acc[t][r];
+                    for (int r = 0; r < 16; ++r) red[((tr * TPW + t) * 16 + r) * 64 + lane] = acc[0][t][r];
             }
             __syncthreads();
-            if (ks == 0 && q == qq) {
+            if (ks == 0 && q0 == qq) {
 #pragma unroll
                 for (int t = 0; t < TPW; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] += red[((tr * TPW + t) * 16 + r) * 64 + lane];
+                    for (int r = 0; r < 16; ++r) acc[0][t][r] += red[((tr * TPW + t) * 16 + r) * 64 + lane];
             }
         }
     }
     if (ks == 0) {
         // D[row = A channel][col = dY channel]: register r of a lane is row (r&3) + 8*(r>>2) + 4*(lane>>5)
-        const int co = co0 + cob * 32 + (lane & 31);
-        if (STEM) {
-            float* out = p.part + (size_t)blockIdx.x * p.cin * 9 * p.cout;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kidx = (r & 3) + 8 * (r >> 2) + 4 * kh;  // = ci*9 + tap
-                if (kidx < p.cin * 9 && co < p.cout) out[(size_t)kidx * p.cout + co] = acc[0][r];
-            }
-        } else {
-            float* out = p.part + (size_t)blockIdx.x * p.cin * TAPS * p.cout;
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
+        for (int b = 0; b < SBW; ++b) {
+            const int cib = (q0 + b) % CIB, cob = (q0 + b) / CIB;
+            const int co = co0 + cob * 32 + (lane & 31);
+            if (STEM) {
+                float* out = p.part + (size_t)blockIdx.x * p.cin * 9 * p.cout;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ci = ci0 + cib * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (ci < p.cin && co < p.cout)
-                        out[((size_t)ci * TAPS + tr * TPW + t) * p.cout + co] = acc[t][r];
+                    const int kidx = (r & 3) + 8 * (r >> 2) + 4 * kh;  // = ci*9 + tap
+                    if (kidx < p.cin * 9 && co < p.cout) out[(size_t)kidx * p.cout + co] = acc[b][0][r];
                 }
+            } else {
+                float* out = p.part + (size_t)blockIdx.x * p.cin * TAPS * p.cout;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ci = ci0 + cib * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        if (ci < p.cin && co < p.cout)
+                            out[((size_t)ci * TAPS + tr * TPW + t) * p.cout + co] = acc[b][t][r];
+                    }
+            }
         }
     }
 }
@@ -504,35 +538,40 @@ WgBf16Plan plan_wgrad_bf16(int n, int cin, int cout, int h, int w, int ksize) {
 
 constexpr int kSumGroup = 32;
 
-template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM>
+template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM, int G>
 int launch_wg(const WgBf16Args& a, dim3 grid, hipStream_t s) {
     using S = WgShape<TAPS, TW, TH, CIB, COB, STEM>;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<TAPS, TW, TH, CIB, COB, STEM>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<TAPS, TW, TH, CIB, COB, STEM, G>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess) {
             lf::set_error("lf_conv2d_wgrad_bf16: cannot reserve %d bytes of LDS", S::LDS);
             return LF_ERR_LAUNCH;
         }
         raised = true;
     }
-    wgrad_bf16_kernel<TAPS, TW, TH, CIB, COB, STEM><<<grid, S::NT, S::LDS, s>>>(a);
+    wgrad_bf16_kernel<TAPS, TW, TH, CIB, COB, STEM, G><<<grid, S::NT, S::LDS, s>>>(a);
     return LF_OK;
 }
 
 template <int TAPS>
 int dispatch_wg(const WgBf16Plan& pl, const WgBf16Args& a, dim3 grid, hipStream_t s) {
-#define LF_WG(TW_, TH_, CIB_, COB_) \
-    if (pl.tw == TW_ && pl.th == TH_ && pl.cib == CIB_ && pl.cob == COB_) return launch_wg<TAPS, TW_, TH_, CIB_, COB_, false>(a, grid, s)
-    LF_WG(32, 8, 1, 1);
-    LF_WG(32, 8, 1, 2);
-    LF_WG(32, 8, 2, 2);
-    LF_WG(56, 4, 1, 1);
-    LF_WG(56, 4, 1, 2);
-    LF_WG(56, 4, 2, 2);
-    LF_WG(28, 4, 1, 1);
-    LF_WG(28, 4, 1, 2);
-    LF_WG(28, 4, 2, 2);
+    const bool wide = a.w % 8 == 0;  // rows 16-byte aligned: 8-pixel staging groups
+#define LF_WG(TW_, TH_, CIB_, COB_, G_) \
+    if (pl.tw == TW_ && pl.th == TH_ && pl.cib == CIB_ && pl.cob == COB_ && wide == (G_ == 8)) \
+        return launch_wg<TAPS, TW_, TH_, CIB_, COB_, false, G_>(a, grid, s)
+    LF_WG(32, 8, 1, 1, 8);
+    LF_WG(32, 8, 1, 2, 8);
+    LF_WG(32, 8, 2, 2, 8);
+    LF_WG(32, 8, 1, 1, 4);
+    LF_WG(32, 8, 1, 2, 4);
+    LF_WG(32, 8, 2, 2, 4);
+    LF_WG(56, 4, 1, 1, 8);
+    LF_WG(56, 4, 1, 2, 8);
+    LF_WG(56, 4, 2, 2, 8);
+    LF_WG(28, 4, 1, 1, 4);
+    LF_WG(28, 4, 1, 2, 4);
+    LF_WG(28, 4, 2, 2, 4);
 #undef LF_WG
     lf::set_error("lf_conv2d_wgrad_bf16: no kernel for tile %dx%d blocks %dx%d", pl.tw, pl.th, pl.cib, pl.cob);
     return LF_ERR_INVALID;
@@ -569,8 +608,8 @@ int lf_conv2d_wgrad_bf16(const void* x, const uint16_t* g, const uint16_t* bn_y,
     LF_REQUIRE(pl.stem || cin % 4 == 0, "lf_conv2d_wgrad_bf16: cin must be a multiple of 4 (got %d)", cin);
     LF_REQUIRE(!pl.stem || (in_scale == nullptr), "lf_conv2d_wgrad_bf16: the small-Cin path takes no prologue");
     LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(bn_y) |
-                 reinterpret_cast<size_t>(dy_out)) & 7) == 0,
-               "lf_conv2d_wgrad_bf16: tensors must be 8-byte aligned");
+                 reinterpret_cast<size_t>(dy_out)) & 15) == 0,
+               "lf_conv2d_wgrad_bf16: tensors must be 16-byte aligned");
     if (ws_bytes < lf_conv2d_wgrad_bf16_workspace(n, cin, h, w, cout, ksize)) {
         lf::set_error("lf_conv2d_wgrad_bf16: workspace %zu < %zu bytes", ws_bytes,
                       lf_conv2d_wgrad_bf16_workspace(n, cin, h, w, cout, ksize));
@@ -587,7 +626,8 @@ int lf_conv2d_wgrad_bf16(const void* x, const uint16_t* g, const uint16_t* bn_y,
     hipStream_t s = lf::as_stream(stream);
     int rc;
     if (pl.stem)
-        rc = launch_wg<1, 32, 8, 1, 1, true>(a, grid, s);
+        rc = a.w % 8 == 0 ? launch_wg<1, 32, 8, 1, 1, true, 8>(a, grid, s)
+                          : launch_wg<1, 32, 8, 1, 1, true, 4>(a, grid, s);
     else
         rc = ksize == 3 ? dispatch_wg<9>(pl, a, grid, s) : dispatch_wg<1>(pl, a, grid, s);
     if (rc != LF_OK) return rc;
