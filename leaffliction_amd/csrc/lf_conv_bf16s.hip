@@ -20,12 +20,16 @@
 //     lane across ALL tiles of the workgroup and reduced once at the end: one partial per
 //     workgroup instead of one per tile.
 //
-// D[row = output channel][col = pixel] on v_mfma_f32_32x32x16_bf16; a lane's two pixel blocks are
-// horizontally ADJACENT pixels (lane l: pixels 2l and 2l+1 of the wave's 64), so every epilogue
-// access is one dword per lane and 128 contiguous bytes per half-wave, and the read-modify-write
-// operands of the epilogue (old value when accumulating, the BatchNorm input for the backward
-// sums) are fetched BEFORE the MFMAs, so no store waits behind a dependent load.  Replaces Conv2D forward and its
-// input-gradient (srcs/model/cnn.py:27-29 under the mixed_float16 policy of train.py:179-190).
+// Every global access is 16 bytes per lane: the vector memory pipe moves ~5.3 TB/s with 16-byte
+// lanes but only ~3 TB/s with 8-byte and ~1.5 TB/s with 4-byte lanes
+// (scripts/microbench/seg_bw.hip, profiles/r02_microbench_seg_bw.txt).  The MFMA leaves a lane with
+// ONE pixel column of 16 channels (D[row = output channel][col = pixel]), i.e. 2-byte pieces; the
+// accumulators therefore go through LDS once (fp32, [channel][pixel]) and come back as eight
+// consecutive pixels of one channel per lane: 16-byte stores, 16-byte loads of the read-modify-
+// write operands (old value when accumulating, the BatchNorm input for the backward sums — both
+// requested BEFORE the MFMAs), and the statistics of a channel live in one half-wave.
+// Replaces Conv2D forward and its input-gradient (srcs/model/cnn.py:27-29 under the mixed_float16
+// policy of train.py:179-190).
 #include "lf_common.h"
 
 namespace {
@@ -70,26 +74,33 @@ struct SShape {
     static constexpr int R = 256 / ROWB, C = ROWB / 16;    // rows per 256-byte bank window, 16-byte groups per row
     static constexpr int COUT = 32 * NCO, CH = CI / 16;
     static constexpr int WBYTES = CH * TAPS * 2 * COUT * 16;
-    static constexpr int PBYTES = PPIX * ROWB;
-    static constexpr int RED = 4 * COUT * 2 * 4;
-    static constexpr int LDS = WBYTES + (PBYTES > RED ? PBYTES : RED);
+    static constexpr int PBYTES = (PPIX * ROWB + 15) / 16 * 16;
+    static constexpr int EBYTES = 32 * 256 * 4;             // fp32 accumulators of one 32-channel block
+    // the epilogue's transpose buffer reuses the patch (dead once the tile's MFMAs are done)
+    static constexpr int LDS = WBYTES + (PBYTES > EBYTES ? PBYTES : EBYTES);
 };
 
 template <int TAPS, int CI, int NCO, int TW, int TH, bool XBF>
-__global__ __launch_bounds__(kT, 2) void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
+__global__ __launch_bounds__(kT, (SShape<TAPS, CI, NCO, TW, TH>::LDS <= 80 * 1024 ? 2 : 1))
+void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     using S = SShape<TAPS, CI, NCO, TW, TH>;
-    static_assert(TW * TH == 256 && TW % 4 == 0, "tile = 4 waves x 64 pixels, whole 4-pixel groups");
+    static_assert(TW * TH == 256 && TW % 8 == 0, "tile = 4 waves x 64 pixels, whole 8-pixel groups");
     static_assert(XBF || CI == 16, "fp32 input: the stem only (3 channels padded to one 16-channel group)");
     constexpr int HALO = S::HALO, PW = S::PW, PH = S::PH, ROWB = S::ROWB, COUT = S::COUT, CH = S::CH;
-    constexpr int PGS = TW / 4, NB = 2;
+    constexpr int G = XBF ? 8 : 4;           // pixels per staging unit: 16 bytes of bf16 / of fp32
+    constexpr int PGS = TW / G, NB = 2;
+    typedef unsigned uvec __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* lw = lds;
     unsigned char* lp = lds + S::WBYTES;
+    float* le = reinterpret_cast<float*>(lp);  // [32 channels][256 pixels], over the patch
     __shared__ float lsc[2 * CI];
+    __shared__ float lst[2 * COUT];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 31, kh = lane >> 5;
     const size_t hw = (size_t)p.h * p.w;
     const bool pro = p.in_scale != nullptr;
+    const bool stats = p.stat_part != nullptr, masked = p.stat_mask_y != nullptr;
     const int tiles = p.tiles_x * p.tiles_y;
     const int first = blockIdx.x * p.items_per_wg;
     const int last = min(first + p.items_per_wg, p.items);
@@ -107,6 +118,10 @@ __global__ __launch_bounds__(kT, 2) void conv_bf16s_kernel(lf::ConvBf16TrainArgs
                 lsc[c] = c < p.cin ? p.in_scale[c] : 1.f;
                 lsc[CI + c] = c < p.cin ? p.in_shift[c] : 0.f;
             }
+        for (int c = tid; c < COUT; c += kT) {  // per-channel epilogue constants: pivot | mask scale, mask shift
+            lst[c] = masked ? p.mask_scale[c] : ((stats && p.stat_pivot != nullptr) ? p.stat_pivot[c] : 0.f);
+            lst[COUT + c] = masked ? p.mask_shift[c] : 0.f;
+        }
         if (!XBF)  // channels 4..15 of the stem's rows are never written by the staging: zero them once
             for (int e = tid; e < S::PBYTES / 16; e += kT)
                 *reinterpret_cast<lf::u32x4*>(lp + 16 * e) = lf::u32x4{0u, 0u, 0u, 0u};
@@ -116,12 +131,12 @@ __global__ __launch_bounds__(kT, 2) void conv_bf16s_kernel(lf::ConvBf16TrainArgs
         return pp * ROWB + ((c16 ^ ((pp / S::R) % S::C)) << 4);
     };
 
-    // ---- staging units: 4 channels x 4 pixels (interior), 4 channels x 1 pixel (halo columns)
+    // ---- staging units: 4 channels x G pixels (interior: one 16-byte load per channel), 4 channels x 1
+    // pixel (halo columns)
     constexpr int QD = XBF ? CI / 4 : 1;  // channel quads that carry data
     constexpr int NXU = QD * PH * PGS, XPT = (NXU + kT - 1) / kT;
     constexpr int NHU = QD * PH * 2 * HALO, HPT = (NHU + kT - 1) / kT;
-    u32x2 rx[XBF ? XPT : 1][4];
-    f32x4v rf[XBF ? 1 : XPT][3];
+    uvec rx[XPT][XBF ? 4 : 3];
     unsigned rh[HPT > 0 ? HPT : 1][XBF ? 2 : 3];
     unsigned xmask = 0, hmask = 0;
 
@@ -142,18 +157,18 @@ __global__ __launch_bounds__(kT, 2) void conv_bf16s_kernel(lf::ConvBf16TrainArgs
         for (int k = 0; k < XPT; ++k) {
             const int u = tid + k * kT;
             const int pg = u % PGS, t1 = u / PGS, quad = t1 % QD, pr = t1 / QD;
-            const int gy = ty0 - HALO + pr, gx = tx0 + 4 * pg;
+            const int gy = ty0 - HALO + pr, gx = tx0 + G * pg;
             const bool ok = u < NXU && gy >= 0 && gy < p.h && gx < p.w && 4 * quad < p.cin;
             xmask |= (ok ? 1u : 0u) << k;
             if (!ok) continue;
             const size_t o = (size_t)(4 * quad) * hw + (size_t)gy * p.w + gx;
             if (XBF) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rx[k][i] = *reinterpret_cast<const u32x2*>(xb + o + (size_t)i * hw);
+                for (int i = 0; i < 4; ++i) rx[k][i] = *reinterpret_cast<const uvec*>(xb + o + (size_t)i * hw);
             } else {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    if (i < p.cin) rf[k][i] = *reinterpret_cast<const f32x4v*>(xf + o + (size_t)i * hw);
+                    if (i < p.cin) rx[k][i] = *reinterpret_cast<const uvec*>(xf + o + (size_t)i * hw);
             }
         }
 #pragma unroll
@@ -182,39 +197,43 @@ __global__ __launch_bounds__(kT, 2) void conv_bf16s_kernel(lf::ConvBf16TrainArgs
             if (u >= NXU) continue;
             const int pg = u % PGS, t1 = u / PGS, quad = t1 % QD, pr = t1 / QD;
             const bool ok = xmask >> k & 1u;
-            float f[4][4];
+            const unsigned pi = (unsigned)(pr * PW + HALO + G * pg);
+            float prev[G];
+            // channel by channel; every second channel the pair goes to LDS, one dword per pixel
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float v[4] = {0.f, 0.f, 0.f, 0.f};  // zero padding stays exactly zero
-                if (ok) {
-                    if (XBF) {
-                        v[0] = up(rx[k][i].x & 0xffffu);
-                        v[1] = up(rx[k][i].x >> 16);
-                        v[2] = up(rx[k][i].y & 0xffffu);
-                        v[3] = up(rx[k][i].y >> 16);
-                    } else if (i < 3 && i < p.cin) {
+                float v[G];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = rf[k][i][e];
+                for (int e = 0; e < G; ++e) v[e] = 0.f;  // zero padding stays exactly zero
+                if (ok && (XBF || (i < 3 && i < p.cin))) {
+                    if (XBF) {
+#pragma unroll
+                        for (int e = 0; e < G; e += 2) {
+                            v[e] = up(rx[k][i][e / 2] & 0xffffu);
+                            v[e + 1] = up(rx[k][i][e / 2] >> 16);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < G; ++e) v[e] = __uint_as_float(rx[k][i < 3 ? i : 0][e]);
                     }
                     if (pro) {
                         const float sc = lsc[4 * quad + i], sh = lsc[CI + 4 * quad + i];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
+                        for (int e = 0; e < G; ++e) {
                             v[e] = fmaf(v[e], sc, sh);
                             if (p.in_relu) v[e] = fmaxf(v[e], 0.f);
                         }
                     }
                 }
+                if (i & 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f[i][e] = v[e];
-            }
-            const unsigned pi = (unsigned)(pr * PW + HALO + 4 * pg);
+                    for (int e = 0; e < G; ++e)
+                        *reinterpret_cast<unsigned*>(lp + poff(pi + e, (unsigned)quad >> 1) + 8 * (quad & 1) +
+                                                     4 * (i >> 1)) = pack2(prev[e], v[e]);
+                } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u32x2 o;
-                o.x = pack2(f[0][e], f[1][e]);
-                o.y = pack2(f[2][e], f[3][e]);
-                *reinterpret_cast<u32x2*>(lp + poff(pi + e, (unsigned)quad >> 1) + 8 * (quad & 1)) = o;
+                    for (int e = 0; e < G; ++e) prev[e] = v[e];
+                }
             }
         }
 #pragma unroll
@@ -249,27 +268,22 @@ __global__ __launch_bounds__(kT, 2) void conv_bf16s_kernel(lf::ConvBf16TrainArgs
         }
     };
 
-    // per-lane geometry: the wave owns 64 consecutive flat tile positions; lane px holds positions
-    // 2*px (block 0) and 2*px + 1 (block 1): the same row, adjacent columns
+    // MFMA geometry: the wave owns 64 consecutive flat tile positions; lane px holds positions 2*px
+    // (block 0) and 2*px + 1 (block 1): the same row, adjacent columns
     const int f0 = 64 * wv + 2 * px;
     const int prow = f0 / TW, pcol = f0 - prow * TW;
     const unsigned pp0 = (unsigned)(prow * PW + pcol);
-
-    // per-channel epilogue constants in LDS (pivot | mask scale, mask shift)
-    __shared__ float lst[2 * COUT];
-    const bool stats = p.stat_part != nullptr, masked = p.stat_mask_y != nullptr;
-    for (int c = tid; c < COUT; c += kT) {
-        lst[c] = masked ? p.mask_scale[c] : ((stats && p.stat_pivot != nullptr) ? p.stat_pivot[c] : 0.f);
-        lst[COUT + c] = masked ? p.mask_shift[c] : 0.f;
-    }
+    // epilogue geometry: thread = (pixel group eg of 8 consecutive flat positions, channel ec + 8*j)
+    const int eg = tid & 31, ec = tid >> 5;
+    const int erow = (8 * eg) / TW, ecol = (8 * eg) - erow * TW;
 
     f32x16 acc[NB][NCO];
-    float s1[NCO][16], s2[NCO][16];  // running channel sums of this lane over all its pixels and tiles
+    float s1[NCO][4], s2[NCO][4];  // running sums of this thread's channels over all its pixels and tiles
 #pragma unroll
     for (int cb = 0; cb < NCO; ++cb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s1[cb][r] = s2[cb][r] = 0.f;
-    unsigned rold[NCO][16], rmask[NCO][16];  // the lane's pixel pair of each channel, as stored
+        for (int j = 0; j < 4; ++j) s1[cb][j] = s2[cb][j] = 0.f;
+    uvec rold[NCO][4], rmask[NCO][4];  // eight pixels of one channel each, as stored
 
     if (first < last) issue(first);
     for (int item = first; item < last; ++item) {
@@ -280,27 +294,23 @@ __global__ __launch_bounds__(kT, 2) void conv_bf16s_kernel(lf::ConvBf16TrainArgs
         int n, tx0, ty0;
         tile_of(item, n, tx0, ty0);
         uint16_t* yb = p.y + (size_t)n * p.cout * hw;
-        const int gy = ty0 + prow, gx = tx0 + pcol;
-        const bool ok = gy < p.h && gx < p.w;  // the pair is inside or outside as a whole (w % 4 == 0, gx even)
-        const unsigned po = ok ? (unsigned)gy * (unsigned)p.w + (unsigned)gx : 0u;
+        const int gy = ty0 + erow, gx = tx0 + ecol;
+        const bool ok = gy < p.h && gx < p.w;  // the 8-pixel group is inside or outside as a whole (w % 8 == 0)
+        const size_t po = ok ? (size_t)gy * p.w + gx : 0;
         if (p.accumulate) {
 #pragma unroll
             for (int cb = 0; cb < NCO; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cb * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                    rold[cb][r] = *reinterpret_cast<const unsigned*>(yb + (size_t)co * hw + po);
-                }
+                for (int j = 0; j < 4; ++j)
+                    rold[cb][j] = *reinterpret_cast<const uvec*>(yb + (size_t)(cb * 32 + 8 * j + ec) * hw + po);
         }
         if (masked) {
             const uint16_t* my = p.stat_mask_y + (size_t)n * p.cout * hw;
 #pragma unroll
             for (int cb = 0; cb < NCO; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cb * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                    rmask[cb][r] = *reinterpret_cast<const unsigned*>(my + (size_t)co * hw + po);
-                }
+                for (int j = 0; j < 4; ++j)
+                    rmask[cb][j] = *reinterpret_cast<const uvec*>(my + (size_t)(cb * 32 + 8 * j + ec) * hw + po);
         }
         __syncthreads();
 #pragma unroll
@@ -330,64 +340,73 @@ __global__ __launch_bounds__(kT, 2) void conv_bf16s_kernel(lf::ConvBf16TrainArgs
                         acc[nb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cb], B[nb], acc[nb][cb], 0, 0, 0);
             }
         }
-        // ---- epilogue: bf16 pair store (optionally on top of the old values) + sums of the rounded values
+        // ---- epilogue, one 32-channel block at a time through LDS: lane (pixel pair, 16 channels)
+        // -> thread (8 pixels, 4 channels); then 16-byte stores and the sums of the rounded values
 #pragma unroll
         for (int cb = 0; cb < NCO; ++cb) {
+            __syncthreads();  // every wave is done with the patch (cb = 0) / with the previous block in `le`
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = cb * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                float v0 = acc[0][cb][r], v1 = acc[1][cb][r];
-                if (p.accumulate) {
-                    v0 += up(rold[cb][r] & 0xffffu);
-                    v1 += up(rold[cb][r] >> 16);
-                }
-                const unsigned vb = pack2(v0, v1);
-                if (ok) *reinterpret_cast<unsigned*>(yb + (size_t)co * hw + po) = vb;
-                if (!stats) continue;
-                const float r0 = up(vb & 0xffffu), r1 = up(vb >> 16);
+                const int cl = 8 * (r >> 2) + 4 * kh + (r & 3);
+                *reinterpret_cast<float2*>(le + cl * 256 + 64 * wv + 2 * px) = make_float2(acc[0][cb][r], acc[1][cb][r]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cl = 8 * j + ec, co = cb * 32 + cl;
+                const lf::f32x4 a0 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg);
+                const lf::f32x4 a1 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg + 4);
+                float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                if (p.accumulate)
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        v[e] += up(rold[cb][j][e / 2] & 0xffffu);
+                        v[e + 1] += up(rold[cb][j][e / 2] >> 16);
+                    }
+                uvec o;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) o[e / 2] = pack2(v[e], v[e + 1]);
+                if (ok) *reinterpret_cast<uvec*>(yb + (size_t)co * hw + po) = o;
+                if (!stats || !ok) continue;
+                float a = 0.f, b = 0.f;
                 if (!masked) {
                     const float pv = lst[co];
-                    const float d0 = ok ? r0 - pv : 0.f, d1 = ok ? r1 - pv : 0.f;
-                    s1[cb][r] += d0 + d1;
-                    s2[cb][r] = fmaf(d1, d1, fmaf(d0, d0, s2[cb][r]));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = up((e & 1) ? o[e / 2] >> 16 : o[e / 2] & 0xffffu) - pv;
+                        a += d;
+                        b = fmaf(d, d, b);
+                    }
                 } else {
                     const float msc = lst[co], msh = lst[COUT + co];
-                    const float y0 = up(rmask[cb][r] & 0xffffu), y1 = up(rmask[cb][r] >> 16);
-                    const float d0 = (ok && (!p.mask_relu || fmaf(y0, msc, msh) > 0.f)) ? r0 : 0.f;
-                    const float d1 = (ok && (!p.mask_relu || fmaf(y1, msc, msh) > 0.f)) ? r1 : 0.f;
-                    s1[cb][r] += d0 + d1;
-                    s2[cb][r] = fmaf(d1, y1, fmaf(d0, y0, s2[cb][r]));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float rv = up((e & 1) ? o[e / 2] >> 16 : o[e / 2] & 0xffffu);
+                        const unsigned mw = rmask[cb][j][e / 2];
+                        const float yv = up((e & 1) ? mw >> 16 : mw & 0xffffu);
+                        const float d = (!p.mask_relu || fmaf(yv, msc, msh) > 0.f) ? rv : 0.f;
+                        a += d;
+                        b = fmaf(d, yv, b);
+                    }
                 }
+                s1[cb][j] += a;
+                s2[cb][j] += b;
             }
         }
     }
     if (stats) {
-        // one partial per workgroup: lanes -> half-wave sums -> the four waves through LDS
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(lp);  // [4 waves][COUT][2]
+        // one partial per workgroup: a channel's pixel groups are the 32 lanes of one half-wave
 #pragma unroll
         for (int cb = 0; cb < NCO; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float a = half_sum32(s1[cb][r]), b = half_sum32(s2[cb][r]);
-                if (px == 31) {
-                    const int col = cb * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                    red[(wv * COUT + col) * 2] = a;
-                    red[(wv * COUT + col) * 2 + 1] = b;
+            for (int j = 0; j < 4; ++j) {
+                const float a = half_sum32(s1[cb][j]), b = half_sum32(s2[cb][j]);
+                if (eg == 31) {
+                    float* dst = p.stat_part + ((size_t)(cb * 32 + 8 * j + ec) * (size_t)p.stat_tiles + blockIdx.x) * 2;
+                    dst[0] = a;
+                    dst[1] = b;
                 }
             }
-        __syncthreads();
-        if (tid < COUT) {
-            float a = 0.f, b = 0.f;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
-                a += red[(w4 * COUT + tid) * 2];
-                b += red[(w4 * COUT + tid) * 2 + 1];
-            }
-            float* dst = p.stat_part + ((size_t)tid * (size_t)p.stat_tiles + blockIdx.x) * 2;
-            dst[0] = a;
-            dst[1] = b;
-        }
     }
 }
 
@@ -400,6 +419,7 @@ SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
     SPlan pl{};
     pl.ok = false;
     if (cout != 32 && cout != 64) return pl;
+    if (w % 8 != 0) return pl;                              // 16-byte rows
     if (!x_bf16) {
         if (cin > 3 || ksize != 3 || cout != 32) return pl;
         pl.ci = 16;
@@ -408,7 +428,6 @@ SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
         pl.ci = cin;
     }
     pl.nco = cout / 32;
-    if (pl.ci == 64 && pl.nco == 2) return pl;             // 74 KB of weights: not resident (old kernel)
     if (ksize == 1 && !(pl.ci == 32 && pl.nco == 2) && !(pl.ci == 64 && pl.nco == 1)) return pl;
     if (w % 32 == 0 || w > 128) { pl.tw = 32; pl.th = 8; } else { pl.tw = 16; pl.th = 16; }
     pl.tiles_x = (w + pl.tw - 1) / pl.tw;
@@ -445,6 +464,7 @@ int dispatch_s(const SPlan& pl, int ksize, const lf::ConvBf16TrainArgs& a, hipSt
         if (pl.ci == 32 && pl.nco == 1) return launch_s<9, 32, 1, TW, TH, true>(a, pl.wgs, s);
         if (pl.ci == 32 && pl.nco == 2) return launch_s<9, 32, 2, TW, TH, true>(a, pl.wgs, s);
         if (pl.ci == 64 && pl.nco == 1) return launch_s<9, 64, 1, TW, TH, true>(a, pl.wgs, s);
+        if (pl.ci == 64 && pl.nco == 2) return launch_s<9, 64, 2, TW, TH, true>(a, pl.wgs, s);
     } else {
         if (pl.ci == 32 && pl.nco == 2) return launch_s<1, 32, 2, TW, TH, true>(a, pl.wgs, s);
         if (pl.ci == 64 && pl.nco == 1) return launch_s<1, 64, 1, TW, TH, true>(a, pl.wgs, s);

@@ -168,6 +168,8 @@ class LeafCNN:
         self._saved: Dict[str, Any] = {}
         self._global_n: Optional[int] = None
         self._compiled: Dict[str, Any] = {}
+        self._graphs: Dict[Any, Dict[str, Any]] = {}
+        self._graphs_on = os.environ.get("LEAFFLICTION_GRAPH", "1") != "0"
 
     # ------------------------------------------------------------------ init
     def _init_weights(self) -> None:
@@ -726,9 +728,56 @@ class LeafCNN:
         return probs, loss
 
     def _forward_backward(self, x, y_true: torch.Tensor):
-        """Forward + backward of one local batch: fills flat_g, returns (probs, loss)."""
+        """Forward + backward of one local batch: fills flat_g, returns (probs, loss).
+
+        The ~250 launches of a step are recorded once per (batch shape, precision) into a HIP graph
+        and replayed (the host would otherwise spend 3-6 ms per step issuing them, a fifth of the
+        bf16 step): the first two steps of a shape run eagerly (they size every buffer), the third is
+        captured.  Inputs and labels are copied into fixed buffers, the per-step random draws go up
+        through their fixed staging buffer before the replay; the optimizer (its learning rate
+        changes every step) and the gradient all-reduce stay outside.  LEAFFLICTION_GRAPH=0 turns
+        this off."""
+        if self._graphs_on and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.uint8:
+            return self._forward_backward_graph(x, y_true)
+        return self._forward_backward_eager(x, y_true)
+
+    def _forward_backward_graph(self, x: torch.Tensor, y_true: torch.Tensor):
+        n = int(x.shape[0])
+        key = (tuple(x.shape), self.train_dtype, self.augment, self._global_n, tuple(y_true.shape))
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = {"calls": 0, "graph": None}
+        st["calls"] += 1
+        if st["graph"] is None and st["calls"] <= 2:
+            return self._forward_backward_eager(x, y_true)
+        drops, top, aug4 = self.draw_step_randoms(n, self.augment)  # fixed device views, fresh values
+        if st["graph"] is None:
+            st["x"] = torch.empty_like(x)
+            st["y"] = torch.empty_like(y_true)
+            st["x"].copy_(x)
+            st["y"].copy_(y_true)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    st["out"] = self._forward_backward_body(st["x"], st["y"], drops, top, aug4)
+            except Exception:
+                self._graphs_on = False   # capture is an optimisation: fall back to eager launches
+                torch.cuda.synchronize()
+                return self._forward_backward_body(x, y_true, drops, top, aug4)
+            st["graph"] = g
+        else:
+            st["x"].copy_(x)
+            st["y"].copy_(y_true)
+        st["graph"].replay()
+        return st["out"]
+
+    def _forward_backward_eager(self, x, y_true: torch.Tensor):
         n = int(x.shape[0])
         drops, top, aug4 = self.draw_step_randoms(n, self.augment)
+        return self._forward_backward_body(x, y_true, drops, top, aug4)
+
+    def _forward_backward_body(self, x, y_true, drops, top, aug4):
         x0 = self._input(x, True, aug4)
         if self.train_dtype == "bf16":
             if not (self.use_se and self._bf16_storage_ok(x0.shape[2], x0.shape[3])):

@@ -269,3 +269,28 @@ def test_train_step_bf16_matches_lowp_oracle(cuda, size, n, widths, classes):
     m.train_step(x, y, lr=1e-3)
     torch.cuda.synchronize()
     assert torch.isfinite(m.flat_p).all()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graph_replay_equals_eager_launches(cuda, dtype):
+    """train_step records its launches into a HIP graph on the third step of a shape; five steps
+    with the graph must leave the same bits in the parameters as five eager steps (the kernels are
+    deterministic, and the random draws go through the same generators)."""
+    from leaffliction_amd.model.cnn import LeafCNN
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 256, (6, 32, 32, 3), dtype=torch.uint8, generator=g).to(cuda)
+    y = F.one_hot(torch.randint(0, 3, (6,), generator=g), 3).float().to(cuda)
+    res = []
+    for graphs in (True, False):
+        m = LeafCNN(num_classes=3, img_size=32, widths=[32, 64], l2_reg=1e-4, use_norm=False, seed=9, device=cuda)
+        m.set_training_dtype(dtype)
+        m._graphs_on = graphs
+        losses = []
+        for step in range(5):
+            _p, loss = m.train_step(x, y, lr=1e-3)
+            losses.append(float(loss.mean()))
+        torch.cuda.synchronize()
+        assert (not graphs) or any(st["graph"] is not None for st in m._graphs.values())
+        res.append((m.flat_p.clone(), m.flat_s.clone(), losses))
+    assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
