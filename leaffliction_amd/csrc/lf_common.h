@@ -75,6 +75,31 @@ struct ConvBf16TrainArgs {
     int mask_relu;
     int tiles_x, tiles_y, items, items_per_wg;  // filled by the streaming launcher
 };
+// lf_conv2d_wgrad_bf16: the general kernel (lf_wgrad_bf16.hip) and the producer / consumer kernel for
+// the large-tensor stages (lf_wgrad_bf16_pc.hip) take the same arguments
+struct WgradBf16Args {
+    const uint16_t* x;   // [N][Cin][H][W] bf16 (STEM: const float*, fp32 [N][Cin][H][W])
+    const uint16_t* g;   // [N][Cout][H][W] bf16: dY itself, or the upstream gradient when bn_y is set
+    float* part;         // [splits][Cin][TAPS][Cout]
+    const float* in_scale;  // optional prologue on A: relu?(x*scale[ci]+shift[ci])
+    const float* in_shift;
+    int in_relu;
+    int n, cin, cout, h, w;
+    int tiles_x, tiles_y, items, items_per_split;
+    // optional: dY = BatchNorm backward of g (BN input bn_y), formed while staging:
+    //   dz = (g*alpha[n][co] + add[n][co]) * [bn_y*coef0[co] + coef1[co] > 0 or !bn_relu]
+    //   dY = bf16(coef2[co]*dz + coef3[co]*bn_y + coef4[co])
+    // and written to dy_out (may be null) by the ci-block-0 workgroups, each element once
+    const uint16_t* bn_y;
+    const float* bn_alpha;
+    const float* bn_add;
+    const float* bn_coef;  // [5][Cout]
+    uint16_t* dy_out;
+    int bn_relu;
+};
+bool wgrad_bf16_pc_covers(int cin, int cout, int w, int ksize, int tw, int th);
+int wgrad_bf16_pc_launch(const WgradBf16Args& a, int tw, int cob, dim3 grid, hipStream_t s);
+
 long long conv_bf16s_parts(int n, int cin, int h, int w, int cout, int ksize, int x_bf16);  // 0 = shape not covered
 int conv_bf16s_launch(ConvBf16TrainArgs a, int ksize, int x_bf16, hipStream_t s);
 

@@ -39,12 +39,16 @@ __device__ __forceinline__ void block_sum(float (&v)[K], float* red /* [K][4] */
 }
 
 // out[plane] = mean_hw act(x*scale[c]+shift[c]); mask_sums[plane] = {count of x*scale+shift > 0,
-// sum of x over those} (the SE squeeze of relu(BN2(y2)), and what BN2's backward needs from it)
+// sum of x over those} (the SE squeeze of relu(BN2(y2)), and what BN2's backward needs from it).
+// V = bf16 values per load: 8 (16-byte lanes: what the vector memory pipe needs to reach its rate,
+// scripts/microbench/seg_bw.hip) when hw % 8 == 0, else 4.
+template <int V>
 __global__ __launch_bounds__(kBlock) void gap_stats_bf16_kernel(const uint16_t* __restrict__ x,
                                                                 float* __restrict__ out, int hw, int c,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int relu,
                                                                 float* __restrict__ mask_sums) {
+    typedef unsigned uvec __attribute__((ext_vector_type(V / 2)));
     __shared__ float red[12];
     const size_t base = (size_t)blockIdx.x * hw;
     const bool pro = scale != nullptr;
@@ -63,11 +67,13 @@ __global__ __launch_bounds__(kBlock) void gap_stats_bf16_kernel(const uint16_t* 
         }
         return v;
     };
-    const u32x2* x4 = reinterpret_cast<const u32x2*>(x + base);  // hw % 4 == 0
-    for (int i = threadIdx.x; i < hw / 4; i += kBlock) {
-        const u32x2 v = x4[i];
-        const float a = one(v.x & 0xffffu), b = one(v.x >> 16), cc = one(v.y & 0xffffu), d = one(v.y >> 16);
-        acc[0] += (a + b) + (cc + d);
+    const uvec* xv = reinterpret_cast<const uvec*>(x + base);
+    for (int i = threadIdx.x; i < hw / V; i += kBlock) {
+        const uvec v = xv[i];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < V / 2; ++e) s += one(v[e] & 0xffffu) + one(v[e] >> 16);
+        acc[0] += s;
     }
     block_sum<3>(acc, red);
     if (threadIdx.x == 0) {
@@ -115,42 +121,60 @@ __device__ __forceinline__ unsigned tail_code(float r00, float r01, float r10, f
     return bi | (best > 0.f ? 4u : 0u);
 }
 
-// p = bf16(drop * maxpool2x2(relu(shortcut' + relu(BN(y)) * gate))), route byte per pooled value
+// p = bf16(drop * maxpool2x2(relu(shortcut' + relu(BN(y)) * gate))), route byte per pooled value.
+// One thread = two rows x V input pixels (V = 8: 16-byte loads, w % 8 == 0; else 4) = V/2 pooled values.
+template <int V>
 __global__ __launch_bounds__(kBlock) void tail_fwd_train_bf16_kernel(TailTrainArgs t, uint8_t* __restrict__ route,
                                                                      uint16_t* __restrict__ p) {
+    typedef unsigned uvec __attribute__((ext_vector_type(V / 2)));
+    typedef unsigned ovec __attribute__((ext_vector_type(V / 4)));
     const int plane = blockIdx.x, ch = plane % t.c;
     const float sv = t.s ? t.s[plane] : 1.f;
     const float as = t.a_scale ? t.a_scale[ch] : 1.f, ab = t.a_scale ? t.a_shift[ch] : 0.f;
     const float ks = t.sc_scale ? t.sc_scale[ch] : 1.f, kb = t.sc_scale ? t.sc_shift[ch] : 0.f;
     const float dv = t.drop ? t.drop[plane] : 1.f;
-    const int h = t.h, w = t.w, ph = h / 2, pw = w / 2, pw2 = pw / 2;
+    const int h = t.h, w = t.w, ph = h / 2, pw = w / 2, pwv = w / V;
     const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
-    for (int q = blockIdx.y * kBlock + threadIdx.x; q < ph * pw2; q += gridDim.y * kBlock) {
-        const int py = q / pw2, px2 = q - py * pw2;
-        float r[2][4];
+    for (int q = blockIdx.y * kBlock + threadIdx.x; q < ph * pwv; q += gridDim.y * kBlock) {
+        const int py = q / pwv, pxv = q - py * pwv;
+        float r[2][V];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-            const size_t o = base + (size_t)(2 * py + dy) * w + 4 * px2;
-            const u32x2 yv = *reinterpret_cast<const u32x2*>(t.y + o);
-            const u32x2 s4 = *reinterpret_cast<const u32x2*>(t.sc + o);
-            r[dy][0] = tail_r(t, yv.x & 0xffffu, s4.x & 0xffffu, as, ab, sv, ks, kb);
-            r[dy][1] = tail_r(t, yv.x >> 16, s4.x >> 16, as, ab, sv, ks, kb);
-            r[dy][2] = tail_r(t, yv.y & 0xffffu, s4.y & 0xffffu, as, ab, sv, ks, kb);
-            r[dy][3] = tail_r(t, yv.y >> 16, s4.y >> 16, as, ab, sv, ks, kb);
+            const size_t o = base + (size_t)(2 * py + dy) * w + V * pxv;
+            const uvec yv = *reinterpret_cast<const uvec*>(t.y + o);
+            const uvec s4 = *reinterpret_cast<const uvec*>(t.sc + o);
+#pragma unroll
+            for (int e = 0; e < V / 2; ++e) {
+                r[dy][2 * e] = tail_r(t, yv[e] & 0xffffu, s4[e] & 0xffffu, as, ab, sv, ks, kb);
+                r[dy][2 * e + 1] = tail_r(t, yv[e] >> 16, s4[e] >> 16, as, ab, sv, ks, kb);
+            }
         }
-        float m0, m1;
-        const unsigned c0 = tail_code(r[0][0], r[0][1], r[1][0], r[1][1], m0);
-        const unsigned c1 = tail_code(r[0][2], r[0][3], r[1][2], r[1][3], m1);
-        const size_t po = pbase + (size_t)py * pw + 2 * px2;  // even: pw is even here
-        *reinterpret_cast<uint16_t*>(route + po) = (uint16_t)(c0 | (c1 << 8));
-        *reinterpret_cast<unsigned*>(p + po) = down(m0 * dv) | down(m1 * dv) << 16;
+        const size_t po = pbase + (size_t)py * pw + (V / 2) * pxv;
+        ovec packed;
+        unsigned codes = 0;
+#pragma unroll
+        for (int k = 0; k < V / 2; k += 2) {
+            float m0, m1;
+            const unsigned c0 = tail_code(r[0][2 * k], r[0][2 * k + 1], r[1][2 * k], r[1][2 * k + 1], m0);
+            const unsigned c1 = tail_code(r[0][2 * k + 2], r[0][2 * k + 3], r[1][2 * k + 2], r[1][2 * k + 3], m1);
+            codes |= (c0 | (c1 << 8)) << (8 * k);
+            packed[k / 2] = down(m0 * dv) | down(m1 * dv) << 16;
+        }
+        if (V == 8) {
+            *reinterpret_cast<unsigned*>(route + po) = codes;
+        } else {
+            *reinterpret_cast<uint16_t*>(route + po) = (uint16_t)codes;
+        }
+        *reinterpret_cast<ovec*>(p + po) = packed;
     }
 }
 
 // dr = bf16(dp*drop) routed to the recorded position of each 2x2 window when its maximum was > 0.
 // Per plane: ds = sum dr*a with a = relu(y*a_scale+a_shift), plane_sums = {sum dr*[a>0],
 // sum dr*[a>0]*y} (BatchNorm-2's backward sums), sc_sums = {sum dr, sum dr*sc_y} (the projection
-// shortcut's BatchNorm).  The sums are over the rounded dr.
+// shortcut's BatchNorm).  The sums are over the rounded dr.  One thread = V/2 pooled values ->
+// two rows x V gradient pixels (V = 8: 16-byte stores, w % 8 == 0; else 4).
+template <int V>
 __global__ __launch_bounds__(kBlock) void tail_bwd_bf16_kernel(const uint16_t* __restrict__ dp,
                                                                const uint8_t* __restrict__ route,
                                                                const uint16_t* __restrict__ y,
@@ -161,11 +185,13 @@ __global__ __launch_bounds__(kBlock) void tail_bwd_bf16_kernel(const uint16_t* _
                                                                float* __restrict__ plane_sums,
                                                                const uint16_t* __restrict__ sc_y,
                                                                float* __restrict__ sc_sums, int c, int h, int w) {
+    typedef unsigned uvec __attribute__((ext_vector_type(V / 2)));
+    typedef unsigned ivec __attribute__((ext_vector_type(V / 4)));
     __shared__ float red[20];
     const int plane = blockIdx.x, ch = plane % c;
     const float dv = drop ? drop[plane] : 1.f;
     const float as = a_scale ? a_scale[ch] : 1.f, ab = a_scale ? a_shift[ch] : 0.f;
-    const int ph = h / 2, pw = w / 2, pw2 = pw / 2;
+    const int ph = h / 2, pw = w / 2, pwv = w / V;
     const size_t base = (size_t)plane * h * w, pbase = (size_t)plane * ph * pw;
     const bool sums = ds != nullptr || plane_sums != nullptr;
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -189,25 +215,27 @@ __global__ __launch_bounds__(kBlock) void tail_bwd_bf16_kernel(const uint16_t* _
             acc[0] += gg * av;
         }
     };
-    for (int q = threadIdx.x; q < ph * pw2; q += kBlock) {
-        const int py = q / pw2, px2 = q - py * pw2;
-        const size_t po = pbase + (size_t)py * pw + 2 * px2;
-        const unsigned codes = *reinterpret_cast<const uint16_t*>(route + po);
-        const unsigned g2 = *reinterpret_cast<const unsigned*>(dp + po);
-        const unsigned c0 = codes & 0xff, c1 = codes >> 8;
-        const unsigned g0b = (c0 & 4u) ? down(up(g2 & 0xffffu) * dv) : 0u;
-        const unsigned g1b = (c1 & 4u) ? down(up(g2 >> 16) * dv) : 0u;
-        const unsigned b0 = c0 & 3u, b1 = c1 & 3u;
-        const size_t o0 = base + (size_t)(2 * py) * w + 4 * px2, o1 = o0 + w;
-        u32x2 top, bot;
-        top.x = (b0 == 0 ? g0b : 0u) | (b0 == 1 ? g0b << 16 : 0u);
-        top.y = (b1 == 0 ? g1b : 0u) | (b1 == 1 ? g1b << 16 : 0u);
-        bot.x = (b0 == 2 ? g0b : 0u) | (b0 == 3 ? g0b << 16 : 0u);
-        bot.y = (b1 == 2 ? g1b : 0u) | (b1 == 3 ? g1b << 16 : 0u);
-        *reinterpret_cast<u32x2*>(dr + o0) = top;
-        *reinterpret_cast<u32x2*>(dr + o1) = bot;
-        tally(up(g0b), (b0 < 2 ? o0 : o1) + (b0 & 1u));
-        tally(up(g1b), (b1 < 2 ? o0 : o1) + 2 + (b1 & 1u));
+    for (int q = threadIdx.x; q < ph * pwv; q += kBlock) {
+        const int py = q / pwv, pxv = q - py * pwv;
+        const size_t po = pbase + (size_t)py * pw + (V / 2) * pxv;
+        unsigned codes;
+        if (V == 8) codes = *reinterpret_cast<const unsigned*>(route + po);
+        else codes = *reinterpret_cast<const uint16_t*>(route + po);
+        const ivec g2 = *reinterpret_cast<const ivec*>(dp + po);
+        const size_t o0 = base + (size_t)(2 * py) * w + V * pxv, o1 = o0 + w;
+        uvec top, bot;
+#pragma unroll
+        for (int k = 0; k < V / 2; ++k) {   // pooled value k -> input columns 2k, 2k+1
+            const unsigned cd = (codes >> (8 * k)) & 0xffu;
+            const unsigned gw = g2[k / 2];
+            const unsigned gb = (cd & 4u) ? down(up((k & 1) ? gw >> 16 : gw & 0xffffu) * dv) : 0u;
+            const unsigned b = cd & 3u;
+            top[k] = (b == 0 ? gb : 0u) | (b == 1 ? gb << 16 : 0u);
+            bot[k] = (b == 2 ? gb : 0u) | (b == 3 ? gb << 16 : 0u);
+            tally(up(gb), (b < 2 ? o0 : o1) + 2 * k + (b & 1u));
+        }
+        *reinterpret_cast<uvec*>(dr + o0) = top;
+        *reinterpret_cast<uvec*>(dr + o1) = bot;
     }
     if (sums || sc_y != nullptr) {
         block_sum<5>(acc, red);
@@ -263,7 +291,10 @@ int lf_gap_stats_bf16(const uint16_t* x, float* out, float* mask_sums, int n, in
     LF_REQUIRE((scale == nullptr) == (shift == nullptr), "lf_gap_stats_bf16: scale/shift must both be set");
     LF_REQUIRE(mask_sums == nullptr || scale != nullptr, "lf_gap_stats_bf16: mask_sums needs scale/shift");
     LF_REQUIRE(al8(x), "lf_gap_stats_bf16: x must be 8-byte aligned");
-    gap_stats_bf16_kernel<<<n * c, kBlock, 0, lf::as_stream(stream)>>>(x, out, hw, c, scale, shift, relu, mask_sums);
+    if (hw % 8 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0)
+        gap_stats_bf16_kernel<8><<<n * c, kBlock, 0, lf::as_stream(stream)>>>(x, out, hw, c, scale, shift, relu, mask_sums);
+    else
+        gap_stats_bf16_kernel<4><<<n * c, kBlock, 0, lf::as_stream(stream)>>>(x, out, hw, c, scale, shift, relu, mask_sums);
     return lf::check_launch("lf_gap_stats_bf16");
 }
 
@@ -280,8 +311,14 @@ int lf_block_tail_fwd_train_bf16(const uint16_t* y, const float* a_scale, const 
                    (reinterpret_cast<size_t>(route) & 1) == 0,
                "lf_block_tail_fwd_train_bf16: misaligned buffer");
     TailTrainArgs t{y, a_scale, a_shift, s, sc, sc_scale, sc_shift, drop, sc_relu, c, h, w};
-    tail_fwd_train_bf16_kernel<<<dim3(n * c, plane_grid((h / 2) * (w / 4))), kBlock, 0, lf::as_stream(stream)>>>(
-        t, route, pooled);
+    const bool wide = w % 8 == 0 && ((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(sc)) & 15) == 0 &&
+                      (reinterpret_cast<size_t>(pooled) & 7) == 0 && (reinterpret_cast<size_t>(route) & 3) == 0;
+    if (wide)
+        tail_fwd_train_bf16_kernel<8><<<dim3(n * c, plane_grid((h / 2) * (w / 8))), kBlock, 0, lf::as_stream(stream)>>>(
+            t, route, pooled);
+    else
+        tail_fwd_train_bf16_kernel<4><<<dim3(n * c, plane_grid((h / 2) * (w / 4))), kBlock, 0, lf::as_stream(stream)>>>(
+            t, route, pooled);
     return lf::check_launch("lf_block_tail_fwd_train_bf16");
 }
 
@@ -298,8 +335,14 @@ int lf_block_tail_bwd_bf16(const uint16_t* dp, const uint8_t* route, const uint1
                "lf_block_tail_bwd_bf16: y goes with ds / plane_sums");
     LF_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "lf_block_tail_bwd_bf16: a_scale/a_shift");
     LF_REQUIRE(al8(dr) && (reinterpret_cast<size_t>(dp) & 3) == 0, "lf_block_tail_bwd_bf16: misaligned buffer");
-    tail_bwd_bf16_kernel<<<n * c, kBlock, 0, lf::as_stream(stream)>>>(dp, route, y, a_scale, a_shift, drop, dr, ds,
-                                                                     plane_sums, sc_y, sc_sums, c, h, w);
+    const bool wide = w % 8 == 0 && (reinterpret_cast<size_t>(dr) & 15) == 0 && (reinterpret_cast<size_t>(dp) & 7) == 0 &&
+                      (reinterpret_cast<size_t>(route) & 3) == 0;
+    if (wide)
+        tail_bwd_bf16_kernel<8><<<n * c, kBlock, 0, lf::as_stream(stream)>>>(dp, route, y, a_scale, a_shift, drop, dr,
+                                                                            ds, plane_sums, sc_y, sc_sums, c, h, w);
+    else
+        tail_bwd_bf16_kernel<4><<<n * c, kBlock, 0, lf::as_stream(stream)>>>(dp, route, y, a_scale, a_shift, drop, dr,
+                                                                            ds, plane_sums, sc_y, sc_sums, c, h, w);
     return lf::check_launch("lf_block_tail_bwd_bf16");
 }
 

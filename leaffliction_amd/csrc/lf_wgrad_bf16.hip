@@ -40,26 +40,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSumT = 256;
 
-struct WgBf16Args {
-    const uint16_t* x;   // [N][Cin][H][W] bf16 (STEM: const float*, fp32 [N][Cin][H][W])
-    const uint16_t* g;   // [N][Cout][H][W] bf16: dY itself, or the upstream gradient when bn_y is set
-    float* part;         // [splits][Cin][TAPS][Cout]
-    const float* in_scale;  // optional prologue on A: relu?(x*scale[ci]+shift[ci])
-    const float* in_shift;
-    int in_relu;
-    int n, cin, cout, h, w;
-    int tiles_x, tiles_y, items, items_per_split;
-    // optional: dY = BatchNorm backward of g (BN input bn_y), formed while staging:
-    //   dz = (g*alpha[n][co] + add[n][co]) * [bn_y*coef0[co] + coef1[co] > 0 or !bn_relu]
-    //   dY = bf16(coef2[co]*dz + coef3[co]*bn_y + coef4[co])
-    // and written to dy_out (may be null) by the ci-block-0 workgroups, each element once
-    const uint16_t* bn_y;
-    const float* bn_alpha;
-    const float* bn_add;
-    const float* bn_coef;  // [5][Cout]
-    uint16_t* dy_out;
-    int bn_relu;
-};
+using WgBf16Args = lf::WgradBf16Args;
 
 __device__ __forceinline__ float up(unsigned bits16) { return __uint_as_float(bits16 << 16); }
 
@@ -625,7 +606,10 @@ int lf_conv2d_wgrad_bf16(const void* x, const uint16_t* g, const uint16_t* bn_y,
     dim3 grid(pl.splits, pl.gy, pl.gz);
     hipStream_t s = lf::as_stream(stream);
     int rc;
-    if (pl.stem)
+    if (!pl.stem && lf::wgrad_bf16_pc_covers(cin, cout, w, ksize, pl.tw, pl.th) && pl.cib == 1 &&
+        pl.cob == cout / 32)
+        rc = lf::wgrad_bf16_pc_launch(a, pl.tw, pl.cob, grid, s);
+    else if (pl.stem)
         rc = a.w % 8 == 0 ? launch_wg<1, 32, 8, 1, 1, true, 8>(a, grid, s)
                           : launch_wg<1, 32, 8, 1, 1, true, 4>(a, grid, s);
     else
