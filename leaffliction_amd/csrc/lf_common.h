@@ -75,8 +75,7 @@ struct ConvBf16TrainArgs {
     int mask_relu;
     int tiles_x, tiles_y, items, items_per_wg;  // filled by the streaming launcher
 };
-// lf_conv2d_wgrad_bf16: the general kernel (lf_wgrad_bf16.hip) and the producer / consumer kernel for
-// the large-tensor stages (lf_wgrad_bf16_pc.hip) take the same arguments
+// arguments of the bf16 weight-gradient kernel (lf_wgrad_bf16.hip)
 struct WgradBf16Args {
     const uint16_t* x;   // [N][Cin][H][W] bf16 (STEM: const float*, fp32 [N][Cin][H][W])
     const uint16_t* g;   // [N][Cout][H][W] bf16: dY itself, or the upstream gradient when bn_y is set
@@ -97,8 +96,6 @@ struct WgradBf16Args {
     uint16_t* dy_out;
     int bn_relu;
 };
-bool wgrad_bf16_pc_covers(int cin, int cout, int w, int ksize, int tw, int th);
-int wgrad_bf16_pc_launch(const WgradBf16Args& a, int tw, int cob, dim3 grid, hipStream_t s);
 
 long long conv_bf16s_parts(int n, int cin, int h, int w, int cout, int ksize, int x_bf16);  // 0 = shape not covered
 int conv_bf16s_launch(ConvBf16TrainArgs a, int ksize, int x_bf16, hipStream_t s);

@@ -57,7 +57,7 @@ __device__ __forceinline__ unsigned img_off(unsigned pixel, unsigned quad) {
     return pixel * 64u + ((quad ^ ((pixel >> 2) & 7u)) << 3);
 }
 
-template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM>
+template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM, int WPRQ = 0>
 struct WgShape {
     static constexpr int HALO = (TAPS == 9 && !STEM) ? 1 : 0;
     static constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO;
@@ -69,16 +69,16 @@ struct WgShape {
     static constexpr int ROWS = TAPS == 9 ? 3 : 1;    // filter rows spread over waves
     // waves per filter row (they split the sub-blocks / K): 3x3 with one or two sub-blocks runs 6
     // waves (<= 2 per SIMD: 256 registers each), 2x2 sub-blocks 12 waves (one sub-block each)
-    static constexpr int WPR = TAPS == 9 ? (CIB * COB == 4 ? 4 : 2) : 4;
+    static constexpr int WPR = WPRQ ? WPRQ : (TAPS == 9 ? (CIB * COB == 4 ? 4 : 2) : 4);
     static constexpr int NT = 64 * WPR * ROWS;
 };
 
 // G = pixels per staging unit: 8 (16-byte global accesses: the vector memory pipe moves ~5.3 TB/s
 // with 16-byte lanes, ~3 TB/s with 8-byte lanes, ~1.5 TB/s with 4-byte lanes —
 // scripts/microbench/seg_bw.hip) when rows are 16-byte aligned (w % 8 == 0), else 4.
-template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM, int G>
-__global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM>::NT), 1) void wgrad_bf16_kernel(WgBf16Args p) {
-    using S = WgShape<TAPS, TW, TH, CIB, COB, STEM>;
+template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM, int G, int WPRQ = 0>
+__global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 1) void wgrad_bf16_kernel(WgBf16Args p) {
+    using S = WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>;
     static_assert((G == 4 || G == 8) && TW % G == 0, "staging groups of 4 or 8 pixels");
     typedef unsigned uvec __attribute__((ext_vector_type(G / 2)));   // G bf16
     constexpr int kT = S::NT, ROWS = S::ROWS, TPW = TAPS / ROWS;  // taps per wave
@@ -519,19 +519,19 @@ WgBf16Plan plan_wgrad_bf16(int n, int cin, int cout, int h, int w, int ksize) {
 
 constexpr int kSumGroup = 32;
 
-template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM, int G>
+template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM, int G, int WPRQ = 0>
 int launch_wg(const WgBf16Args& a, dim3 grid, hipStream_t s) {
-    using S = WgShape<TAPS, TW, TH, CIB, COB, STEM>;
+    using S = WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<TAPS, TW, TH, CIB, COB, STEM, G>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<TAPS, TW, TH, CIB, COB, STEM, G, WPRQ>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess) {
             lf::set_error("lf_conv2d_wgrad_bf16: cannot reserve %d bytes of LDS", S::LDS);
             return LF_ERR_LAUNCH;
         }
         raised = true;
     }
-    wgrad_bf16_kernel<TAPS, TW, TH, CIB, COB, STEM, G><<<grid, S::NT, S::LDS, s>>>(a);
+    wgrad_bf16_kernel<TAPS, TW, TH, CIB, COB, STEM, G, WPRQ><<<grid, S::NT, S::LDS, s>>>(a);
     return LF_OK;
 }
 
@@ -606,9 +606,12 @@ int lf_conv2d_wgrad_bf16(const void* x, const uint16_t* g, const uint16_t* bn_y,
     dim3 grid(pl.splits, pl.gy, pl.gz);
     hipStream_t s = lf::as_stream(stream);
     int rc;
-    if (!pl.stem && lf::wgrad_bf16_pc_covers(cin, cout, w, ksize, pl.tw, pl.th) && pl.cib == 1 &&
-        pl.cob == cout / 32)
-        rc = lf::wgrad_bf16_pc_launch(a, pl.tw, pl.cob, grid, s);
+    // one 32-channel block each way (32->32 at 224x224, the largest tensors): measured on one MI355X
+    // box — 12 waves with 8-byte staging groups 1.35 ms, 6 waves with 16-byte groups 1.52 ms, a
+    // producer/consumer split with two tiles of loads in flight 1.57 ms, 12 waves with 16-byte groups
+    // (register spills) 2.52 ms: this shape wants waves more than it wants wide loads
+    if (!pl.stem && ksize == 3 && pl.cib == 1 && pl.cob == 1 && pl.tw == 56)
+        rc = launch_wg<9, 56, 4, 1, 1, false, 4, 4>(a, grid, s);
     else if (pl.stem)
         rc = a.w % 8 == 0 ? launch_wg<1, 32, 8, 1, 1, true, 8>(a, grid, s)
                           : launch_wg<1, 32, 8, 1, 1, true, 4>(a, grid, s);
