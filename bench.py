@@ -76,7 +76,13 @@ class KernelTimer:
             if name == "lf_conv2d_bf16_train":
                 n, cin, h, w, cout, k = args[4:10]
                 px = n * h * w
-                kname = f"conv_bf16_kernel<{k * k},{'2,2' if cout % 64 == 0 else '1,4'}> {cin}->{cout}@{h}"
+                stem = (not args[1]) and cin <= 3 and k == 3 and cout == 32
+                if cout in (32, 64) and w % 8 == 0 and (stem or (args[1] and cin in (32, 64))) and \
+                        (k == 3 or (cin, cout) in ((32, 64), (64, 32))):
+                    tw, th = (32, 8) if (w % 32 == 0 or w > 128) else (16, 16)   # plan_s of lf_conv_bf16s.hip
+                    kname = f"conv_bf16s_kernel<{k * k},{16 if stem else cin},{cout // 32},{tw},{th}> {cin}->{cout}@{h}"
+                else:
+                    kname = f"conv_bf16_kernel<{k * k},{'2,2' if cout % 64 == 0 else '1,4'}> {cin}->{cout}@{h}"
                 nbytes = px * ((2.0 if args[1] else 4.0) * cin + 2.0 * cout) + 2.0 * cin * cout * k * k
                 nbytes += 2.0 * px * cout * ((1 if args[13] else 0) + (1 if args[17] else 0))
                 timer.records.append((kname, 2.0 * px * cin * cout * k * k, e0, e1, nbytes))
@@ -123,11 +129,25 @@ class KernelTimer:
                 for k, v in agg.items()}
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU
+    box shows every core of the host but grants a share of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(seconds_budget: float = 25.0):
     """The oracle (torch CPU fp32 restatement of the reference's Keras train step) timed on
     this box's host cores: base preset, img 224, batch 32 (the reference default, train.py:67)."""
     from oracle import cnn_ref as R
-    threads = torch.get_num_threads()
+    threads = usable_cores()
+    torch.set_num_threads(threads)   # not torch's default (every core it can see): no oversubscription
     bs = 32
     params = R.init_params(NUM_CLASSES, WIDTHS, seed=0)
     state = R.init_state(WIDTHS)
@@ -147,6 +167,7 @@ def cpu_baseline(seconds_budget: float = 25.0):
         t_used += time.perf_counter() - t0
         steps += 1
     return {"value": round(bs * steps / t_used, 2), "unit": "images/sec", "cores": threads,
+            "gflops": round(TRAIN_GFLOP_PER_IMG * bs * steps / t_used, 1),
             "kind": "port",
             "sample": f"{steps} training steps of leaf_cnn base at 224x224, batch {bs}, fp32 "
                       f"(oracle/cnn_ref.py on torch CPU, {threads} threads)"}
@@ -275,6 +296,131 @@ def augment_throughput(dev, n=4096, iters=5, only=None):
     return out
 
 
+# ---- end to end: `Augmentation.py` over synthetic 224x224 JPEGs (BASELINE configs[2]) -----------
+_E2E_LAYOUT = {"Apple": {"healthy": 2500, "rust": 500, "scab": 500, "rot": 500},
+               "Grape": {"healthy": 2500, "esca": 1000, "spot": 500, "blight": 500}}   # 11,500 to generate
+
+
+def _e2e_write(job):
+    from PIL import Image
+    arr, path = job
+    Image.fromarray(arr).save(path, quality=95)
+    return True
+
+
+def _e2e_make_dataset(root: Path, dev, threads: int) -> int:
+    """8,500 synthetic originals: low-frequency colour fields + noise (JPEG sizes like photographs:
+    ~25 KB), generated on the GPU in chunks, encoded on host threads.  Not timed."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = torch.Generator(device=dev).manual_seed(42)
+    jobs = []
+    for plant, classes in _E2E_LAYOUT.items():
+        for cls, n in classes.items():
+            d = root / plant / f"{plant}_{cls}"
+            d.mkdir(parents=True)
+            jobs += [d / f"image ({i + 1}).JPG" for i in range(n)]
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        for b0 in range(0, len(jobs), 512):
+            paths = jobs[b0:b0 + 512]
+            low = torch.rand((len(paths), 3, 14, 14), generator=g, device=dev)
+            img = torch.nn.functional.interpolate(low, size=(IMG, IMG), mode="bilinear", align_corners=False)
+            img = (img * 255 + torch.randn(img.shape, generator=g, device=dev) * 8).clamp_(0, 255)
+            arr = img.permute(0, 2, 3, 1).to(torch.uint8).cpu().numpy()
+            list(pool.map(_e2e_write, [(arr[i], paths[i]) for i in range(len(paths))]))
+    return len(jobs)
+
+
+def _pil_task(task):
+    """One task the way the reference's pool worker does it (image_augmenter.py:20-133): Pillow decode ->
+    one of the six operations with the task's seed -> Pillow encode, quality 95."""
+    import random
+
+    import numpy as np
+    from PIL import Image, ImageOps
+    src, dst, op, seed = task
+    random.seed(seed)
+    np.random.seed(seed)
+    im = Image.open(src).convert("RGB")
+    W, H = im.size
+    if op == "flip":
+        out = im.transpose(Image.FLIP_LEFT_RIGHT if random.choice([True, False]) else Image.FLIP_TOP_BOTTOM)
+    elif op == "rotate":
+        out = im.rotate(random.uniform(-30, 30), expand=True, fillcolor="white")
+    elif op == "skew":
+        f = random.uniform(0.05, 0.15)
+        out = im.transform((W, H), Image.PERSPECTIVE, [1 + f, 0, -f * W, 0, 1 + f, -f * H, 0, 0], Image.BICUBIC)
+    elif op == "shear":
+        v = random.uniform(-0.2, 0.2)
+        out = im.transform((W, H), Image.AFFINE, [1, v, 0, 0, 1, 0] if random.choice([True, False]) else [1, 0, 0, v, 1, 0],
+                           Image.BICUBIC)
+    elif op == "crop":
+        r = random.uniform(0.8, 0.95)
+        nw, nh = int(W * r), int(H * r)
+        left, top = random.randint(0, W - nw), random.randint(0, H - nh)
+        out = im.crop((left, top, left + nw, top + nh)).resize((W, H), Image.LANCZOS)
+    else:
+        a = np.array(im)
+        out = ImageOps.autocontrast(Image.fromarray(a + np.random.normal(0, 5, a.shape).astype(np.uint8)),
+                                    cutoff=random.uniform(0, 2))
+    out.save(dst, quality=95)
+    return True
+
+
+def augment_end_to_end(dev):
+    """The rate a user of `Augmentation.py` sees (BASELINE configs[2]): DatasetBalancer.run() over a
+    synthetic dataset of 8,500 224x224 JPEGs -> 11,500 generated files + manifest (JPEG decode on host
+    threads -> H2D -> kernels -> D2H -> JPEG encode, plus the copy of the originals), and beside it the
+    same task list run the reference's way — one Pillow call chain per task in a process pool — with the
+    reference's default worker count (dataset_balancer.py:41-44) and with every core, on a bounded sample."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ProcessPoolExecutor
+
+    from leaffliction_amd.preprocessing.dataset_balancer import DatasetBalancer
+    from leaffliction_amd.utils.system_info import get_available_cores, get_optimal_worker_count
+    cores = min(get_available_cores(), usable_cores())
+    tmp = Path(tempfile.mkdtemp(prefix="lf_e2e_"))
+    cwd = os.getcwd()
+    try:
+        src, dst = tmp / "images", tmp / "augmented"
+        n_orig = _e2e_make_dataset(src, dev, cores)
+        os.chdir(tmp)
+        bal = DatasetBalancer(source_dir=str(src), target_dir=str(dst), seed=42,
+                              workers=min(cores, get_optimal_worker_count()))
+        bal.analyze_distribution()
+        bal.calculate_plan()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bal.execute_balancing()
+        sec = time.perf_counter() - t0
+        out = {"images_per_sec": round(bal.completed / sec, 1), "generated": bal.completed, "failed": bal.failed,
+               "originals": n_orig, "seconds": round(sec, 2), "codec_processes": bal.workers, "host_cores": cores,
+               "stage_seconds": {k: round(v, 2) for k, v in bal.timings.items()},
+               "pipeline_images_per_sec": round(bal.completed / max(
+                   bal.timings.get("decode_kernels_encode", sec) - bal.timings.get("codec_pool_start", 0.0), 1e-6), 1),
+               "includes": "copy of the originals, JPEG decode, H2D, kernels, D2H, JPEG encode (q=95), manifest"}
+        # CPU pools on a sample of the same task list (fresh output names in a scratch tree)
+        sample = bal.tasks[:: max(1, len(bal.tasks) // 1500)][:1500]
+        scratch = tmp / "cpu_out"
+        scratch.mkdir()
+        jobs = [(t["source_img"], str(scratch / f"{i}.jpg"), t["transform_name"], t["seed"]) for i, t in enumerate(sample)]
+        pools = {}
+        ref_default = max(1, int(cores * 0.75) // 2)   # dataset_balancer.py:41-44 with system_info.py:37-46
+        for label, workers in (("reference_default_workers", ref_default), ("all_cores", cores)):
+            with ProcessPoolExecutor(max_workers=workers) as ex:
+                list(ex.map(_pil_task, jobs[:workers * 2], chunksize=1))   # start the workers
+                t0 = time.perf_counter()
+                list(ex.map(_pil_task, jobs, chunksize=8))
+                dt = time.perf_counter() - t0
+            pools[label] = {"images_per_sec": round(len(jobs) / dt, 1), "workers": workers, "tasks": len(jobs)}
+        out["cpu_pool_baseline"] = {"kind": "the reference's libraries (Pillow/numpy call chain of image_augmenter.py, one "
+                                            "process per worker, file -> file)", "cores": cores, **pools}
+        return out
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def inference_throughput(model, dev, batch=1024, iters=5):
     """Forward pass only (predict.py's batch mode, BASELINE configs[4] shape: 1024 images per GPU;
     fp32 here): uint8 batch resident in HBM -> pack/normalise -> conv stack (inference
@@ -300,9 +446,17 @@ def inference_throughput(model, dev, batch=1024, iters=5):
         labels16 = model.predict_device(x).argmax(-1)
     torch.cuda.synchronize()
     sec16 = (time.perf_counter() - t0) / iters
+    p16 = model.predict_device(x).clone()
     model.set_inference_dtype("f32")
+    p32 = model.predict_device(x)
+    top2 = p32.topk(2).values
     out["bf16"] = {"images_per_sec": round(batch / sec16, 1),
                    "tflops": round(TRAIN_GFLOP_PER_IMG / 3.0 * batch / sec16 / 1e3, 2),
+                   # weights here are a few steps from random init: the fp32 top-2 margin is ~1e-3, far
+                   # inside ANY reduced-precision error, so label agreement on THIS model says nothing; the
+                   # confusion-matrix check on a trained model is tests/test_cnn_gpu.py
+                   "max_abs_prob_diff_vs_f32": round(float((p16 - p32).abs().max().item()), 5),
+                   "median_top2_margin_f32": round(float((top2[:, 0] - top2[:, 1]).median().item()), 5),
                    "labels_equal_to_f32": float((labels16 == labels).float().mean().item())}
     return out
 
@@ -320,6 +474,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-augment", action="store_true", help="skip the augmentation-pass measurement")
     ap.add_argument("--no-inference", action="store_true", help="skip the forward-only measurement")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end Augmentation.py measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -418,6 +573,17 @@ def main() -> None:
         conv_b = sum(v["bytes"] for v in kern.values())
         conv_f = sum(v["flop"] for v in kern.values())
         gbs = dk["bytes"] / dk["seconds"] / 1e9
+        traffic, traffic_source = None, None
+        pmc = ROOT / "profiles" / "pmc_latest_bf16.json"
+        if pmc.exists():   # committed rocprofv3 PMC summary of `bench.py --dtype bf16` (not taken in this run)
+            try:
+                doc = json.loads(pmc.read_text())
+                tmpl = dname.split(">")[0].replace("<", "<").strip()
+                hit = [v for kk, v in doc.items() if kk != "_source" and kk.replace(" ", "").startswith(tmpl.replace(" ", ""))]
+                traffic = hit[0] if hit else None
+                traffic_source = {"file": "profiles/pmc_latest_bf16.json", **doc.get("_source", {})}
+            except Exception:
+                traffic = None
         return {"images_per_sec": round(world * n * steps / sec, 2), "ms_per_step": round(sec / steps * 1e3, 3),
                 "steps": steps, "dtype": "bf16 storage + bf16 MFMA operands, fp32 accumulate / BN / SE / softmax / "
                                          "master weights",
@@ -425,7 +591,9 @@ def main() -> None:
                 "frac_of_bf16_mfma_peak_2500TF": round(TRAIN_GFLOP_PER_IMG * n * steps / sec / 1e3 / 2500.0, 4),
                 "final_loss": round(fl, 4),
                 "roofline": {"bound": "hbm", "kernel": dname, "achieved": round(gbs, 1), "peak": 8000.0,
-                             "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                             "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": traffic,
+                             "traffic_unit": "L2 fabric-side bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE; "
+                                             "includes Infinity-Cache hits)", "traffic_source": traffic_source,
                              "algorithmic_bytes_per_launch": round(dk["bytes"] / dk["launches"]),
                              "launches_per_step": dk["launches"] / ksteps,
                              "avg_launch_ms": round(dk["seconds"] / dk["launches"] * 1e3, 4),
@@ -503,11 +671,15 @@ def main() -> None:
         achieved = dom["flop"] / dom["seconds"] / 1e12
         conv_s = sum(v["seconds"] for v in kern.values())
         conv_f = sum(v["flop"] for v in kern.values())
-        traffic = None
+        # HBM bytes per launch from rocprofv3 PMC passes are NOT taken in this run (counters need their
+        # own passes): the figure is the committed summary's, with where it came from next to it
+        traffic, traffic_source = None, None
         pmc = ROOT / "profiles" / "pmc_latest.json"
         if pmc.exists():
             try:
-                traffic = json.loads(pmc.read_text()).get(dom_name)
+                doc = json.loads(pmc.read_text())
+                traffic = doc.get(dom_name)
+                traffic_source = {"file": "profiles/pmc_latest.json", **doc.get("_source", {"command": "scripts/profile_round.sh (round 1, tag j)"})}
             except Exception:
                 traffic = None
         images = world * n * args.steps
@@ -532,6 +704,7 @@ def main() -> None:
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                          "launches_per_step": dom["launches"] / ksteps,
                          "measured": f"HIP events around each launch, {ksteps} eager steps right after the timed "
@@ -555,6 +728,8 @@ def main() -> None:
             out["augment"] = augment_throughput(dev)
             if not args.no_cpu_baseline:
                 out["augment"]["cpu_baseline"] = cpu_augment_baseline()
+            if not args.no_e2e:
+                out["augment"]["end_to_end"] = augment_end_to_end(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -88,6 +88,12 @@ int lf_flip_u8(const uint8_t* in, uint8_t* out, const int32_t* mode, int n, int 
 int lf_noise_wrap_add_u8(const uint8_t* in, const double* noise, uint8_t* out, size_t nbytes,
                          lf_stream_t stream);
 
+/* The same wrap-around add when the noise was already cast to uint8 on the host (numpy's own
+ * astype, image_augmenter.py:121-123; the codec worker processes of DatasetBalancer do that next
+ * to the JPEG decode): out = in + add mod 256, bytewise.  nbytes % 4 == 0, 4-byte aligned. */
+int lf_add_wrap_u8(const uint8_t* in, const uint8_t* add, uint8_t* out, size_t nbytes,
+                   lf_stream_t stream);
+
 /* Same op with the noise drawn on the device: counter-based Philox4x32-10 +
  * Box-Muller N(0, sigma) keyed by (seed, byte index).  Statistically, not
  * bit-wise, equal to the numpy stream; used for the synthetic C3 pass. */

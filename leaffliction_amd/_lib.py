@@ -30,6 +30,7 @@ SIGNATURES = {
     "lf_gather_rows_u8": [P, P, P, c_int, c_size_t, P],
     "lf_flip_u8": [P, P, P, c_int, c_int, c_int, P],
     "lf_noise_wrap_add_u8": [P, P, P, c_size_t, P],
+    "lf_add_wrap_u8": [P, P, P, c_size_t, P],
     "lf_noise_philox_add_u8": [P, P, c_size_t, c_u64, c_float, P],
     "lf_mask_composite_u8": [P, P, P, c_int, c_int, c_int, c_int, P],
     "lf_rgb2hsv_u8": [P, P, c_size_t, P],

@@ -349,6 +349,18 @@ __global__ __launch_bounds__(kBlock) void noise_add_kernel(const uint8_t* __rest
     }
 }
 
+// out = in + add (mod 256) on whole dwords: the same wrap-around add when the noise has already been
+// cast to uint8 on the host (numpy's own astype, image_augmenter.py:121-123)
+__global__ __launch_bounds__(kBlock) void add_wrap_u8_kernel(const uint32_t* __restrict__ a,
+                                                             const uint32_t* __restrict__ b,
+                                                             uint32_t* __restrict__ out, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nwords; i += (size_t)gridDim.x * kBlock) {
+        const uint32_t x = a[i], y = b[i];
+        // per-byte add without carries across bytes
+        out[i] = ((x & 0x7f7f7f7fu) + (y & 0x7f7f7f7fu)) ^ ((x ^ y) & 0x80808080u);
+    }
+}
+
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t* r) {
 #pragma unroll
@@ -1021,6 +1033,17 @@ int lf_noise_wrap_add_u8(const uint8_t* in, const double* noise, uint8_t* out, s
     noise_add_kernel<<<lf::stream_grid(nbytes, kBlock), kBlock, 0, lf::as_stream(stream)>>>(
         in, noise, out, nbytes);
     return lf::check_launch("lf_noise_wrap_add");
+}
+
+int lf_add_wrap_u8(const uint8_t* in, const uint8_t* add, uint8_t* out, size_t nbytes, lf_stream_t stream) {
+    LF_REQUIRE(in && add && out, "lf_add_wrap_u8: null buffer");
+    LF_REQUIRE(nbytes > 0 && nbytes % 4 == 0, "lf_add_wrap_u8: size must be a positive multiple of 4 bytes");
+    LF_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(add) | reinterpret_cast<size_t>(out)) & 3) == 0,
+               "lf_add_wrap_u8: buffers must be 4-byte aligned");
+    add_wrap_u8_kernel<<<lf::stream_grid(nbytes / 4, kBlock, lf::kFullGrid), kBlock, 0, lf::as_stream(stream)>>>(
+        reinterpret_cast<const uint32_t*>(in), reinterpret_cast<const uint32_t*>(add),
+        reinterpret_cast<uint32_t*>(out), nbytes / 4);
+    return lf::check_launch("lf_add_wrap_u8");
 }
 
 int lf_noise_philox_add_u8(const uint8_t* in, uint8_t* out, size_t nbytes, uint64_t seed,

@@ -74,6 +74,11 @@ struct ConvBf16TrainArgs {
     const float* mask_shift;
     int mask_relu;
     int tiles_x, tiles_y, items, items_per_wg;  // filled by the streaming launcher
+    // inference: v*out_scale[co]+out_shift[co] (+ReLU) on the fp32 accumulators before rounding — the
+    // layer's folded BatchNorm(+ReLU), so that what is stored is the activation itself
+    const float* out_scale;
+    const float* out_shift;
+    int out_relu;
 };
 // arguments of the bf16 weight-gradient kernel (lf_wgrad_bf16.hip)
 struct WgradBf16Args {

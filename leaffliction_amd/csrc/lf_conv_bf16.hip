@@ -85,14 +85,14 @@ __device__ __forceinline__ uint16_t bf16_down(float v) { return __builtin_bit_ca
 // occupancy brings — 40.4 k and 24.5 k img/s against 47.3 k for the whole forward pass)
 template <int TAPS, int NCO, int NB, bool XBF, bool YBF, bool TR = false, bool WIDE = false>
 __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
-    static_assert(!WIDE || (TR && NCO == 2 && NB == 2), "the 16-byte epilogue: training, 32x8 tile");
+    static_assert(!WIDE || (YBF && NCO == 2 && NB == 2), "the 16-byte epilogue: bf16 output, 32x8 tile");
     static_assert(!TR || YBF, "the training epilogue stores bf16");
     constexpr int kTH = 4 * NB;
     constexpr int R = TAPS == 9 ? 1 : 0, PH = kTH + 2 * R, KS = TAPS == 9 ? 3 : 1;
     // one LDS buffer: input patch | weight slice; the training epilogue's transpose buffer (fp32
     // [32 channels][256 pixels]) reuses it once the chunk loop is done
     constexpr int kPatchB = 8 * PH * kPW * 4, kWlB = TAPS * NCO * 32 * 2 * 16;
-    constexpr bool kWide = WIDE;   // training, 32x8 tile, w % 8 == 0: 16-byte epilogue through LDS
+    constexpr bool kWide = WIDE;   // bf16 output, 32x8 tile, w % 8 == 0: 16-byte epilogue through LDS
     constexpr int kSmemB = (kWide && kPatchB + kWlB < 32 * 256 * 4) ? 32 * 256 * 4 : kPatchB + kWlB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kSmemB];
     uint32_t (*patch)[PH][kPW] = reinterpret_cast<uint32_t (*)[PH][kPW]>(smem);
@@ -247,19 +247,20 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     const int egy = y0 + (eg >> 2), egx = x0 + 8 * (eg & 3);
     const bool eok = egy < p.h && egx < p.w;
     const size_t epo = eok ? (size_t)egy * p.w + egx : 0;
-    uvec4 rold[kWide ? NCO : 1][4], rmask[kWide ? NCO : 1][4];
+    uvec4 rold[(kWide && TR) ? NCO : 1][4], rmask[(kWide && TR) ? NCO : 1][4];
     auto request_rmw = [&]() {
+        if (!TR) return;  // inference: nothing is read back
         const uint16_t* yold = static_cast<const uint16_t*>(p.y) + (size_t)n * p.cout * hw;
         if (p.accumulate)
 #pragma unroll
-            for (int cb = 0; cb < (kWide ? NCO : 1); ++cb)
+            for (int cb = 0; cb < ((kWide && TR) ? NCO : 1); ++cb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     rold[cb][j] = *reinterpret_cast<const uvec4*>(yold + (size_t)(co0 + cb * 32 + 8 * j + ec) * hw + epo);
         if (p.stat_mask_y != nullptr) {
             const uint16_t* ym = p.stat_mask_y + (size_t)n * p.cout * hw;
 #pragma unroll
-            for (int cb = 0; cb < (kWide ? NCO : 1); ++cb)
+            for (int cb = 0; cb < ((kWide && TR) ? NCO : 1); ++cb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     rmask[cb][j] = *reinterpret_cast<const uvec4*>(ym + (size_t)(co0 + cb * 32 + 8 * j + ec) * hw + epo);
@@ -307,6 +308,82 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     float* yn = static_cast<float*>(p.y) + (YBF ? 0 : (size_t)n * p.cout * hw);
     uint16_t* yb = static_cast<uint16_t*>(p.y) + (YBF ? (size_t)n * p.cout * hw : 0);
     const int gx = x0 + px;
+    const bool stats = p.stat_part != nullptr, masked = p.stat_mask_y != nullptr;
+    if (wide) {
+        // through LDS: lane (pixel, 16 channels) -> thread (8 pixels, one channel): 16-byte stores,
+        // and a channel's whole tile sits in one half-wave (no cross-wave reduction)
+        float* le = reinterpret_cast<float*>(smem);
+        uint16_t* yout = static_cast<uint16_t*>(p.y) + (size_t)n * p.cout * hw;
+        const long long tg = (long long)n * gridDim.x + tile;
+#pragma unroll
+        for (int cb = 0; cb < NCO; ++cb) {
+            __syncthreads();  // every wave is done with the staging LDS / with the previous block
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = 8 * (r >> 2) + 4 * half + (r & 3);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) le[cl * 256 + (NB * wv + nb) * 32 + px] = acc[nb][cb][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cl = 8 * j + ec, co = co0 + cb * 32 + cl;
+                const lf::f32x4 a0 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg);
+                const lf::f32x4 a1 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg + 4);
+                float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                if (TR && p.accumulate)
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        v[e] += bf16_up(rold[TR ? cb : 0][j][e / 2] & 0xffffu);
+                        v[e + 1] += bf16_up(rold[TR ? cb : 0][j][e / 2] >> 16);
+                    }
+                if (p.out_scale) {
+                    const float osc = eps[0][cb * 32 + cl], osh = eps[1][cb * 32 + cl];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], osc, osh);
+                }
+                if (p.out_relu)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+                uvec4 o;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) o[e / 2] = pack_bf16(v[e], v[e + 1]);
+                if (eok) *reinterpret_cast<uvec4*>(yout + (size_t)co * hw + epo) = o;
+                if (!TR || !stats) continue;
+                float a = 0.f, b = 0.f;
+                if (eok) {
+                    if (!masked) {
+                        const float pv = p.stat_pivot != nullptr ? p.stat_pivot[co] : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float d = bf16_up((e & 1) ? o[e / 2] >> 16 : o[e / 2] & 0xffffu) - pv;
+                            a += d;
+                            b = fmaf(d, d, b);
+                        }
+                    } else {
+                        const float msc = p.mask_scale[co], msh = p.mask_shift[co];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float rv = bf16_up((e & 1) ? o[e / 2] >> 16 : o[e / 2] & 0xffffu);
+                            const unsigned mw = rmask[TR ? cb : 0][j][e / 2];
+                            const float yv = bf16_up((e & 1) ? mw >> 16 : mw & 0xffffu);
+                            const float d = (!p.mask_relu || fmaf(yv, msc, msh) > 0.f) ? rv : 0.f;
+                            a += d;
+                            b = fmaf(d, yv, b);
+                        }
+                    }
+                }
+                a = half_sum32(a);
+                b = half_sum32(b);
+                if (eg == 31) {
+                    float* dst = p.stat_part + ((size_t)co * (size_t)p.stat_tiles + (size_t)tg) * 2;
+                    dst[0] = a;
+                    dst[1] = b;
+                }
+            }
+        }
+        return;
+    }
     if (!TR) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -332,74 +409,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     }
     // ---- training: bf16 store (optionally on top of the old value) + per-tile channel sums of
     // the rounded values
-    const bool stats = p.stat_part != nullptr, masked = p.stat_mask_y != nullptr;
-    if (wide) {
-        // through LDS: lane (pixel, 16 channels) -> thread (8 pixels, one channel): 16-byte stores,
-        // and a channel's whole tile sits in one half-wave (no cross-wave reduction)
-        float* le = reinterpret_cast<float*>(smem);
-        uint16_t* yout = static_cast<uint16_t*>(p.y) + (size_t)n * p.cout * hw;
-        const long long tg = (long long)n * gridDim.x + tile;
-#pragma unroll
-        for (int cb = 0; cb < NCO; ++cb) {
-            __syncthreads();  // every wave is done with the staging LDS / with the previous block
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cl = 8 * (r >> 2) + 4 * half + (r & 3);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) le[cl * 256 + (NB * wv + nb) * 32 + px] = acc[nb][cb][r];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int cl = 8 * j + ec, co = co0 + cb * 32 + cl;
-                const lf::f32x4 a0 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg);
-                const lf::f32x4 a1 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg + 4);
-                float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                if (p.accumulate)
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        v[e] += bf16_up(rold[cb][j][e / 2] & 0xffffu);
-                        v[e + 1] += bf16_up(rold[cb][j][e / 2] >> 16);
-                    }
-                uvec4 o;
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) o[e / 2] = pack_bf16(v[e], v[e + 1]);
-                if (eok) *reinterpret_cast<uvec4*>(yout + (size_t)co * hw + epo) = o;
-                if (!stats) continue;
-                float a = 0.f, b = 0.f;
-                if (eok) {
-                    if (!masked) {
-                        const float pv = p.stat_pivot != nullptr ? p.stat_pivot[co] : 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float d = bf16_up((e & 1) ? o[e / 2] >> 16 : o[e / 2] & 0xffffu) - pv;
-                            a += d;
-                            b = fmaf(d, d, b);
-                        }
-                    } else {
-                        const float msc = p.mask_scale[co], msh = p.mask_shift[co];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float rv = bf16_up((e & 1) ? o[e / 2] >> 16 : o[e / 2] & 0xffffu);
-                            const unsigned mw = rmask[cb][j][e / 2];
-                            const float yv = bf16_up((e & 1) ? mw >> 16 : mw & 0xffffu);
-                            const float d = (!p.mask_relu || fmaf(yv, msc, msh) > 0.f) ? rv : 0.f;
-                            a += d;
-                            b = fmaf(d, yv, b);
-                        }
-                    }
-                }
-                a = half_sum32(a);
-                b = half_sum32(b);
-                if (eg == 31) {
-                    float* dst = p.stat_part + ((size_t)co * (size_t)p.stat_tiles + (size_t)tg) * 2;
-                    dst[0] = a;
-                    dst[1] = b;
-                }
-            }
-        }
-        return;
-    }
+
     const uint16_t* my = masked ? p.stat_mask_y + (size_t)n * p.cout * hw : nullptr;
     float* red = reinterpret_cast<float*>(smem);  // [4 waves][NCO*32][2]
     static_assert(4 * NCO * 32 * 2 <= 8 * PH * kPW, "statistics scratch must fit the patch LDS");
@@ -586,8 +596,8 @@ template <bool XBF, bool YBF, bool TR>
 void launch_conv_bf16(const Bf16ConvArgs& a, int ksize, hipStream_t s) {
     const int nco = bf16_nco(a.cout);
     dim3 grid(bf16_tiles(a.h, a.w, a.cout), a.cout / (32 * nco), a.n);
-    constexpr bool W = TR;
-    const bool wide = TR && nco == 2 && a.w % 8 == 0;  // rows of 16 bytes: the epilogue through LDS
+    constexpr bool W = YBF;
+    const bool wide = YBF && nco == 2 && a.w % 8 == 0;  // rows of 16 bytes: the epilogue through LDS
     if (ksize == 3) {
         if (nco == 2) {
             if (wide) conv_bf16_kernel<9, 2, 2, XBF, YBF, TR, W><<<grid, kThreads, 0, s>>>(a);
@@ -641,12 +651,24 @@ int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y
     LF_REQUIRE(n <= 65535, "lf_conv2d_bf16: batch too large for grid.z");
     LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wprep)) & 15) == 0,
                "lf_conv2d_bf16: x and wprep must be 16-byte aligned");
+    hipStream_t s = lf::as_stream(stream);
+    if (y_bf16 && cout == 32 && lf::conv_bf16s_parts(n, cin, h, w, cout, ksize, x_bf16) > 0) {
+        // the 224x224 stage (stem, 32->32): the streaming kernel (resident filter bank, 16-byte accesses).
+        // With no read-modify-write epilogue the K-chunked kernel stays ahead on the 64-channel layers
+        // (1.7 ms against 3.2 ms at 64->64 / 112x112, batch 1,024), the other way round from training.
+        lf::ConvBf16TrainArgs t{};
+        t.x = x; t.wprep = wprep; t.y = static_cast<uint16_t*>(y); t.n = n; t.cin = cin; t.h = h; t.w = w; t.cout = cout;
+        t.in_scale = in_scale; t.in_shift = in_shift; t.in_relu = in_relu;
+        t.out_scale = out_scale; t.out_shift = out_shift; t.out_relu = out_relu;
+        const int rc = lf::conv_bf16s_launch(t, ksize, x_bf16, s);
+        if (rc != LF_OK) return rc;
+        return lf::check_launch("lf_conv2d_bf16");
+    }
     Bf16ConvArgs a{};
     a.x = x; a.wprep = wprep; a.y = y; a.n = n; a.cin = cin; a.h = h; a.w = w; a.cout = cout;
     a.chunks = (cin + 15) / 16;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
     a.out_scale = out_scale; a.out_shift = out_shift; a.out_relu = out_relu;
-    hipStream_t s = lf::as_stream(stream);
     if (x_bf16) {
         if (y_bf16) launch_conv_bf16<true, true, false>(a, ksize, s); else launch_conv_bf16<true, false, false>(a, ksize, s);
     } else {

@@ -96,6 +96,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     float* le = reinterpret_cast<float*>(lp);  // [32 channels][256 pixels], over the patch
     __shared__ float lsc[2 * CI];
     __shared__ float lst[2 * COUT];
+    __shared__ float los[2 * COUT];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 31, kh = lane >> 5;
     const size_t hw = (size_t)p.h * p.w;
@@ -121,6 +122,8 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
         for (int c = tid; c < COUT; c += kT) {  // per-channel epilogue constants: pivot | mask scale, mask shift
             lst[c] = masked ? p.mask_scale[c] : ((stats && p.stat_pivot != nullptr) ? p.stat_pivot[c] : 0.f);
             lst[COUT + c] = masked ? p.mask_shift[c] : 0.f;
+            los[c] = p.out_scale != nullptr ? p.out_scale[c] : 1.f;
+            los[COUT + c] = p.out_scale != nullptr ? p.out_shift[c] : 0.f;
         }
         if (!XBF)  // channels 4..15 of the stem's rows are never written by the staging: zero them once
             for (int e = tid; e < S::PBYTES / 16; e += kT)
@@ -363,6 +366,14 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
                         v[e] += up(rold[cb][j][e / 2] & 0xffffu);
                         v[e + 1] += up(rold[cb][j][e / 2] >> 16);
                     }
+                if (p.out_scale != nullptr) {
+                    const float osc = los[co], osh = los[COUT + co];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], osc, osh);
+                }
+                if (p.out_relu)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 uvec o;
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) o[e / 2] = pack2(v[e], v[e + 1]);

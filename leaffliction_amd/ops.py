@@ -130,6 +130,17 @@ def noise_wrap_add_u8(x: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def add_wrap_u8(x: torch.Tensor, add: torch.Tensor) -> torch.Tensor:
+    """x + add (mod 256), bytewise: the distortion's noise add when the noise is uint8 already."""
+    _chk(x, _U8, "add_wrap.x")
+    _chk(add, _U8, "add_wrap.add")
+    if add.shape != x.shape or x.numel() == 0 or x.numel() % 4:
+        raise ValueError("add_wrap: same non-empty shape, size a multiple of 4 bytes")
+    out = torch.empty_like(x)
+    _lib.call("lf_add_wrap_u8", x.data_ptr(), add.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
 def noise_philox_add_u8(x: torch.Tensor, seed: int, sigma: float = 5.0) -> torch.Tensor:
     _chk(x, _U8, "noise_philox.x")
     if x.numel() == 0:

@@ -1,0 +1,177 @@
+"""The JPEG edge of the balancer in worker PROCESSES, around the GPU stage.
+
+The reference decodes, transforms and encodes each task inside a pool process
+(srcs/preprocessing/dataset_balancer.py:137-141,201-207).  Here the transform runs on the GPU, but
+the two codec halves are still libjpeg on host cores, and they are the whole cost of the job
+(≈0.5 ms decode + ≈0.7 ms encode per 224x224 image against microseconds of kernels).  Python
+threads cannot feed that: 16 threads reached 1.8 k images/s on a box whose 16 cores run the
+reference's own process pool at 10.8 k images/s.  So the codec work goes to processes as well, and
+pixels cross the process boundary through shared memory, never through pickles:
+
+  decode worker: JPEG -> RGB uint8 written straight into the task's slot of the INPUT slab; the
+      task's random parameters are drawn there too (a fresh seeded RNG per task, exactly what the
+      reference's worker does), including the distortion's 150 k normal deviates, which are cast to
+      uint8 by numpy itself (image_augmenter.py:121-123) into the NOISE slab;
+  main process:  one H2D per (transform, size) group, batched kernels, D2H into the OUTPUT slab;
+  encode worker: slot of the OUTPUT slab -> JPEG quality 95 -> the task's output path.
+
+Only paths, shapes, seeds and a few floats are pickled.  Slots are fixed-size (an image that does
+not fit — a rotated copy of an unusually large original — falls back to a pickled array).
+"""
+from __future__ import annotations
+
+import random
+from concurrent.futures import Future, ProcessPoolExecutor
+from multiprocessing import get_context, shared_memory
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_SLABS: Dict[str, shared_memory.SharedMemory] = {}
+
+
+def _slabs(names: Dict[str, str]) -> Dict[str, shared_memory.SharedMemory]:
+    """Attach (once per worker) to the parent's slabs."""
+    for key, name in names.items():
+        cur = _SLABS.get(key)
+        if cur is None or cur.name != name:
+            _SLABS[key] = shared_memory.SharedMemory(name=name)
+    return _SLABS
+
+
+def _warm(_i: int) -> bool:
+    """First job of every worker: pay the imports while the parent is still copying the originals."""
+    from ..utils.image_utils import ImageLoader  # noqa: F401
+    from .image_augmenter import draw_params  # noqa: F401
+    import time
+    time.sleep(0.05)   # long enough that every worker of the pool takes one
+    return True
+
+
+def _decode_jobs(names: Dict[str, str], jobs: Sequence[Tuple[str, str, int, int, int, int]]):
+    """jobs: (source path, transform, seed, input offset, noise offset, slot bytes).  Returns per job
+    ("ok", shape, params) | ("big", array, params) | ("err", message)."""
+    from ..utils.image_utils import ImageLoader
+    from .image_augmenter import draw_params
+    out = []
+    slabs = _slabs(names)
+    buf_in, buf_noise = slabs["in"].buf, slabs["noise"].buf
+    for path, op, seed, off, noff, cap in jobs:
+        try:
+            arr = ImageLoader.load_as_array(path)
+            h, w, _c = arr.shape
+            params = None
+            if seed:   # seed 0 = "unseeded" in the reference: drawn by the parent from its global streams
+                params = draw_params(op, w, h, random.Random(seed), np.random.RandomState(seed))
+                if op == "distortion":
+                    n8 = params.pop("noise").astype(np.uint8)   # numpy's own cast, as the reference does next
+                    if n8.nbytes <= cap:
+                        np.frombuffer(buf_noise, np.uint8, n8.nbytes, noff)[:] = n8.reshape(-1)
+                        params["noise8"] = None      # in the noise slab, at this task's slot
+                    else:
+                        params["noise8"] = n8
+            if arr.nbytes <= cap:
+                np.frombuffer(buf_in, np.uint8, arr.nbytes, off)[:] = arr.reshape(-1)
+                out.append(("ok", arr.shape, params))
+            else:
+                out.append(("big", arr, params))
+        except Exception as e:  # noqa: BLE001 — the reference counts any failure
+            out.append(("err", f"{path} - {e}", None))
+    return out
+
+
+def _encode_jobs(names: Dict[str, str], jobs: Sequence[Tuple[str, int, Tuple[int, int, int], Any]]):
+    """jobs: (output path, output offset, shape, inline array or None).  Returns one bool per job."""
+    from ..utils.image_utils import ImageLoader
+    buf = _slabs(names)["out"].buf
+    done = []
+    for path, off, shape, inline in jobs:
+        try:
+            arr = inline if inline is not None else np.frombuffer(
+                buf, np.uint8, int(np.prod(shape)), off).reshape(shape)
+            ImageLoader.save_array(arr, path)
+            done.append(True)
+        except Exception:  # noqa: BLE001
+            done.append(False)
+    return done
+
+
+class CodecPool:
+    """`workers` codec processes (started, and warmed up, at construction) + three shared-memory
+    slabs of `slots` slots of `slot_bytes` each (`allocate`, once the image size is known)."""
+
+    def __init__(self, workers: int) -> None:
+        self.workers = int(workers)
+        self.slots = self.slot_bytes = 0
+        self.slabs: Dict[str, shared_memory.SharedMemory] = {}
+        self.names: Dict[str, str] = {}
+        # spawn, not fork: the parent has an initialised HIP runtime that a forked child must not inherit
+        self.pool = ProcessPoolExecutor(max_workers=self.workers, mp_context=get_context("spawn"))
+        self._warming = [self.pool.submit(_warm, i) for i in range(self.workers)]
+
+    def allocate(self, slots: int, slot_bytes: int) -> None:
+        self.slots, self.slot_bytes = int(slots), int(slot_bytes)
+        size = self.slots * self.slot_bytes
+        self.slabs = {k: shared_memory.SharedMemory(create=True, size=size) for k in ("in", "noise", "out")}
+        self.names = {k: s.name for k, s in self.slabs.items()}
+
+    def pin(self) -> bool:
+        """Page-lock the input and output slabs (hipHostRegister) so that a whole chunk crosses PCIe as
+        ONE asynchronous copy each way, straight from / into the memory the codec workers use.
+        Returns False when the runtime refuses (the pageable path still works, at a third of the rate)."""
+        import torch
+        rt = torch.cuda.cudart()
+        self._pinned = []
+        for key in ("in", "out"):
+            t = torch.frombuffer(self.slabs[key].buf, dtype=torch.uint8)
+            if int(rt.cudaHostRegister(t.data_ptr(), t.numel(), 0)) != 0:
+                return False
+            self._pinned.append(t)
+        return True
+
+    def unpin(self) -> None:
+        pinned = getattr(self, "_pinned", [])
+        if pinned:
+            import torch
+            rt = torch.cuda.cudart()
+            for t in pinned:
+                rt.cudaHostUnregister(t.data_ptr())
+        self._pinned = []
+
+    def tensor(self, slab: str, first_slot: int, n_slots: int):
+        """uint8 torch view [n_slots, slot_bytes] of a run of slots (shares the slab's memory)."""
+        import torch
+        t = torch.frombuffer(self.slabs[slab].buf, dtype=torch.uint8, count=n_slots * self.slot_bytes,
+                             offset=first_slot * self.slot_bytes)
+        return t.view(n_slots, self.slot_bytes)
+
+    def view(self, slab: str, slot: int, shape: Tuple[int, ...]) -> np.ndarray:
+        n = int(np.prod(shape))
+        return np.frombuffer(self.slabs[slab].buf, np.uint8, n, slot * self.slot_bytes).reshape(shape)
+
+    def _split(self, jobs: List[Any]) -> List[List[Any]]:
+        per = max(1, -(-len(jobs) // self.workers))
+        return [jobs[i:i + per] for i in range(0, len(jobs), per)]
+
+    def decode(self, tasks: Sequence[dict], first_slot: int) -> List[Future]:
+        jobs = [(t["source_img"], t["transform_name"], t["seed"], (first_slot + k) * self.slot_bytes,
+                 (first_slot + k) * self.slot_bytes, self.slot_bytes) for k, t in enumerate(tasks)]
+        return [self.pool.submit(_decode_jobs, self.names, part) for part in self._split(jobs)]
+
+    def encode(self, jobs: List[Tuple[str, int, Tuple[int, int, int], Optional[np.ndarray]]]) -> List[Future]:
+        return [self.pool.submit(_encode_jobs, self.names, part) for part in self._split(jobs)]
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=False, cancel_futures=True)   # every result has been collected
+        self.unpin()
+        import gc
+        gc.collect()   # numpy views of the slabs that are only kept alive by cycles
+        for s in self.slabs.values():
+            try:
+                s.unlink()          # the name goes now; the pages when the last mapping does
+            except FileNotFoundError:
+                pass
+            try:
+                s.close()
+            except BufferError:     # a caller still holds a view: its mapping outlives the pool, harmlessly
+                pass

@@ -10,8 +10,9 @@ so sources, names and per-task seeds are the reference's.
 What is different: execution.  The reference hands one PIL call per task to a process pool
 (:137-141).  Here the list is cut into one contiguous share per GPU (rank-0 builds it and
 broadcasts it) and every share runs as a three-stage pipeline over chunks —
-JPEG decode on host threads, one batched kernel launch per (transform, image size) group,
-JPEG encode on host threads — with the stages of neighbouring chunks overlapping.  There is no
+JPEG decode in worker processes, one batched kernel launch per (transform, image size) group,
+JPEG encode in worker processes (pixels cross through shared memory: codec_pool.py) — with the
+stages of neighbouring chunks overlapping.  There is no
 exchange step: ranks meet at a barrier, their success/failure counts are summed, and rank 0
 writes the manifest.  Pixels are bit-identical to the reference's for every seeded task.
 """
@@ -19,16 +20,16 @@ from __future__ import annotations
 
 import random
 import shutil
-from concurrent.futures import ThreadPoolExecutor
+import time
 from pathlib import Path
 from typing import Dict, List, Optional
 
 import numpy as np
 
+from .codec_pool import CodecPool
 from .dataset_components import AugmentationPlanner, DistributionAnalyzer, ManifestGenerator
 from .image_augmenter import ImageAugmenter, apply_batch, draw_params
 from ..utils.common import get_logger
-from ..utils.image_utils import ImageLoader
 from ..utils import ranks as _ranks
 from ..utils.ranks import contiguous_share
 from ..utils.system_info import get_optimal_worker_count
@@ -54,17 +55,20 @@ class DatasetBalancer:
         self.tasks: List[dict] = []
         self.completed = self.failed = 0
         self.ranks = _ranks.current()
+        self.timings: Dict[str, float] = {}   # seconds per stage of the last execute_balancing()
+        self._mirror = None                   # device mirrors of one chunk of the input / output slabs
+        self._codec: Optional[CodecPool] = None
 
     @staticmethod
     def _host_threads(requested) -> int:
         """`--workers` keeps the reference's meaning and bounds (default = half the optimal
-        count, capped at it; dataset_balancer.py:41-57); here they are decode/encode THREADS."""
+        count, capped at it; dataset_balancer.py:41-57); here they are the JPEG codec PROCESSES."""
         ceiling = get_optimal_worker_count()
         n = max(1, ceiling // 2) if requested is None else max(1, int(requested))
         if n > ceiling:
             logger.warning(f"Requested {n} workers, but only {ceiling} CPUs available; using {ceiling}")
             n = ceiling
-        logger.info(f"Using {n} host threads for JPEG decode/encode (max available: {ceiling})")
+        logger.info(f"Using {n} codec worker processes for JPEG decode/encode (max available: {ceiling})")
         return n
 
     # ------------------------------------------------------------------ planning (host)
@@ -121,33 +125,9 @@ class DatasetBalancer:
         return tasks
 
     # ------------------------------------------------------------------ one share, on one GPU
-    @staticmethod
-    def _decode(task):
-        try:
-            return ImageLoader.load_as_array(task["source_img"])
-        except Exception as e:  # noqa: BLE001 — the reference counts any failure
-            logger.error(f"Failed to process {task['source_img']} - {e}")
-            return None
-
-    @staticmethod
-    def _encode(item):
-        arr, path = item
-        try:
-            ImageLoader.save_array(arr, path)
-            return True
-        except Exception as e:  # noqa: BLE001
-            logger.error(f"Failed: {path} - {e}")
-            return False
-
-    @staticmethod
-    def _draw_seeded(job):
-        """One task's parameters from its own seeded generators (same values as seeding the
-        process-global streams with that seed, which is what the reference's worker does)."""
-        op, w, h, seed = job
-        return draw_params(op, w, h, random.Random(seed), np.random.RandomState(seed))
-
     def _run_group(self, op: str, images: List[np.ndarray], params: List[dict]) -> List[np.ndarray]:
-        """One (transform, size) group as one batched launch on this rank's GPU."""
+        """One (transform, size) group as one batched launch on this rank's GPU, host arrays in and
+        out (the path for pieces that do not go through the device mirror of the slabs)."""
         import torch
         x = torch.from_numpy(np.stack(images)).cuda()
         res = apply_batch(op, x, params)
@@ -156,63 +136,139 @@ class DatasetBalancer:
             return [host[j] for j in range(len(images))]
         return [o.cpu().numpy() for o in res]
 
-    def _gpu_stage(self, chunk: List[dict], images: List[Optional[np.ndarray]], pool) -> List[tuple]:
-        """Draw every task's parameters (a fresh seeded RNG per task, like the reference's
-        `_process_single_transformation`; seeded tasks are independent and drawn on the host
-        threads, seed 0 = "unseeded" continues this process's global streams), run the ops
-        batched by (transform, size), return (pixels, output_path) pairs for the encoder."""
+    def _gpu_stage(self, chunk: List[dict], decoded: List[tuple], pool: CodecPool, base: int) -> List[tuple]:
+        """`decoded[k]` is what the codec worker left for task k: pixels in slot base+k of the input
+        slab and the task's parameters (a fresh seeded RNG per task, like the reference's
+        `_process_single_transformation`; seed 0 = "unseeded": drawn here from this process's
+        global streams).  The chunk's run of the input slab goes to the device as ONE copy (the
+        slab is page-locked), the ops run batched by (transform, size) on rows gathered from that
+        mirror, results land in a device mirror of the output slab and come back as ONE copy.
+        Returns the encode jobs (path, offset, shape, inline array or None)."""
+        import torch
+        n = len(chunk)
+        device_path = self._mirror is not None
+        if device_path:
+            dev_in, dev_out = self._mirror
+            dev_in[:n].copy_(pool.tensor("in", base, n), non_blocking=True)
         groups: Dict[tuple, List[int]] = {}
-        params: List[Optional[dict]] = [None] * len(chunk)
-        drawing = {}
-        for k, (task, img) in enumerate(zip(chunk, images)):
-            if img is None:
+        images: List[Optional[np.ndarray]] = [None] * n
+        params: List[Optional[dict]] = [None] * n
+        for k, (task, (status, payload, prm)) in enumerate(zip(chunk, decoded)):
+            if status == "err":
+                logger.error(f"Failed to process {payload}")
                 self.failed += 1
                 continue
+            img = pool.view("in", base + k, payload) if status == "ok" else payload
             h, w, _ = img.shape
-            if task["seed"]:
-                drawing[k] = pool.submit(self._draw_seeded, (task["transform_name"], w, h, task["seed"]))
-            else:
-                params[k] = draw_params(task["transform_name"], w, h)
-            groups.setdefault((task["transform_name"], h, w), []).append(k)
-        for k, fut in drawing.items():
-            params[k] = fut.result()
-        out: List[tuple] = []
-        for (op, _h, _w), ks in groups.items():
+            if prm is None:
+                prm = draw_params(task["transform_name"], w, h)
+            elif "noise8" in prm and prm["noise8"] is None:
+                prm["noise8"] = pool.view("noise", base + k, img.shape)
+            images[k], params[k] = img, prm
+            groups.setdefault((task["transform_name"], h, w, status), []).append(k)
+        jobs: List[tuple] = []
+        for (op, h, w, status), ks in groups.items():
+            prm = [params[k] for k in ks]
             try:
-                res = self._run_group(op, [images[k] for k in ks], [params[k] for k in ks])
-                out.extend((r, chunk[k]["output_path"]) for r, k in zip(res, ks))
+                if device_path and status == "ok":
+                    idx = torch.tensor(ks, dtype=torch.int64, device=dev_in.device)
+                    x = dev_in[idx, :h * w * 3].view(len(ks), h, w, 3)
+                    res = apply_batch(op, x, prm)
+                    if op != "rotate":
+                        dev_out[idx, :h * w * 3] = torch.stack(res).view(len(ks), -1)
+                        jobs += [(chunk[k]["output_path"], (base + k) * pool.slot_bytes, (h, w, 3), None) for k in ks]
+                    else:
+                        for o, k in zip(res, ks):
+                            if o.numel() <= pool.slot_bytes:
+                                dev_out[k, :o.numel()] = o.reshape(-1)
+                                jobs.append((chunk[k]["output_path"], (base + k) * pool.slot_bytes, tuple(o.shape), None))
+                            else:
+                                jobs.append((chunk[k]["output_path"], 0, tuple(o.shape), o.cpu().numpy()))
+                    continue
+                res = self._run_group(op, [images[k] for k in ks], prm)
             except Exception as e:  # noqa: BLE001
                 logger.error(f"Failed batch {op}: {e}")
                 self.failed += len(ks)
-        return out
+                continue
+            for r, k in zip(res, ks):
+                if r.nbytes <= pool.slot_bytes:
+                    if device_path:   # joins the chunk's single copy back
+                        dev_out[k, :r.nbytes] = torch.from_numpy(np.ascontiguousarray(r)).reshape(-1).cuda()
+                    else:
+                        pool.view("out", base + k, r.shape)[...] = r
+                    jobs.append((chunk[k]["output_path"], (base + k) * pool.slot_bytes, tuple(r.shape), None))
+                else:
+                    jobs.append((chunk[k]["output_path"], 0, tuple(r.shape), r))
+        if device_path:
+            pool.tensor("out", base, n).copy_(dev_out[:n])   # synchronous: the encoders may start
+        return jobs
 
-    def _collect(self, futures) -> None:
-        for f in futures:
-            if f.result():
+    def _collect(self, futures, paths: List[str]) -> None:
+        flags = [ok for f in futures for ok in f.result()]
+        for ok, path in zip(flags, paths):
+            if ok:
                 self.completed += 1
             else:
                 self.failed += 1
+                logger.error(f"Failed: {path}")
 
     def _run_share(self, share: List[dict], total: int) -> None:
-        """decode | kernels | encode over CHUNK-sized pieces of this rank's share; chunk i+1 is
-        being decoded and chunk i-1 encoded while chunk i is on the GPU."""
-        chunks = [share[b:b + CHUNK] for b in range(0, len(share), CHUNK)]
-        if not chunks:
+        """decode | kernels | encode over chunks of this rank's share: chunk i+1 is being decoded and
+        chunk i-1 encoded (codec worker processes, pixels through shared memory) while chunk i is on
+        the GPU.  Slots are sized from the first source image (x2: a 30-degree rotation grows the
+        canvas 1.87x); anything larger travels as a pickled array."""
+        if not share:
+            if self._codec is not None:
+                self._codec.close()
+                self._codec = None
             return
-        with ThreadPoolExecutor(max_workers=self.workers) as pool:
-            decoding = [pool.submit(self._decode, t) for t in chunks[0]]
-            encoding: list = []
+        from PIL import Image
+        n_chunk = min(CHUNK, len(share))
+        chunks = [share[b:b + n_chunk] for b in range(0, len(share), n_chunk)]
+        with Image.open(share[0]["source_img"]) as probe:
+            w0, h0 = probe.size
+        slot = (2 * h0 * w0 * 3 + 4095) // 4096 * 4096
+        t0 = time.perf_counter()
+        pool = self._codec or CodecPool(self.workers)
+        pool.allocate(3 * n_chunk, slot)
+        self._mirror = None
+        try:
+            import torch
+            if type(self)._run_group is DatasetBalancer._run_group and torch.cuda.is_available() and pool.pin():
+                dev = torch.device("cuda", torch.cuda.current_device())
+                self._mirror = (torch.empty((n_chunk, slot), dtype=torch.uint8, device=dev),
+                                torch.empty((n_chunk, slot), dtype=torch.uint8, device=dev))
+            decoding = pool.decode(chunks[0], 0)
+            decoding[0].result()   # the workers are up (spawn + imports) once the first piece is back
+            self.timings["codec_pool_start"] = time.perf_counter() - t0
+            encoding, enc_paths = [], []
+            decoded = jobs = None
+            tw = {"wait_decode": 0.0, "gpu_stage": 0.0, "wait_encode": 0.0}
+            self.timings.update(tw)
+            self.timings["slabs_page_locked"] = float(self._mirror is not None)
             for i, chunk in enumerate(chunks):
-                images = [f.result() for f in decoding]
-                decoding = [pool.submit(self._decode, t) for t in chunks[i + 1]] if i + 1 < len(chunks) else []
-                results = self._gpu_stage(chunk, images, pool)
-                self._collect(encoding)
-                encoding = [pool.submit(self._encode, r) for r in results]
+                ta = time.perf_counter()
+                decoded = [r for f in decoding for r in f.result()]
+                decoding = pool.decode(chunks[i + 1], ((i + 1) % 3) * n_chunk) if i + 1 < len(chunks) else []
+                tb = time.perf_counter()
+                jobs = self._gpu_stage(chunk, decoded, pool, (i % 3) * n_chunk)
+                tc = time.perf_counter()
+                self._collect(encoding, enc_paths)
+                td = time.perf_counter()
+                self.timings["wait_decode"] += tb - ta
+                self.timings["gpu_stage"] += tc - tb
+                self.timings["wait_encode"] += td - tc
+                encoding, enc_paths = pool.encode(jobs), [j[0] for j in jobs]
                 done = self.completed + self.failed
-                if done and done % 500 < CHUNK:
+                if done and done % 500 < n_chunk:
                     logger.info(f"Progress (rank {self.ranks.rank}): {done}/{len(share)} of this share "
                                 f"({total} tasks in all) - {self.completed} success, {self.failed} failed")
-            self._collect(encoding)
+            self._collect(encoding, enc_paths)
+        finally:
+            decoded = jobs = None   # the last views of the slabs
+            self._mirror = None
+            self._codec = None
+            pool.close()
 
     # ------------------------------------------------------------------ the whole job
     def execute_balancing(self):
@@ -220,24 +276,32 @@ class DatasetBalancer:
             logger.info("No augmentation plan - skipping execution")
             return
         rk = self.ranks
+        t0 = time.perf_counter()
+        self._codec = CodecPool(self.workers)   # the workers start (and import) while the tree is copied
         if rk.rank == 0:
             self._fresh_target()
+            t1 = time.perf_counter()
             self.tasks = self.build_tasks(self._images_by_class())
+            self.timings = {"copy_originals": t1 - t0, "task_list": time.perf_counter() - t1}
         self.tasks = rk.broadcast_object(self.tasks if rk.rank == 0 else None)
         total = len(self.tasks)
         begin, end = contiguous_share(total, rk.rank, rk.world)
         logger.info(f"Starting GPU augmentation: {total} images to generate"
                     + (f" (rank {rk.rank}/{rk.world}: tasks {begin}..{end - 1})" if rk.active else ""))
         streams = (random.getstate(), np.random.get_state())
+        t2 = time.perf_counter()
         self._run_share(self.tasks[begin:end], total)
+        self.timings["decode_kernels_encode"] = time.perf_counter() - t2
         random.setstate(streams[0])
         np.random.set_state(streams[1])
         self.completed, self.failed = rk.sum_ints([self.completed, self.failed])
         rk.barrier()  # every share's files are on disk before the tree is listed
         logger.info(f"Augmentation complete: {self.completed} images generated, {self.failed} failed")
+        t3 = time.perf_counter()
         if rk.rank == 0:
             self._generate_augmented_manifest()
         rk.barrier()
+        self.timings["manifest"] = time.perf_counter() - t3
 
     def _generate_augmented_manifest(self):
         self.manifest_generator = ManifestGenerator(self.analyzer.original_manifest, self.source_dir,

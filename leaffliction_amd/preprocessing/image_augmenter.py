@@ -71,8 +71,11 @@ def apply_batch(op: str, x, params: Sequence[Dict[str, Any]]) -> List:
     if op == "crop":
         return list(ops.crop_resize_lanczos_u8(x, [p["box"] for p in params]))
     if op == "distortion":
-        noise = torch.from_numpy(np.stack([p["noise"] for p in params])).to(dev)
         cutoff = torch.tensor([p["cutoff"] for p in params], dtype=torch.float64, device=dev)
+        if "noise8" in params[0]:   # the codec workers cast the noise to uint8 (numpy's own astype)
+            n8 = torch.from_numpy(np.stack([p["noise8"] for p in params])).to(dev)
+            return list(ops.autocontrast_u8(ops.add_wrap_u8(x, n8), cutoff))
+        noise = torch.from_numpy(np.stack([p["noise"] for p in params])).to(dev)
         return list(ops.autocontrast_u8(ops.noise_wrap_add_u8(x, noise), cutoff))
     raise AttributeError(op)
 

@@ -51,6 +51,8 @@ class OracleBalancer(DatasetBalancer):
                 out.append(P.warp_bicubic(img, p["coeffs"], perspective=(op == "skew")))
             elif op == "crop":
                 out.append(P.crop_resize_lanczos(img, *p["box"]))
+            elif "noise8" in p:   # the codec workers cast the noise to uint8 (numpy's astype): bytewise add
+                out.append(P.autocontrast((img + p["noise8"]).astype(np.uint8), p["cutoff"]))
             else:
                 out.append(P.autocontrast(P.noise_wrap_add(img, p["noise"]), p["cutoff"]))
         return out
