@@ -330,3 +330,38 @@ def test_full_size_batch_properties(cuda):
     assert torch.equal(ops.lut_apply_u8(x, ident), x)
     m1 = torch.ones(256, dtype=torch.int32, device=cuda)
     assert torch.equal(ops.flip_u8(ops.flip_u8(x, m1), m1), x)
+
+
+def test_gathers_stay_inside_a_batch_that_ends_its_allocation(cuda):
+    """The bicubic warps fetch a footprint row with one unaligned 12-byte load and the nearest
+    rotate fetches a pixel with one unaligned 4-byte load (lf_geom.hip: `x + 3 < w`, `sp < last`
+    decide when the wide load is allowed).  A development build of round 1 without those guards read
+    up to 9 bytes past the last pixel of the last image and aborted the process when the batch
+    happened to end its allocation (gpurun_out/t10.log of round 1).  Here the
+    batch is the FINAL slice of an exactly-sized allocation whose size is a multiple of the 2 MiB
+    allocation granule, so such a read leaves the allocation; results must equal those of the same
+    batch in the middle of a larger buffer."""
+    import torch
+    from leaffliction_amd import ops
+    n, h, w = 4, 96, 128                                    # 147,456 bytes: a multiple of 16
+    nbytes = n * h * w * 3
+    big = torch.empty(2 << 20, dtype=torch.uint8, device=cuda)      # one whole 2 MiB granule
+    g = torch.Generator().manual_seed(4)
+    host = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, generator=g)
+    tail = big[-nbytes:].view(n, h, w, 3)
+    tail.copy_(host)
+    mid = torch.empty(nbytes + 8192, dtype=torch.uint8, device=cuda)[4096:4096 + nbytes].view(n, h, w, 3)
+    mid.copy_(host)
+    f = [0.05, 0.08, 0.12, 0.15]
+    skew = torch.tensor([[1 + v, 0, -v * w, 0, 1 + v, -v * h, 0, 0] for v in f], dtype=torch.float64, device=cuda)
+    shear = torch.tensor([[1, 0.2, 0, 0, 1, 0, 0, 0], [1, 0, 0, -0.2, 1, 0, 0, 0], [1, -0.15, 0, 0, 1, 0, 0, 0],
+                          [1, 0, 0, 0.1, 1, 0, 0, 0]], dtype=torch.float64, device=cuda)
+    angles = [-30.0, 29.5, 0.0, 13.0]
+    for a, b in ((ops.warp_bicubic_u8(tail, skew, True, True), ops.warp_bicubic_u8(mid, skew, True, True)),
+                 (ops.warp_bicubic_u8(tail, shear, False), ops.warp_bicubic_u8(mid, shear, False))):
+        assert torch.equal(a, b)
+    for a, b in zip(ops.rotate_expand_u8(tail, angles), ops.rotate_expand_u8(mid, angles)):
+        assert torch.equal(a, b)
+    boxes = [(3, 2, 110, 80), (0, 0, 102, 77), (18, 16, 110, 80), (5, 9, 120, 86)]
+    assert torch.equal(ops.crop_resize_lanczos_u8(tail, boxes), ops.crop_resize_lanczos_u8(mid, boxes))
+    torch.cuda.synchronize()
