@@ -4,8 +4,9 @@
 Same flags, presets and artifacts as srcs/cli/train.py:30-117,450-473.  One process per GPU:
 launch with `python -m torch.distributed.run --nproc-per-node N ...` for data-parallel
 training (global batch = --batch-size, sharded across ranks; RCCL all-reduce of the flat
-gradient bucket); a plain `python -m ...` run is single-GPU.  `--no-mixed-precision`
-(fp32) is the implemented precision; without it the run logs that fp32 is used.
+gradient bucket); a plain `python -m ...` run is single-GPU.  Like the reference, training is
+mixed-precision unless `--no-mixed-precision` is given: bf16 storage and MFMA operands, fp32
+accumulation / variables / statistics (fp32 throughout when the shape cannot take the bf16 path).
 Logs and returns 0 on FileNotFoundError/ValueError like the reference (train.py:471-473).
 """
 from __future__ import annotations
@@ -125,6 +126,14 @@ def build_and_compile_model(args, cfg: Dict, num_classes: int, train_seq: Any, d
                                 one_hot=train_seq.one_hot, workers=train_seq.workers)
         full.indexes = list(train_seq.indexes)
         adapt_normalization(norm_layer, full)
+    if not args.no_mixed_precision:
+        # the reference's default policy (train.py:179-190: mixed_float16 unless --no-mixed-precision):
+        # 16-bit storage and matrix operands, fp32 variables / statistics / loss — here in bf16
+        try:
+            model.set_training_dtype("bf16")
+            LOGGER.info("Mixed precision: bf16 storage and MFMA operands, fp32 accumulation and variables")
+        except ValueError as e:
+            LOGGER.info("Mixed precision not available for this shape (%s): training in fp32", e)
     dp.broadcast_(model.flat_p, 0)
     if dp.active:
         # same initial weights everywhere; independent dropout / in-model augmentation draws per shard
@@ -171,13 +180,12 @@ def main(argv=None) -> None:
         manifest_path = validate_manifest(args)
         train_items, val_items, label2idx = prepare_data(manifest_path)
         num_classes = len(label2idx)
-        if not args.no_mixed_precision:
-            LOGGER.info("mixed_float16 is not implemented on this backend: training in fp32")
         cfg = get_training_config(args.fast)
         train_seq, val_seq = create_data_sequences(train_items, val_items, label2idx, args, cfg,
                                                    num_classes, dp)
         model = build_and_compile_model(args, cfg, num_classes, train_seq, dp)
         meta = create_training_metadata(args, cfg, num_classes, train_items, val_items, dp)
+        meta["training"]["mixed_precision"] = model.train_dtype == "bf16"
         callbacks, ema_cb = build_callbacks(cfg)
         if getattr(args, "target_val_acc", None):
             callbacks.append(StopOnValAcc(args.target_val_acc))

@@ -114,8 +114,8 @@ class LeafCNN:
         self.train_dtype = os.environ.get("LEAFFLICTION_TRAIN_DTYPE", "f32")  # see set_training_dtype
         if self.train_dtype not in ("f32", "bf16"):
             raise ValueError("LEAFFLICTION_TRAIN_DTYPE must be f32 or bf16")
-        # data-parallel gradient bucket: "bf16" halves the bytes on xGMI (2.5 MB), "f32" keeps the sum exact
-        self.grad_bucket_dtype = os.environ.get("LEAFFLICTION_GRAD_BUCKET", "auto")
+        # (the data-parallel gradient bucket's dtype is train.parallel.DataParallel.bucket_dtype)
+        self.grad_bucket_dtype = os.environ.get("LEAFFLICTION_GRAD_BUCKET", "f32")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.norm = Normalization() if use_norm else None
         self.stop_training = False

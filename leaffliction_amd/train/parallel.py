@@ -20,6 +20,10 @@ class DataParallel:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
         self.active = self.world > 1
+        # "f32" (default): the flat gradient bucket crosses xGMI as it is (5.0 MB, exact sum);
+        # "bf16": rounded to bf16 for the all-reduce (2.5 MB) and widened again — BASELINE.md section 4
+        self.bucket_dtype = os.environ.get("LEAFFLICTION_GRAD_BUCKET", "f32")
+        self._bucket16: Optional[torch.Tensor] = None
         if self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -34,7 +38,16 @@ class DataParallel:
     def allreduce_grads(self, flat_g: torch.Tensor) -> torch.Tensor:
         """Sum the flat gradient bucket over ranks (local gradients are already scaled by
         1/global_batch, so the sum is the global-batch mean gradient)."""
-        if self.active:
+        if not self.active:
+            return flat_g
+        if self.bucket_dtype == "bf16" and flat_g.is_cuda:
+            from .. import nn
+            if self._bucket16 is None or self._bucket16.numel() != flat_g.numel():
+                self._bucket16 = torch.empty(flat_g.numel(), dtype=torch.bfloat16, device=flat_g.device)
+            nn.cast_f32_bf16(flat_g, self._bucket16)
+            self.dist.all_reduce(self._bucket16, op=self.dist.ReduceOp.SUM)
+            nn.cast_bf16_f32(self._bucket16, flat_g)
+        else:
             self.dist.all_reduce(flat_g, op=self.dist.ReduceOp.SUM)
         return flat_g
 
