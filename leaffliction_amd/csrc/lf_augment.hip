@@ -680,9 +680,7 @@ __global__ __launch_bounds__(kBlock) void hsv_stats_kernel(const uint8_t* __rest
 // horizontal pass -> Q8.8 uint16 rows in LDS, vertical pass -> (acc + 2^15) >> 16.
 constexpr int kBT = 32;
 constexpr int kMaxR = 15;
-struct BlurTaps {  // kernel argument: the Q8.8 taps live in scalar registers
-    uint16_t k[2 * kMaxR + 2];
-};
+using lf::BlurTaps;  // kernel argument: the Q8.8 taps live in scalar registers
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -1221,6 +1219,7 @@ int lf_gauss_blur_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int c
         fit_u8 = fit_u8 && kq[i] <= 255;
     }
     hipStream_t s = lf::as_stream(stream);
+    if (lf::blur_mfma_launch(in, out, n, h, w, channels, taps, ksize, s)) return lf::check_launch("lf_gauss_blur");
     if (fit_u8 && (channels == 3 ? launch_blur_fast<3>(in, out, n, h, w, taps, ksize, s)
                                  : launch_blur_fast<1>(in, out, n, h, w, taps, ksize, s)))
         return lf::check_launch("lf_gauss_blur");

@@ -52,6 +52,14 @@ constexpr unsigned kFullGrid = 1u << 30;
 inline bool streaming(size_t bytes_touched) { return bytes_touched >= ((size_t)256 << 20); }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Q8.8 Gaussian taps as a kernel argument (they live in scalar registers), and the i8-MFMA blur
+// (lf_blur_mfma.hip) that lf_gauss_blur_u8 tries first.
+struct BlurTaps {
+    uint16_t k[32];
+};
+bool blur_mfma_launch(const uint8_t* in, uint8_t* out, int n, int h, int w, int channels,
+                      const BlurTaps& taps, int ksize, hipStream_t s);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // lf_conv2d_bf16_train is served by two kernels: the streaming one (lf_conv_bf16s.hip: Cin, Cout <= 64,

@@ -129,9 +129,15 @@ def test_hsv_all_colours(cuda):
     assert np.array_equal(ops.rgb2hsv_u8(dev(grid, cuda)).cpu().numpy(), CV.rgb2hsv(grid))
 
 
-@pytest.mark.parametrize("h,w", [(224, 224), (64, 48), (33, 17)])
-@pytest.mark.parametrize("ksize,sigma", [(15, 0.0), (5, 1.5), (3, 0.0)])
+@pytest.mark.parametrize("h,w", [(224, 224), (64, 48), (33, 17), (256, 256), (32, 32), (64, 352), (96, 64)])
+@pytest.mark.parametrize("ksize,sigma", [(15, 0.0), (5, 1.5), (3, 0.0), (5, 0.0), (7, 0.0), (11, 2.0), (13, 0.0),
+                                         (9, 0.6)])
 def test_gauss_blur_bit_exact(cuda, h, w, ksize, sigma):
+    """cv2.GaussianBlur's fixed-point arithmetic, every pixel.  Heights and row lengths that are multiples of
+    32 with taps below 128 go to the i8-MFMA kernel (2 k-steps up to 3*R <= 16, else 3; one, several or a
+    prime number of 32-byte columns per row; a single 32-row block, where both reflections act on the same
+    block); everything else (ragged shapes, the 128 tap of the 3-tap kernel, the 0.6-sigma kernel's centre tap)
+    to the dot-product kernels."""
     from leaffliction_amd import ops
     x = batch_inputs(2, h, w, 6)
     got = ops.gauss_blur_u8(dev(x, cuda), ksize, sigma).cpu().numpy()
