@@ -273,6 +273,8 @@ def augment_throughput(dev, n=4096, iters=5, only=None):
         "rgb2hsv": (lambda: ops.rgb2hsv_u8(x), 2 * img_b),
         # the whole saliency filter of transform/filters/blur.py (image + leaf mask in, image out)
         "blur_saliency": (lambda: ops.blur_saliency_u8(x, mask), 2 * img_b + IMG * IMG),
+        # make_mask's default candidate mask (mask.py:727-831): image in, one byte plane out
+        "inclusive_mask": (lambda: ops.inclusive_mask_u8(x), img_b + IMG * IMG),
     }
     out, inv = {}, 0.0
     if only:

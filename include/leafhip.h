@@ -145,6 +145,20 @@ int lf_blur_saliency_u8(const uint8_t* rgb, const uint8_t* leaf_mask, uint8_t* o
                         const uint16_t* kq15, const uint16_t* kq5, void* workspace,
                         size_t ws_bytes, lf_stream_t stream);
 
+/* _create_inclusive_mask (srcs/transform/filters/mask.py:727-831), the default strategy of make_mask
+ * (mask.py:548-582, config.yaml:6 "inclusive"), on the working image: colour predicates in 8-bit HSV and
+ * L*a*b* (mask.py:735-770), gray / purple / untextured background removal (:772-789), Canny(30, 100)
+ * edges dilated 3x3 (:791-794), open 3x3 / close 9x9 / close 7x7 with cv2's MORPH_ELLIPSE elements
+ * (:806-815), largest 8-connected component (:817-824), close 5x5 (:826-829).
+ * rgb [N,H,W,3] -> mask [N,H,W] 0 / 255.  green_lo / green_hi: cfg.green_hue_range (config.yaml:10);
+ * kq15: HOST pointer to the 15 Q8.8 taps of GaussianBlur(gray, (15, 15), 0).
+ * The upscale before it (_prepare_working_image, mask.py:29-50) and GrabCut / brown extension after it
+ * (:307-392) are not part of this call.  Parity unpinned (no cv2); follows oracle/cv_ops.py:inclusive_mask. */
+size_t lf_inclusive_mask_workspace(int n, int h, int w);
+int lf_inclusive_mask_u8(const uint8_t* rgb, uint8_t* mask, int n, int h, int w, int green_lo,
+                         int green_hi, const uint16_t* kq15, void* workspace, size_t ws_bytes,
+                         lf_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* Geometric ops (Pillow semantics, bit-exact; coordinates in IEEE double)    */
 /* ------------------------------------------------------------------------- */

@@ -37,6 +37,8 @@ SIGNATURES = {
     "lf_rgb2gray_u8": [P, P, c_size_t, P],
     "lf_gauss_blur_u8": [P, P, c_int, c_int, c_int, c_int, P, c_int, P],
     "lf_hsv_region_stats": [P, P, P, c_int, c_int, c_int, P],
+    "lf_inclusive_mask_workspace": [c_int, c_int, c_int],
+    "lf_inclusive_mask_u8": [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P],
     "lf_blur_saliency_workspace": [c_int, c_int, c_int],
     "lf_blur_saliency_u8": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P,
                             c_size_t, P],
@@ -110,7 +112,7 @@ SIGNATURES = {
 _RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t,
              "lf_bn_workspace": c_size_t, "lf_se_bwd_workspace": c_size_t,
              "lf_adamw_workspace": c_size_t, "lf_conv2d_stats_tiles": C.c_longlong,
-             "lf_blur_saliency_workspace": c_size_t, "lf_conv2d_bf16_weight_elems": c_size_t,
+             "lf_blur_saliency_workspace": c_size_t, "lf_inclusive_mask_workspace": c_size_t, "lf_conv2d_bf16_weight_elems": c_size_t,
              "lf_conv2d_bf16_stats_tiles": C.c_longlong, "lf_conv2d_wgrad_bf16_workspace": c_size_t}
 
 

@@ -9,6 +9,10 @@
 // translation unit is compiled with -ffp-contract=off; the one fused multiply-add OpenCV itself
 // uses (convertTo inside cv2.normalize) is written as an explicit fmaf.
 #include <float.h>
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "lf_common.h"
 
@@ -359,6 +363,304 @@ __global__ __launch_bounds__(kBlock) void saliency_out_kernel(const uint8_t* __r
     }
 }
 
+// ===========================================================================
+// _create_inclusive_mask (srcs/transform/filters/mask.py:727-831): the default strategy of make_mask.
+// Per-pixel colour predicates (8-bit HSV and L*a*b*, uint8 channel comparisons that wrap as numpy's
+// do), Canny (L1 gradient, 30 / 100) dilated by the 3x3 ellipse, the texture test against a 15x15
+// Gaussian of the gray plane -> one BIT per pixel; then, one workgroup per image with the bit planes
+// in LDS: open 3x3, close 9x9, close 7x7 (cv2's MORPH_ELLIPSE elements), largest 8-connected
+// component (run-length union-find), close 5x5.
+// ===========================================================================
+__global__ __launch_bounds__(kBlock) void canny_sobel_l1_kernel(const uint8_t* __restrict__ gray,
+                                                                int32_t* __restrict__ mag,
+                                                                uint32_t* __restrict__ dxdy, int h, int w) {
+    const unsigned n = blockIdx.y;
+    const int hw = h * w;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= hw) return;
+    const int y = p / w, x = p - y * w;
+    const Sob s = sobel_at(gray + (size_t)n * hw, w, clampi(y - 1, 0, h - 1), y, clampi(y + 1, 0, h - 1),
+                           clampi(x - 1, 0, w - 1), x, clampi(x + 1, 0, w - 1));
+    mag[(size_t)n * hw + p] = (s.dx < 0 ? -s.dx : s.dx) + (s.dy < 0 ? -s.dy : s.dy);
+    dxdy[(size_t)n * hw + p] = ((unsigned)s.dx & 0xffffu) | ((unsigned)s.dy << 16);
+}
+
+constexpr int kLabCbrtSize = 256 * 3 / 2 * 8;   // LAB_CBRT_TAB_SIZE_B
+
+// One wave per 64-pixel segment of a row; bit i of the ballot is pixel x0 + i.
+// bits[n][y][2 * seg + {0, 1}]: `wpr` = 2 * ceil(w / 64) words per row.
+__global__ __launch_bounds__(kBlock) void inclusive_pred_kernel(
+    const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ blur,
+    const uint8_t* __restrict__ edges, const uint16_t* __restrict__ lab_tabs, uint32_t* __restrict__ bits,
+    int n_images, int h, int w, int hue_lo, int hue_hi) {
+    __shared__ int sdiv[256], hdiv[256];
+    __shared__ uint16_t gam[256], cbr[kLabCbrtSize];
+    for (int i = threadIdx.x; i < 256; i += kBlock) {
+        sdiv[i] = i ? __double2int_rn(__ddiv_rn(1044480.0, (double)i)) : 0;
+        hdiv[i] = i ? __double2int_rn(__ddiv_rn(737280.0, __dmul_rn(6.0, (double)i))) : 0;
+        gam[i] = lab_tabs[i];
+    }
+    for (int i = threadIdx.x; i < kLabCbrtSize; i += kBlock) cbr[i] = lab_tabs[256 + i];
+    __syncthreads();
+    const int spr = (w + 63) / 64, wpr = 2 * spr;
+    const long total = (long)n_images * h * spr;
+    const int lane = threadIdx.x & 63;
+    for (long seg = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); seg < total;
+         seg += (long)gridDim.x * (kBlock / 64)) {
+        const int sx = (int)(seg % spr);
+        const long ry = seg / spr;
+        const int y = (int)(ry % h);
+        const size_t n = (size_t)(ry / h);
+        const int x = sx * 64 + lane;
+        bool plant = false;
+        if (x < w) {
+            const size_t p = (n * h + y) * (size_t)w + x;
+            const int r = rgb[3 * p], g = rgb[3 * p + 1], b = rgb[3 * p + 2];
+            // 8-bit HSV (color_hsv: H in [0, 180))
+            const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
+            const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+            const int s = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
+            int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+            hh = (__mul24(hh, hdiv[diff]) + (1 << 11)) >> 12;
+            hh += hh < 0 ? 180 : 0;
+            // 8-bit L*a*b* (color_lab RGB2Lab_b)
+            const int R = gam[r], G = gam[g], B = gam[b];
+            const int fx = cbr[(R * 1777 + G * 1541 + B * 778 + 2048) >> 12];
+            const int fy = cbr[(R * 871 + G * 2929 + B * 296 + 2048) >> 12];
+            const int fz = cbr[(R * 73 + G * 448 + B * 3575 + 2048) >> 12];
+            const int L = clampi((296 * fy - 1336934 + 16384) >> 15, 0, 255);
+            const int la = clampi((500 * (fx - fy) + 4194304 + 16384) >> 15, 0, 255);
+            const int lb = clampi((200 * (fy - fz) + 4194304 + 16384) >> 15, 0, 255);
+            const bool strong_green = hh >= hue_lo && hh <= hue_hi && s >= 30 && v >= 30;
+            // uint8 planes: r + 15 wraps (mask.py:759-763)
+            const bool dominant = g > ((r + 15) & 255) || g > ((b + 15) & 255) ||
+                                  (g > ((r + 5) & 255) && g > ((b + 5) & 255) && s >= 20);
+            const bool lab_green = la <= 125 && lb >= 120 && L >= 20 && L <= 240;
+            const uint8_t* e = edges + (n * h) * (size_t)w;
+            const int q = y * w + x;
+            const bool edge = e[q] || (x > 0 && e[q - 1]) || (x < w - 1 && e[q + 1]) || (y > 0 && e[q - w]) ||
+                              (y < h - 1 && e[q + w]);
+            const int tex = (int)gray[p] - (int)blur[p];
+            const bool background = (s <= 25 && v >= 50 && v <= 220) ||
+                                    (hh >= 120 && hh <= 160 && s >= 20 && r > g && b > g) ||
+                                    (s <= 15 && (tex < 0 ? -tex : tex) < 10);
+            plant = (strong_green || dominant || lab_green || edge) && !background;
+        }
+        const unsigned long long m = __ballot(plant);
+        if (lane == 0) {
+            uint32_t* o = bits + ((n * h + y) * (size_t)wpr + 2 * sx);
+            o[0] = (unsigned)m;
+            o[1] = (unsigned)(m >> 32);
+        }
+    }
+}
+
+// ---- binary morphology on bit rows in LDS
+template <int K>
+struct EllipseRows;   // half-width of each row of cv2.getStructuringElement(MORPH_ELLIPSE, (K, K))
+template <>
+struct EllipseRows<3> {
+    static constexpr int dx[3] = {0, 1, 0};
+};
+template <>
+struct EllipseRows<5> {
+    static constexpr int dx[5] = {0, 2, 2, 2, 0};
+};
+template <>
+struct EllipseRows<7> {
+    static constexpr int dx[7] = {0, 2, 3, 3, 3, 2, 0};
+};
+template <>
+struct EllipseRows<9> {
+    static constexpr int dx[9] = {0, 3, 3, 4, 4, 4, 3, 3, 0};
+};
+
+// dst = dilate(src) or erode(src) by the K x K ellipse; pixels outside the image never win, i.e. an
+// erosion is the dilation of the complement taken INSIDE the image.  Bits past column w stay 0.
+template <int K, bool ERODE>
+__device__ void morph_bits(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int h, int w, int wpr) {
+    constexpr int R = K / 2;
+    const int used = (w + 31) / 32;
+    const unsigned lastmask = (w & 31) ? ((1u << (w & 31)) - 1u) : 0xffffffffu;
+    auto valid = [&](int xw) -> unsigned { return xw < used - 1 ? 0xffffffffu : (xw == used - 1 ? lastmask : 0u); };
+    auto word = [&](int y, int xw) -> unsigned {
+        if (xw < 0 || xw >= wpr) return 0u;
+        const unsigned v = src[y * wpr + xw];
+        return ERODE ? ~v & valid(xw) : v;
+    };
+    for (int i = threadIdx.x; i < h * wpr; i += blockDim.x) {
+        const int y = i / wpr, xw = i - y * wpr;
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int yy = y + k - R;
+            if (yy < 0 || yy >= h) continue;
+            const unsigned cur = word(yy, xw), prev = word(yy, xw - 1), next = word(yy, xw + 1);
+            out |= cur;
+#pragma unroll
+            for (int s = 1; s <= EllipseRows<K>::dx[k]; ++s)
+                out |= (cur << s) | (prev >> (32 - s)) | (cur >> s) | (next << (32 - s));
+        }
+        dst[i] = (ERODE ? ~out : out) & valid(xw);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int uf_load(int* p, int x) {
+    return __hip_atomic_load(p + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past the L1: atomics update L2 only
+}
+__device__ int uf_find(int* p, int x) {
+    for (;;) {
+        const int px = uf_load(p, x);
+        if (px == x) return x;
+        x = px;
+    }
+}
+__device__ void uf_union(int* p, int a, int b) {
+    for (;;) {
+        a = uf_find(p, a);
+        b = uf_find(p, b);
+        if (a == b) return;
+        if (a > b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(p + b, a);   // roots only ever move to a smaller index
+        if (old == b) return;
+        b = old;
+    }
+}
+
+// next run of ones in a bit row at or after column x: [start, end] inclusive; false when none
+__device__ bool next_run(const unsigned* row, int w, int x, int& start, int& end) {
+    while (x < w) {
+        const unsigned wd = row[x >> 5] >> (x & 31);
+        if (wd == 0u) {
+            x = (x | 31) + 1;
+            continue;
+        }
+        x += __builtin_ctz(wd);
+        break;
+    }
+    if (x >= w) return false;
+    start = x;
+    while (x < w) {
+        const unsigned wd = ~(row[x >> 5] >> (x & 31));   // zeros above the shifted-in part end the run too
+        const int room = 32 - (x & 31);
+        const int ones = wd == 0u ? 32 : __builtin_ctz(wd);
+        if (ones < room) {
+            x += ones;
+            break;
+        }
+        x += room;
+    }
+    end = (x > w ? w : x) - 1;
+    return true;
+}
+
+struct MaskRun {
+    unsigned short start, end;
+};
+
+__global__ __launch_bounds__(kBlock) void inclusive_morph_kernel(const uint32_t* __restrict__ bits,
+                                                                 uint8_t* __restrict__ out, MaskRun* __restrict__ runs,
+                                                                 int* __restrict__ parent, int* __restrict__ area,
+                                                                 int h, int w, int wpr, int runs_per_image) {
+    extern __shared__ unsigned lds_bits[];
+    unsigned* A = lds_bits;
+    unsigned* B = A + h * wpr;
+    int* rowstart = reinterpret_cast<int*>(B + h * wpr);   // [h + 1]
+    __shared__ unsigned long long best;
+    const size_t n = blockIdx.x;
+    for (int i = threadIdx.x; i < h * wpr; i += kBlock) A[i] = bits[n * h * wpr + i];
+    __syncthreads();
+    morph_bits<3, true>(A, B, h, w, wpr);    // MORPH_OPEN 3x3
+    morph_bits<3, false>(B, A, h, w, wpr);
+    morph_bits<9, false>(A, B, h, w, wpr);   // MORPH_CLOSE 9x9
+    morph_bits<9, true>(B, A, h, w, wpr);
+    morph_bits<7, false>(A, B, h, w, wpr);   // MORPH_CLOSE 7x7
+    morph_bits<7, true>(B, A, h, w, wpr);
+
+    // ---- largest 8-connected component of A -> B
+    MaskRun* rn = runs + n * runs_per_image;
+    int* par = parent + n * runs_per_image;
+    int* ar = area + n * runs_per_image;
+    for (int y = threadIdx.x; y < h; y += kBlock) {
+        int c = 0, x = 0, s, e;
+        while (next_run(A + y * wpr, w, x, s, e)) {
+            ++c;
+            x = e + 1;
+        }
+        rowstart[y + 1] = c;
+    }
+    if (threadIdx.x == 0) {
+        rowstart[0] = 0;
+        best = 0ull;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int y = 0; y < h; ++y) rowstart[y + 1] += rowstart[y];
+    __syncthreads();
+    const int nruns = rowstart[h];
+    for (int y = threadIdx.x; y < h; y += kBlock) {
+        int k = rowstart[y], x = 0, s, e;
+        while (next_run(A + y * wpr, w, x, s, e)) {
+            rn[k] = MaskRun{(unsigned short)s, (unsigned short)e};
+            par[k] = k;
+            ar[k] = 0;
+            ++k;
+            x = e + 1;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int y = 1 + threadIdx.x; y < h; y += kBlock) {   // runs of row y against runs of row y - 1
+        int a = rowstart[y - 1], b = rowstart[y];
+        const int a_end = rowstart[y], b_end = rowstart[y + 1];
+        while (a < a_end && b < b_end) {
+            const MaskRun ra = rn[a], rb = rn[b];
+            if ((int)ra.start <= (int)rb.end + 1 && (int)ra.end >= (int)rb.start - 1) uf_union(par, a, b);
+            if (ra.end < rb.end) ++a;
+            else ++b;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int k = threadIdx.x; k < nruns; k += kBlock) {
+        const int root = uf_find(par, k);
+        atomicAdd(ar + root, (int)rn[k].end - (int)rn[k].start + 1);
+    }
+    __threadfence();
+    __syncthreads();
+    for (int k = threadIdx.x; k < nruns; k += kBlock) {   // largest area; the earliest component among equals
+        const int a = __hip_atomic_load(ar + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a > 0) atomicMax(&best, ((unsigned long long)a << 32) | (unsigned)(0x7fffffff - k));
+    }
+    for (int i = threadIdx.x; i < h * wpr; i += kBlock) B[i] = 0u;
+    __syncthreads();
+    if (nruns > 0) {
+        const int keep = 0x7fffffff - (int)(best & 0xffffffffull);
+        for (int y = threadIdx.x; y < h; y += kBlock)
+            for (int k = rowstart[y]; k < rowstart[y + 1]; ++k) {
+                if (uf_find(par, k) != keep) continue;
+                for (int x = rn[k].start; x <= (int)rn[k].end;) {   // this thread owns the row's words
+                    const int bit = x & 31, len = min(32 - bit, (int)rn[k].end - x + 1);
+                    B[y * wpr + (x >> 5)] |= (len == 32 ? 0xffffffffu : ((1u << len) - 1u)) << bit;
+                    x += len;
+                }
+            }
+    }
+    __syncthreads();
+    morph_bits<5, false>(B, A, h, w, wpr);   // MORPH_CLOSE 5x5
+    morph_bits<5, true>(A, B, h, w, wpr);
+    uint8_t* o = out + n * (size_t)h * w;
+    for (int p = threadIdx.x; p < h * w; p += kBlock) {
+        const int y = p / w, x = p - y * w;
+        o[p] = (B[y * wpr + (x >> 5)] >> (x & 31)) & 1u ? 255 : 0;
+    }
+}
+
 constexpr size_t kAlign = 256;
 inline size_t up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
@@ -457,6 +759,114 @@ int lf_blur_saliency_u8(const uint8_t* rgb, const uint8_t* leaf_mask, uint8_t* o
     saliency_out_kernel<<<lf::stream_grid(px / 4 + 1, kBlock, lf::kFullGrid), kBlock, 0, s>>>(pb, leaf_mask, out,
                                                                                            px);
     return lf::check_launch("lf_blur_saliency");
+}
+
+static void lab_tables_host(uint16_t* out) {   // color_lab.cpp initLabTabs: sRGBGammaTab_b, LabCbrtTab_b
+    for (int i = 0; i < 256; ++i) {
+        const float x = (float)i / 255.0f;
+        const double xd = (double)x;
+        const float lin = (float)(xd <= 0.04045 ? xd / 12.92 : pow((xd + 0.055) / 1.055, 2.4));
+        const long v = lrint((double)(2040.0f * lin));
+        out[i] = (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+    }
+    const float scale = 1.0f / (255.0f * 8.0f);
+    const float lthresh = 216.0f / 24389.0f, lscale = 841.0f / 108.0f, lbias = 16.0f / 116.0f;
+    for (int i = 0; i < kLabCbrtSize; ++i) {
+        const float y = scale * (float)i;
+        float f;
+        if (y < lthresh) {
+            const float prod = y * lscale;   // two roundings, as numpy's float32 arithmetic in the oracle
+            f = prod + lbias;
+        } else {
+            f = (float)cbrt((double)y);
+        }
+        const long v = lrint((double)(32768.0f * f));
+        out[256 + i] = (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+    }
+}
+
+static size_t mask_runs_per_image(int h, int w) { return (size_t)h * (w / 2 + 1); }
+
+size_t lf_inclusive_mask_workspace(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    const size_t px = (size_t)n * h * w;
+    const size_t wpr = 2 * (size_t)((w + 63) / 64);
+    const size_t runs = (size_t)n * mask_runs_per_image(h, w);
+    // gray, blurred gray, Canny map; |dx| + |dy| and (dx, dy); the bit planes; runs, parents, areas; the two tables
+    return 3 * up(px) + 2 * up(4 * px) + up((size_t)n * h * wpr * 4) + up(runs * sizeof(MaskRun)) + 2 * up(runs * 4) +
+           up((256 + kLabCbrtSize) * sizeof(uint16_t));
+}
+
+int lf_inclusive_mask_u8(const uint8_t* rgb, uint8_t* mask, int n, int h, int w, int green_lo, int green_hi,
+                         const uint16_t* kq15, void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(rgb && mask && kq15 && workspace, "lf_inclusive_mask: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_inclusive_mask: bad dims n=%d h=%d w=%d", n, h, w);
+    LF_REQUIRE(n <= 65535, "lf_inclusive_mask: batch too large for grid.y");
+    LF_REQUIRE(w <= 65535 && h <= 65535, "lf_inclusive_mask: image too large (%d x %d)", h, w);
+    LF_REQUIRE(ws_bytes >= lf_inclusive_mask_workspace(n, h, w), "lf_inclusive_mask: workspace too small (%zu < %zu)",
+               ws_bytes, lf_inclusive_mask_workspace(n, h, w));
+    LF_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "lf_inclusive_mask: workspace must be 16-byte aligned");
+    const int wpr = 2 * ((w + 63) / 64);
+    const size_t lds = (size_t)2 * h * wpr * 4 + (size_t)(h + 1) * 4;
+    static const size_t lds_cap = []() {
+        const size_t want = 150 * 1024;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(inclusive_morph_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess
+                   ? want
+                   : (size_t)60 * 1024;
+    }();
+    LF_REQUIRE(lds <= lds_cap, "lf_inclusive_mask: a %d x %d image needs %zu bytes of LDS for its bit planes (limit %zu)",
+               h, w, lds, lds_cap);
+    hipStream_t s = lf::as_stream(stream);
+    const int hw = h * w;
+    const size_t px = (size_t)n * hw;
+    const size_t runs = (size_t)n * mask_runs_per_image(h, w);
+    uint8_t* base = static_cast<uint8_t*>(workspace);
+    uint8_t* gray = base;
+    uint8_t* blur = gray + up(px);
+    uint8_t* map = blur + up(px);
+    int32_t* mag = reinterpret_cast<int32_t*>(map + up(px));
+    uint32_t* dxdy = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(mag) + up(4 * px));
+    uint32_t* bits = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(dxdy) + up(4 * px));
+    MaskRun* rn = reinterpret_cast<MaskRun*>(reinterpret_cast<uint8_t*>(bits) + up((size_t)n * h * wpr * 4));
+    int* parent = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(rn) + up(runs * sizeof(MaskRun)));
+    int* area = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(parent) + up(runs * 4));
+    uint16_t* tabs = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(area) + up(runs * 4));
+
+    static const std::vector<uint16_t> host_tabs = []() {
+        std::vector<uint16_t> t(256 + kLabCbrtSize);
+        lab_tables_host(t.data());
+        return t;
+    }();
+    if (hipMemcpyAsync(tabs, host_tabs.data(), host_tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s) != hipSuccess) {
+        lf::set_error("lf_inclusive_mask: table upload failed");
+        return LF_ERR_LAUNCH;
+    }
+    int rc = lf_rgb2gray_u8(rgb, gray, px, stream);
+    if (rc != LF_OK) return rc;
+    rc = lf_gauss_blur_u8(gray, blur, n, h, w, 1, kq15, 15, stream);
+    if (rc != LF_OK) return rc;
+    const dim3 grid_px((hw + kBlock - 1) / kBlock, n);
+    canny_sobel_l1_kernel<<<grid_px, kBlock, 0, s>>>(gray, mag, dxdy, h, w);
+    canny_nms_kernel<<<grid_px, kBlock, 0, s>>>(mag, dxdy, map, h, w, 30, 100);   // cv2.Canny(gray, 30, 100)
+    {
+        static const size_t hyst_cap = []() {
+            const size_t want = 156 * 1024;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(canny_hysteresis_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess
+                       ? want
+                       : (size_t)60 * 1024;
+        }();
+        const int in_lds = (size_t)hw <= hyst_cap;
+        canny_hysteresis_kernel<<<n, kHystThreads, in_lds ? (size_t)((hw + 15) & ~15) : 0, s>>>(map, h, w, in_lds);
+    }
+    const long segs = (long)n * h * ((w + 63) / 64);
+    const unsigned pgrid = (unsigned)std::min<long>((segs + 3) / 4, 2048);
+    inclusive_pred_kernel<<<pgrid, kBlock, 0, s>>>(rgb, gray, blur, map, tabs, bits, n, h, w,
+                                                   std::max(0, green_lo - 10), std::min(179, green_hi + 15));
+    inclusive_morph_kernel<<<n, kBlock, lds, s>>>(bits, mask, rn, parent, area, h, w, wpr,
+                                                  (int)mask_runs_per_image(h, w));
+    return lf::check_launch("lf_inclusive_mask");
 }
 
 }  // extern "C"

@@ -256,6 +256,19 @@ def blur_saliency_u8(x: torch.Tensor, leaf_mask: torch.Tensor, gaussian_sigma: f
     return out
 
 
+def inclusive_mask_u8(x: torch.Tensor, green_hue_range=(25, 100)) -> torch.Tensor:
+    """_create_inclusive_mask (srcs/transform/filters/mask.py:727-831) for a batch [N,H,W,3] uint8 of working
+    images: the leaf mask [N,H,W] uint8 (0 / 255).  green_hue_range: srcs/transform/config.yaml:10."""
+    n, h, w = _hwc(x, "inclusive_mask.x")
+    kq15 = np.ascontiguousarray(gaussian_kernel_q8(15, 0.0).astype(np.uint16))  # host constants
+    nbytes = int(_lib.load().lf_inclusive_mask_workspace(n, h, w))
+    ws = torch.empty(nbytes, dtype=_U8, device=x.device)
+    out = torch.empty((n, h, w), dtype=_U8, device=x.device)
+    _lib.call("lf_inclusive_mask_u8", x.data_ptr(), out.data_ptr(), n, h, w, int(green_hue_range[0]),
+              int(green_hue_range[1]), kq15.ctypes.data, ws.data_ptr(), nbytes, _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------
 # geometric ops (Pillow semantics)
 # ---------------------------------------------------------------------------

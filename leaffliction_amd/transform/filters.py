@@ -1,9 +1,12 @@
 """Host mirror of the per-pixel filters of srcs/transform/filters (blur.py, hist.py): same call
 shapes (numpy RGB in, numpy out), the arithmetic runs in libleafhip on the GPU.
 
-The segmentation that produces the leaf mask (`make_mask`, mask.py:548-582) stays with the caller,
-exactly as blur.py receives it through `make_mask_func`; matplotlib rendering of the histogram
-report (hist.py:191-297) is presentation and is not reproduced — the numbers it draws are."""
+Of the segmentation that produces the leaf mask (`make_mask`, mask.py:548-582) the first slice is here:
+`create_inclusive_mask`, the default strategy's candidate mask (mask.py:727-831) on the working image.
+The cubic upscale before it (mask.py:29-50) and the GrabCut / brown-extension refinements after it
+(:307-392) are not, so `apply_blur_filter` still receives its mask through `make_mask_func` exactly as
+blur.py does.  matplotlib rendering of the histogram report (hist.py:191-297) is presentation and is not
+reproduced — the numbers it draws are."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -28,6 +31,7 @@ class TransformConfig:
     brown_hue_range: Tuple[int, int] = (0, 30)
     brown_s_min: int = 20
     brown_v_max: int = 200
+    green_hue_range: Tuple[int, int] = (25, 100)      # config.yaml:10
 
 
 def _device() -> torch.device:
@@ -41,6 +45,14 @@ def _rgb_batch(rgb: np.ndarray) -> torch.Tensor:
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
         raise ValueError(f"expected an HxWx3 uint8 RGB image, got {a.dtype} {a.shape}")
     return torch.from_numpy(a).unsqueeze(0).to(_device())
+
+
+def create_inclusive_mask(rgb_work: np.ndarray, cfg) -> np.ndarray:
+    """srcs/transform/filters/mask.py:727-831 (`_create_inclusive_mask`): HxW uint8 leaf mask (0 / 255) of the
+    working image — colour predicates, background removal, dilated Canny edges, open / close / close,
+    largest connected component, final close."""
+    out = ops.inclusive_mask_u8(_rgb_batch(rgb_work), tuple(cfg.green_hue_range))
+    return out[0].cpu().numpy()
 
 
 def apply_blur_filter(rgb: np.ndarray, cfg, make_mask_func: Callable) -> np.ndarray:

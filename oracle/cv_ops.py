@@ -186,16 +186,21 @@ def sobel3(gray: np.ndarray, border: str):
     return dx, dy
 
 
-def canny(gray: np.ndarray, low: float, high: float) -> np.ndarray:
-    """cv2.Canny(gray, low, high, L2gradient=True), aperture 3 (blur.py:30): squared thresholds
-    on dx^2 + dy^2, 22.5/67.5-degree sector tests in 15-bit fixed point (TG22 = 13573),
-    asymmetric > / >= neighbour tests, 8-connected hysteresis."""
+def canny(gray: np.ndarray, low: float, high: float, l2gradient: bool = True) -> np.ndarray:
+    """cv2.Canny(gray, low, high, L2gradient=...), aperture 3.  L2gradient=True (blur.py:30): squared
+    thresholds on dx^2 + dy^2; False, cv2's default (mask.py:792): floor(threshold) on |dx| + |dy|.
+    22.5/67.5-degree sector tests in 15-bit fixed point (TG22 = 13573), asymmetric > / >= neighbour
+    tests, 8-connected hysteresis."""
     h, w = gray.shape
-    lo = int(np.floor(min(32767.0, low) ** 2)) if low > 0 else int(np.floor(low))
-    hi = int(np.floor(min(32767.0, high) ** 2)) if high > 0 else int(np.floor(high))
     dx, dy = sobel3(gray, "replicate")
     mag = np.zeros((h + 2, w + 2), dtype=np.int64)
-    mag[1:-1, 1:-1] = dx * dx + dy * dy
+    if l2gradient:
+        lo = int(np.floor(min(32767.0, low) ** 2)) if low > 0 else int(np.floor(low))
+        hi = int(np.floor(min(32767.0, high) ** 2)) if high > 0 else int(np.floor(high))
+        mag[1:-1, 1:-1] = dx * dx + dy * dy
+    else:
+        lo, hi = int(np.floor(low)), int(np.floor(high))
+        mag[1:-1, 1:-1] = np.abs(dx) + np.abs(dy)
     m = mag[1:-1, 1:-1]
     x = np.abs(dx)
     y = np.abs(dy) << 15
@@ -285,3 +290,155 @@ def blur_saliency(rgb: np.ndarray, mask: np.ndarray, gaussian_sigma: float = 1.5
     out = np.zeros_like(gray)
     out[leaf] = sal_blur[leaf]
     return np.repeat(out[..., None], 3, axis=2)
+
+
+# ---------------------------------------------------------------------------
+# _create_inclusive_mask (srcs/transform/filters/mask.py:727-831), the default strategy of make_mask.
+# PARITY UNPINNED like the rest of this file (no cv2 here).  Restated: imgproc color_lab.cpp
+# RGB2Lab_b (8-bit sRGB -> L*a*b*: gamma table at 3 fractional bits, 12-bit matrix, cube-root table
+# at 15 bits), morph.dispatch (erode / dilate, border pixels never win), getStructuringElement's
+# MORPH_ELLIPSE rows, connectedcomponents.cpp (8-connectivity, areas).  The two tables are built with
+# double-precision pow / cbrt rounded to float32 where OpenCV uses its softfloat routines: a table
+# entry that sits within one float32 ulp of a rounding boundary may differ by 1.
+# ---------------------------------------------------------------------------
+LAB_SHIFT, GAMMA_SHIFT = 12, 3
+LAB_SHIFT2 = LAB_SHIFT + GAMMA_SHIFT
+LAB_COEFFS = (1777, 1541, 778, 871, 2929, 296, 73, 448, 3575)   # round(4096 * sRGB->XYZ(D65) / white point)
+
+
+def lab_tables():
+    """(sRGBGammaTab_b [256], LabCbrtTab_b [3072]) of color_lab.cpp initLabTabs, uint16."""
+    f32 = np.float32
+    i = np.arange(256, dtype=np.float64)
+    x = (i.astype(f32) / f32(255.0)).astype(np.float64)
+    lin = np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4).astype(f32)
+    gamma = np.rint((f32(255 * (1 << GAMMA_SHIFT)) * lin).astype(np.float64)).astype(np.int64)
+    j = np.arange(256 * 3 // 2 * (1 << GAMMA_SHIFT), dtype=np.float64)
+    scale = f32(1.0) / (f32(255.0) * f32(1 << GAMMA_SHIFT))
+    y = (scale * j.astype(f32)).astype(f32)
+    lthresh, lscale, lbias = f32(216.0) / f32(24389.0), f32(841.0) / f32(108.0), f32(16.0) / f32(116.0)
+    lowf = (y * lscale + lbias).astype(f32)     # mulAdd: float32 here (a fused form differs below 1e-7)
+    fy = np.where(y < lthresh, lowf, np.cbrt(y.astype(np.float64)).astype(f32))
+    cbrt = np.rint((f32(1 << LAB_SHIFT2) * fy).astype(np.float64)).astype(np.int64)
+    return np.clip(gamma, 0, 65535).astype(np.uint16), np.clip(cbrt, 0, 65535).astype(np.uint16)
+
+
+_LAB_GAMMA, _LAB_CBRT = lab_tables()
+
+
+def rgb2lab(rgb: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(rgb, cv2.COLOR_RGB2LAB) for uint8 (mask.py:736): L in [0,255] (L* x 2.55), a and b + 128."""
+    g = _LAB_GAMMA.astype(np.int64)
+    r_, g_, b_ = g[rgb[..., 0]], g[rgb[..., 1]], g[rgb[..., 2]]
+    c = LAB_COEFFS
+    half = 1 << (LAB_SHIFT - 1)
+
+    def f(c0, c1, c2):
+        return _LAB_CBRT.astype(np.int64)[(r_ * c0 + g_ * c1 + b_ * c2 + half) >> LAB_SHIFT]
+
+    fx, fy, fz = f(c[0], c[1], c[2]), f(c[3], c[4], c[5]), f(c[6], c[7], c[8])
+    lscale = (116 * 255 + 50) // 100
+    lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) // 100)
+    half2 = 1 << (LAB_SHIFT2 - 1)
+    L = (lscale * fy + lshift + half2) >> LAB_SHIFT2
+    a = (500 * (fx - fy) + 128 * (1 << LAB_SHIFT2) + half2) >> LAB_SHIFT2
+    b = (200 * (fy - fz) + 128 * (1 << LAB_SHIFT2) + half2) >> LAB_SHIFT2
+    return np.clip(np.stack([L, a, b], -1), 0, 255).astype(np.uint8)
+
+
+def ellipse_se(k: int) -> np.ndarray:
+    """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)) as a bool [k, k] array."""
+    r = c = k // 2
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    se = np.zeros((k, k), dtype=bool)
+    for i in range(k):
+        dy = i - r
+        if abs(dy) <= r:
+            dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))   # saturate_cast<int>: round half to even
+            se[i, max(c - dx, 0):min(c + dx + 1, k)] = True
+    return se
+
+
+def morph(img: np.ndarray, se: np.ndarray, erode: bool) -> np.ndarray:
+    """cv2.erode / cv2.dilate of a uint8 plane with a centred element, default border (outside never wins)."""
+    h, w = img.shape
+    kh, kw = se.shape
+    ry, rx = kh // 2, kw // 2
+    pad = np.full((h + 2 * ry, w + 2 * rx), 255 if erode else 0, dtype=np.uint8)
+    pad[ry:ry + h, rx:rx + w] = img
+    out = np.full((h, w), 255 if erode else 0, dtype=np.uint8)
+    for i in range(kh):
+        for j in range(kw):
+            if se[i, j]:
+                t = pad[i:i + h, j:j + w]
+                out = np.minimum(out, t) if erode else np.maximum(out, t)
+    return out
+
+
+def morph_open(img: np.ndarray, k: int) -> np.ndarray:
+    se = ellipse_se(k)
+    return morph(morph(img, se, True), se, False)
+
+
+def morph_close(img: np.ndarray, k: int) -> np.ndarray:
+    se = ellipse_se(k)
+    return morph(morph(img, se, False), se, True)
+
+
+def largest_component(mask: np.ndarray) -> np.ndarray:
+    """mask.py:817-824: keep the 8-connected component of the largest area (cv2.connectedComponentsWithStats;
+    np.argmax takes the first of equal areas, and labels follow the raster order of each component's first
+    pixel).  A plane with no foreground comes back unchanged."""
+    h, w = mask.shape
+    fg = mask > 0
+    label = np.zeros((h, w), dtype=np.int64)
+    areas = []
+    for y0, x0 in zip(*np.nonzero(fg)):
+        if label[y0, x0]:
+            continue
+        lab = len(areas) + 1
+        stack, area = [(y0, x0)], 0
+        label[y0, x0] = lab
+        while stack:
+            y, x = stack.pop()
+            area += 1
+            for yy in range(max(y - 1, 0), min(y + 2, h)):
+                for xx in range(max(x - 1, 0), min(x + 2, w)):
+                    if fg[yy, xx] and not label[yy, xx]:
+                        label[yy, xx] = lab
+                        stack.append((yy, xx))
+        areas.append(area)
+    if not areas:
+        return mask.copy()
+    best = 1 + int(np.argmax(areas))
+    return ((label == best) * 255).astype(np.uint8)
+
+
+def inclusive_mask(rgb: np.ndarray, green_hue_range=(25, 100)) -> np.ndarray:
+    """_create_inclusive_mask (mask.py:727-831) on the working image: 0 / 255 plane
+    (green_hue_range: srcs/transform/config.yaml:10)."""
+    hsv, lab = rgb2hsv(rgb), rgb2lab(rgb)
+    hh, ss, vv = (hsv[..., i].astype(np.int64) for i in range(3))
+    ll, aa, bb = (lab[..., i].astype(np.int64) for i in range(3))
+    # the reference compares uint8 planes: g > r + 15 is evaluated in uint8 and WRAPS (mask.py:759-763)
+    r8, g8, b8 = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    lo, hi = green_hue_range
+    lo, hi = max(0, lo - 10), min(179, hi + 15)
+    strong_green = (hh >= lo) & (hh <= hi) & (ss >= 30) & (vv >= 30)
+    u8 = np.uint8
+    green_dominant = ((g8 > (r8 + u8(15))) | (g8 > (b8 + u8(15))) |
+                      ((g8 > (r8 + u8(5))) & (g8 > (b8 + u8(5))) & (ss >= 20)))
+    lab_green = (aa <= 125) & (bb >= 120) & (ll >= 20) & (ll <= 240)
+    gray = rgb2gray(rgb)
+    blur_gray = gaussian_blur(gray, 15, 0.0)
+    texture = np.abs(gray.astype(np.int64) - blur_gray.astype(np.int64))
+    background = (((ss <= 25) & (vv >= 50) & (vv <= 220)) |
+                  ((hh >= 120) & (hh <= 160) & (ss >= 20) & (r8 > g8) & (b8 > g8)) |
+                  ((ss <= 15) & (texture < 10)))
+    edges = morph(canny(gray, 30, 100, l2gradient=False), ellipse_se(3), erode=False)
+    plant = ((strong_green | green_dominant | lab_green | (edges > 0)) & ~background).astype(np.uint8) * 255
+    plant = morph_open(plant, 3)
+    plant = morph_close(plant, 9)
+    plant = morph_close(plant, 7)
+    plant = largest_component(plant)
+    return morph_close(plant, 5)

@@ -1,5 +1,5 @@
 """One augmentation op on a resident batch, a few launches: the target of rocprofv3 runs
-(python scripts/prof_one_op.py blur15|blur5|hist|skew|shear|rotate [n_images])."""
+(python scripts/prof_one_op.py blur15|blur5|hist|<row of bench.py's augmentation table> [n_images])."""
 import os
 import sys
 
@@ -22,5 +22,8 @@ if __name__ == "__main__":
         elif what == "hist":
             ops.hist_u8(x)
         else:
-            raise SystemExit(f"unknown op {what}")
+            break
     torch.cuda.synchronize()
+    if what not in ("blur15", "blur5", "hist"):   # any row of bench.py's augmentation table
+        import bench
+        print(bench.augment_throughput(dev, n=n, iters=3, only=[what]))

@@ -203,3 +203,86 @@ def test_blur_saliency_flat_image_and_mask():
     out = CV.blur_saliency(img, mask)
     assert out.shape == (20, 24, 3) and int(out[:, :12].sum()) == 0 and int(out[:, 12:].sum()) > 0
     assert np.array_equal(out[..., 0], out[..., 1]) and np.array_equal(out[..., 0], out[..., 2])
+
+
+# ---- _create_inclusive_mask (mask.py:727-831): L*a*b*, ellipse elements, morphology, components -------------
+def test_lab_primaries_and_greys():
+    """cv2.cvtColor(.., COLOR_RGB2LAB) on 8-bit input: the values OpenCV's documentation and every cv2 session
+    give for the sRGB primaries, white, black and mid grey."""
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128]]], np.uint8)
+    assert CV.rgb2lab(px)[0].tolist() == [[136, 208, 195], [224, 42, 211], [82, 207, 20], [255, 128, 128],
+                                          [0, 128, 128], [137, 128, 128]]
+    g = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    lab = CV.rgb2lab(g)[0]
+    assert (lab[:, 1] == 128).all() and (lab[:, 2] == 128).all()          # greys have no chroma
+    assert (np.diff(lab[:, 0].astype(int)) >= 0).all() and lab[0, 0] == 0 and lab[255, 0] == 255
+    gam, cbrt = CV.lab_tables()
+    assert gam[0] == 0 and gam[255] == 2040 and cbrt[2040] == 32768       # f(1) = 1 at 15 bits
+    assert (np.diff(gam.astype(int)) >= 0).all() and (np.diff(cbrt.astype(int)) > 0).all()
+
+
+def test_ellipse_elements():
+    """cv2.getStructuringElement(MORPH_ELLIPSE, (k, k)): 3 is the plus, 5 loses its four corners and the
+    rows next to them stay full, 7 and 9 as OpenCV prints them."""
+    assert CV.ellipse_se(3).astype(int).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+    assert CV.ellipse_se(5).astype(int).tolist() == [[0, 0, 1, 0, 0]] + [[1] * 5] * 3 + [[0, 0, 1, 0, 0]]
+    assert CV.ellipse_se(7).sum(axis=1).tolist() == [1, 5, 7, 7, 7, 5, 1]
+    assert CV.ellipse_se(9).sum(axis=1).tolist() == [1, 7, 7, 9, 9, 9, 7, 7, 1]
+    for k in (3, 5, 7, 9):
+        se = CV.ellipse_se(k)
+        assert np.array_equal(se, se[::-1]) and np.array_equal(se, se[:, ::-1])   # mirror-symmetric, wider than tall
+        assert np.array_equal(CV.morph(np.eye(1, dtype=np.uint8) * 255, se, False), [[255]])
+
+
+def test_morphology_and_border():
+    m = np.zeros((9, 9), np.uint8)
+    m[4, 4] = 255
+    d = CV.morph(m, CV.ellipse_se(5), erode=False)
+    assert np.array_equal(d[2:7, 2:7] > 0, CV.ellipse_se(5))               # dilating a point draws the element
+    assert np.array_equal(CV.morph(d, CV.ellipse_se(5), erode=True), m)    # and eroding brings the point back
+    full = np.full((6, 7), 255, np.uint8)
+    assert np.array_equal(CV.morph(full, CV.ellipse_se(9), erode=True), full)   # the border never erodes
+    assert np.array_equal(CV.morph_cross3(m, False), CV.morph(m, CV.ellipse_se(3), False))
+    hole = full.copy()
+    hole[3, 3] = 0
+    assert np.array_equal(CV.morph_close(hole, 3), full) and np.array_equal(CV.morph_open(m, 3), np.zeros_like(m))
+
+
+def test_largest_component_rules():
+    m = np.zeros((6, 8), np.uint8)
+    m[0, 0:2] = 255            # area 2
+    m[2, 2] = m[3, 3] = m[4, 2] = 255   # diagonal neighbours join under 8-connectivity: area 3
+    m[5, 6:8] = 255            # area 2
+    out = CV.largest_component(m)
+    assert int(out.sum()) == 3 * 255 and out[3, 3] == 255 and out[0, 0] == 0
+    m[3, 3] = 0                # now 2, 1, 1, 2: the first of the equal largest (raster order) stays
+    out = CV.largest_component(m)
+    assert int(out.sum()) == 2 * 255 and out[0, 0] == 255 and out[5, 7] == 0
+    assert np.array_equal(CV.largest_component(np.zeros((3, 3), np.uint8)), np.zeros((3, 3), np.uint8))
+
+
+def test_canny_l1_thresholds():
+    """cv2.Canny's default gradient: |dx| + |dy| against floor(threshold).  A step of 25 has |dx| = 100 on its
+    two columns: strong at high = 99, nothing at all at low = high = 100."""
+    g = np.zeros((8, 10), np.uint8)
+    g[:, 5:] = 25
+    assert int(CV.canny(g, 30, 99, l2gradient=False).sum()) == 8 * 255
+    assert int(CV.canny(g, 100, 100, l2gradient=False).sum()) == 0
+
+
+def test_inclusive_mask_on_a_synthetic_leaf():
+    """A green disc on a flat grey card: the mask is the disc (to within the closes), nothing of the card; a
+    second, smaller green blob is dropped by the largest-component rule; an all-grey image gives no mask."""
+    h = w = 96
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.full((h, w, 3), 128, np.uint8)
+    disc = (yy - 48) ** 2 + (xx - 40) ** 2 <= 24 ** 2
+    blob = (yy - 12) ** 2 + (xx - 84) ** 2 <= 5 ** 2
+    img[disc] = (40, 160, 50)
+    img[blob] = (40, 160, 50)
+    m = CV.inclusive_mask(img)
+    assert set(np.unique(m)) <= {0, 255}
+    inner = (yy - 48) ** 2 + (xx - 40) ** 2 <= 21 ** 2
+    outer = (yy - 48) ** 2 + (xx - 40) ** 2 <= 29 ** 2
+    assert (m[inner] == 255).all() and (m[~outer] == 0).all() and (m[blob] == 0).all()
+    assert int(CV.inclusive_mask(np.full((40, 40, 3), 128, np.uint8)).sum()) == 0
