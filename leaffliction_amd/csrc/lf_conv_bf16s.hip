@@ -140,7 +140,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     constexpr int NXU = QD * PH * PGS, XPT = (NXU + kT - 1) / kT;
     constexpr int NHU = QD * PH * 2 * HALO, HPT = (NHU + kT - 1) / kT;
     uvec rx[XPT][XBF ? 4 : 3];
-    unsigned rh[HPT > 0 ? HPT : 1][XBF ? 2 : 3];
+    unsigned rh[HPT > 0 ? HPT : 1][XBF ? 4 : 3];   // raw loads: combining them here would wait for them here
     unsigned xmask = 0, hmask = 0;
 
     auto tile_of = [&](int item, int& n, int& tx0, int& ty0) {
@@ -184,8 +184,8 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
             if (!ok) continue;
             const size_t o = (size_t)(4 * quad) * hw + (size_t)gy * p.w + gx;
             if (XBF) {
-                rh[k][0] = (unsigned)xb[o] | (unsigned)xb[o + hw] << 16;
-                rh[k][1] = (unsigned)xb[o + 2 * hw] | (unsigned)xb[o + 3 * hw] << 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rh[k][i] = xb[o + (size_t)i * hw];
             } else {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) rh[k][i] = i < p.cin ? __float_as_uint(xf[o + (size_t)i * hw]) : 0u;
@@ -247,10 +247,8 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (hmask >> k & 1u) {
                 if (XBF) {
-                    v[0] = up(rh[k][0] & 0xffffu);
-                    v[1] = up(rh[k][0] >> 16);
-                    v[2] = up(rh[k][1] & 0xffffu);
-                    v[3] = up(rh[k][1] >> 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = up(rh[k][i]);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) v[i] = __uint_as_float(rh[k][i]);
@@ -440,7 +438,13 @@ SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
     }
     pl.nco = cout / 32;
     if (ksize == 1 && !(pl.ci == 32 && pl.nco == 2) && !(pl.ci == 64 && pl.nco == 1)) return pl;
-    if (w % 32 == 0 || w > 128) { pl.tw = 32; pl.th = 8; } else { pl.tw = 16; pl.th = 16; }
+    // Rows of a tile are the unit of every global access (64 px = 128 bytes of bf16 per channel row): measured
+    // on 32->32 @224, 64x4 tiles against 32x8: forward 687 -> 659 us, input gradient with accumulate + mask +
+    // sums 1167 -> 913 us; 64->64 @112 against 16x16: 724 -> 513 and 1043 -> 699 us — although an eighth of
+    // the last tile of a 224- or 112-pixel row is empty (scripts/microbench/conv_modes.py).
+    if (w >= 64) { pl.tw = 64; pl.th = 4; }
+    else if (w % 32 == 0) { pl.tw = 32; pl.th = 8; }
+    else { pl.tw = 16; pl.th = 16; }
     pl.tiles_x = (w + pl.tw - 1) / pl.tw;
     pl.tiles_y = (h + pl.th - 1) / pl.th;
     pl.items = n * pl.tiles_x * pl.tiles_y;
@@ -501,6 +505,7 @@ int conv_bf16s_launch(ConvBf16TrainArgs a, int ksize, int x_bf16, hipStream_t s)
     }
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.items = pl.items; a.items_per_wg = pl.items_per_wg;
     a.stat_tiles = pl.wgs;
+    if (pl.tw == 64) return dispatch_s<64, 4>(pl, ksize, a, s);
     return pl.tw == 32 ? dispatch_s<32, 8>(pl, ksize, a, s) : dispatch_s<16, 16>(pl, ksize, a, s);
 }
 

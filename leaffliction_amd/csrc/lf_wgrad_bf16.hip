@@ -130,7 +130,7 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
     constexpr int NHU = STEM ? 0 : CIB * 8 * PH * 2 * HALO, HPT = (NHU + kT - 1) / kT;
     uvec rg[DPT][4], ry[DPT][4];
     uvec rx[XPT > 0 ? XPT : 1][4];
-    unsigned rh[HPT > 0 ? HPT : 1][2];
+    unsigned rh[HPT > 0 ? HPT : 1][4];   // raw loads: combining them at issue would wait for them at issue
     float rs[STEM ? 27 : 1];
     unsigned dmask = 0, xmask = 0, hmask = 0;  // bit k: unit k lies inside the image
 
@@ -201,8 +201,8 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
                 hmask |= (ok ? 1u : 0u) << k;
                 if (!ok) continue;
                 const size_t o = (size_t)(ci0 + 4 * quad) * hw + (size_t)gy * p.w + gx;
-                rh[k][0] = (unsigned)xn[o] | (unsigned)xn[o + hw] << 16;
-                rh[k][1] = (unsigned)xn[o + 2 * hw] | (unsigned)xn[o + 3 * hw] << 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rh[k][i] = xn[o + (size_t)i * hw];
             }
         }
     };
@@ -330,10 +330,8 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
                 const int side = u & 1, t1 = u >> 1, quad = t1 % (8 * CIB), pr = t1 / (8 * CIB);
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (hmask >> k & 1u) {
-                    v[0] = up(rh[k][0] & 0xffffu);
-                    v[1] = up(rh[k][0] >> 16);
-                    v[2] = up(rh[k][1] & 0xffffu);
-                    v[3] = up(rh[k][1] >> 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = up(rh[k][i]);
                     if (pro)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
