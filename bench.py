@@ -79,7 +79,7 @@ class KernelTimer:
                 stem = (not args[1]) and cin <= 3 and k == 3 and cout == 32
                 if cout in (32, 64) and w % 8 == 0 and (stem or (args[1] and cin in (32, 64))) and \
                         (k == 3 or (cin, cout) in ((32, 64), (64, 32))):
-                    tw, th = (32, 8) if (w % 32 == 0 or w > 128) else (16, 16)   # plan_s of lf_conv_bf16s.hip
+                    tw, th = (64, 4) if w >= 64 else ((32, 8) if w % 32 == 0 else (16, 16))   # plan_s of lf_conv_bf16s.hip
                     kname = f"conv_bf16s_kernel<{k * k},{16 if stem else cin},{cout // 32},{tw},{th}> {cin}->{cout}@{h}"
                 else:
                     kname = f"conv_bf16_kernel<{k * k},{'2,2' if cout % 64 == 0 else '1,4'}> {cin}->{cout}@{h}"

@@ -16,6 +16,7 @@
 // [chunk][tap][cout][16] bf16 so the A operand (one output channel, eight channels) is one 16-byte
 // LDS read.
 #include "lf_common.h"
+#include <stdlib.h>
 
 namespace {
 
