@@ -1,0 +1,179 @@
+// libleafhip — the pixel half of a baseline JPEG encoder (4:2:0), as libjpeg(-turbo) computes it for
+// Pillow's Image.save(path, quality=q) — the reference's ImageLoader.save_pil_image
+// (srcs/utils/image_utils.py:49-56): jccolor.c rgb_ycc_convert (16-bit fixed point), jcsample.c
+// h2v2_downsample (bias 1, 2, 1, 2 ...), jfdctint.c (CONST_BITS 13, PASS1_BITS 2), jcdctmgr.c
+// quantisation of the 8x-scaled coefficients (round half away from zero).  All integer: the quantised
+// coefficients equal libjpeg's bit for bit, so the host's entropy coder (lf_jpeg_host.cpp) writes the
+// very file Pillow writes (tests/test_jpeg_gpu.py compares the bytes).
+//
+// Output: coef[image][MCU][6 blocks: Y00 Y01 Y10 Y11 Cb Cr][64] int16 in ZIGZAG order — the order the
+// scan is coded in, 768 contiguous bytes per 16x16 MCU, as many bytes as the RGB pixels it replaces.
+// A workgroup takes four MCUs of a row at a time (a 64x16 pixel strip: 12-byte pixel groups in, 3 KiB of
+// coefficients out as 16 bytes per lane); HBM-bound byte work, nothing GEMM-shaped.
+#include "lf_common.h"
+
+namespace {
+
+constexpr int kT = 256, kGroup = 4;   // MCUs per workgroup pass
+
+struct JpegQuant {
+    uint16_t div[2][64];   // (Q << 3) of the luminance / chrominance table, row-major
+    uint8_t pos[64];       // row-major index -> zigzag position
+};
+
+constexpr int kCB = 13, kP1 = 2;
+#define LF_FIX(x) ((int)((x) * (1 << kCB) + 0.5))
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// jpeg_fdct_islow, one 1-D pass over d[0..7]; FIRST: the row pass (results scaled up by 2^PASS1_BITS)
+template <bool FIRST>
+__device__ __forceinline__ void fdct8(int* d) {
+    const int t0 = d[0] + d[7], t7 = d[0] - d[7], t1 = d[1] + d[6], t6 = d[1] - d[6];
+    const int t2 = d[2] + d[5], t5 = d[2] - d[5], t3 = d[3] + d[4], t4 = d[3] - d[4];
+    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    constexpr int SH = FIRST ? kCB - kP1 : kCB + kP1;
+    d[0] = FIRST ? (t10 + t11) << kP1 : descale(t10 + t11, kP1);
+    d[4] = FIRST ? (t10 - t11) << kP1 : descale(t10 - t11, kP1);
+    int z1 = (t12 + t13) * LF_FIX(0.541196100);
+    d[2] = descale(z1 + t13 * LF_FIX(0.765366865), SH);
+    d[6] = descale(z1 + t12 * (-LF_FIX(1.847759065)), SH);
+    z1 = t4 + t7;
+    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+    const int z5 = (z3 + z4) * LF_FIX(1.175875602);
+    const int u4 = t4 * LF_FIX(0.298631336), u5 = t5 * LF_FIX(2.053119869);
+    const int u6 = t6 * LF_FIX(3.072711026), u7 = t7 * LF_FIX(1.501321110);
+    z1 *= -LF_FIX(0.899976223);
+    z2 *= -LF_FIX(2.562915447);
+    z3 = z3 * (-LF_FIX(1.961570560)) + z5;
+    z4 = z4 * (-LF_FIX(0.390180644)) + z5;
+    d[7] = descale(u4 + z1 + z3, SH);
+    d[5] = descale(u5 + z2 + z4, SH);
+    d[3] = descale(u6 + z2 + z3, SH);
+    d[1] = descale(u7 + z1 + z4, SH);
+}
+
+__global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __restrict__ rgb,
+                                                             int16_t* __restrict__ coef, int h, int w, int n_images,
+                                                             JpegQuant q) {
+    __shared__ __attribute__((aligned(16))) uint8_t sy[16][16 * kGroup], scb[16][16 * kGroup], scr[16][16 * kGroup];
+    __shared__ uint8_t sc[2][8][8 * kGroup];
+    __shared__ int mid[6 * kGroup][64];
+    __shared__ __attribute__((aligned(16))) int16_t outb[6 * kGroup][64];
+    __shared__ uint16_t sdiv[2][64];
+    __shared__ uint8_t spos[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        sdiv[0][tid] = q.div[0][tid];
+        sdiv[1][tid] = q.div[1][tid];
+        spos[tid] = q.pos[tid];
+    }
+    const int mcu_w = w / 16, mcu_h = h / 16, gw = (mcu_w + kGroup - 1) / kGroup;
+    const long groups = (long)n_images * mcu_h * gw;
+    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int gx = (int)(g % gw);
+        const long t1 = g / gw;
+        const int my = (int)(t1 % mcu_h);
+        const size_t n = (size_t)(t1 / mcu_h);
+        const int mx0 = gx * kGroup, nm = min(kGroup, mcu_w - mx0);
+        __syncthreads();   // the previous pass is done with the planes; the tables are in place
+        {   // ---- four pixels per thread: RGB -> Y, Cb, Cr (jccolor.c, SCALEBITS 16)
+            const int row = tid >> 4, x = (tid & 15) * 4;
+            if (x < 16 * nm) {
+                const uint8_t* p = rgb + ((n * h + 16 * my + row) * (size_t)w + 16 * mx0 + x) * 3;
+                const unsigned* p4 = reinterpret_cast<const unsigned*>(p);   // 12-byte groups of a 4-pixel-aligned column
+                const unsigned wd[3] = {p4[0], p4[1], p4[2]};
+                unsigned yy = 0, cb = 0, cr = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = (wd[(3 * k) >> 2] >> (8 * ((3 * k) & 3))) & 255;
+                    const int gg = (wd[(3 * k + 1) >> 2] >> (8 * ((3 * k + 1) & 3))) & 255;
+                    const int b = (wd[(3 * k + 2) >> 2] >> (8 * ((3 * k + 2) & 3))) & 255;
+                    yy |= (unsigned)((19595 * r + 38470 * gg + 7471 * b + 32768) >> 16) << (8 * k);
+                    cb |= (unsigned)((-11059 * r - 21709 * gg + 32768 * b + (128 << 16) + 32767) >> 16) << (8 * k);
+                    cr |= (unsigned)((32768 * r - 27439 * gg - 5329 * b + (128 << 16) + 32767) >> 16) << (8 * k);
+                }
+                *reinterpret_cast<unsigned*>(&sy[row][x]) = yy;
+                *reinterpret_cast<unsigned*>(&scb[row][x]) = cb;
+                *reinterpret_cast<unsigned*>(&scr[row][x]) = cr;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * 8 * 8 * kGroup; i += kT) {   // ---- h2v2_downsample, bias 1, 2, 1, 2 ...
+            const int pl = i / (8 * 8 * kGroup), r = (i / (8 * kGroup)) & 7, c = i % (8 * kGroup);
+            const uint8_t(*P)[16 * kGroup] = pl ? scr : scb;
+            sc[pl][r][c] = (uint8_t)((P[2 * r][2 * c] + P[2 * r][2 * c + 1] + P[2 * r + 1][2 * c] + P[2 * r + 1][2 * c + 1] +
+                                      1 + (c & 1)) >> 2);
+        }
+        __syncthreads();
+        const int blk = tid >> 3, k8 = tid & 7, mi = blk / 6, b = blk - 6 * mi;
+        const bool work = blk < 6 * nm;
+        if (work) {   // ---- row pass
+            int d[8];
+            if (b < 4) {
+                const uint8_t* s = &sy[8 * (b >> 1) + k8][16 * mi + 8 * (b & 1)];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = (int)s[k] - 128;
+            } else {
+                const uint8_t* s = &sc[b - 4][k8][8 * mi];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = (int)s[k] - 128;
+            }
+            fdct8<true>(d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mid[blk][8 * k8 + k] = d[k];
+        }
+        __syncthreads();
+        if (work) {   // ---- column pass, quantisation, zigzag
+            int d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = mid[blk][8 * k + k8];
+            fdct8<false>(d);
+            const uint16_t* dv = sdiv[b < 4 ? 0 : 1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = 8 * k + k8, dq = dv[idx];
+                const int a = d[k] < 0 ? -d[k] : d[k];
+                const int v = (a + (dq >> 1)) / dq;
+                outb[blk][spos[idx]] = (int16_t)(d[k] < 0 ? -v : v);
+            }
+        }
+        __syncthreads();
+        if (work) {   // 16 bytes per lane, 768 contiguous bytes per MCU
+            int16_t* dst = coef + ((n * mcu_h + my) * (size_t)mcu_w + mx0) * (6 * 64);
+            reinterpret_cast<lf::u32x4*>(dst)[tid] = reinterpret_cast<const lf::u32x4*>(&outb[0][0])[tid];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lf_jpeg_fdct_quant_u8(const uint8_t* rgb, int16_t* coef, int n, int h, int w, int quality,
+                          lf_stream_t stream) {
+    LF_REQUIRE(rgb && coef, "lf_jpeg_fdct_quant: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_jpeg_fdct_quant: bad dims n=%d h=%d w=%d", n, h, w);
+    LF_REQUIRE(h % 16 == 0 && w % 16 == 0, "lf_jpeg_fdct_quant: whole 16x16 MCUs only (%d x %d)", h, w);
+    LF_REQUIRE(h <= 65535 && w <= 65535, "lf_jpeg_fdct_quant: JPEG dimensions are 16-bit");
+    LF_REQUIRE(quality >= 1 && quality <= 100, "lf_jpeg_fdct_quant: quality %d", quality);
+    LF_REQUIRE((reinterpret_cast<size_t>(rgb) & 3) == 0 && (reinterpret_cast<size_t>(coef) & 15) == 0,
+               "lf_jpeg_fdct_quant: rgb must be 4-byte and coef 16-byte aligned");
+    JpegQuant q;
+    uint8_t tabs[2][64];
+    lf_jpeg_quant_tables(quality, tabs[0], tabs[1]);
+    static const uint8_t natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                        41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                        30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    for (int i = 0; i < 64; ++i) {
+        q.div[0][i] = (uint16_t)(tabs[0][i] << 3);
+        q.div[1][i] = (uint16_t)(tabs[1][i] << 3);
+        q.pos[natural[i]] = (uint8_t)i;
+    }
+    const long groups = (long)n * (h / 16) * ((w / 16 + kGroup - 1) / kGroup);
+    const unsigned grid = (unsigned)(groups < 256 * 16 ? groups : 256 * 16);
+    jpeg_fdct_quant_kernel<<<grid, kT, 0, lf::as_stream(stream)>>>(rgb, coef, h, w, n, q);
+    return lf::check_launch("lf_jpeg_fdct_quant");
+}
+
+}  // extern "C"

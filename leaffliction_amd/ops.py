@@ -269,6 +269,22 @@ def inclusive_mask_u8(x: torch.Tensor, green_hue_range=(25, 100)) -> torch.Tenso
     return out
 
 
+def jpeg_fdct_quant_u8(x: torch.Tensor, quality: int = 95, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The pixel half of Image.save(path, quality=quality) (image_utils.py:49-56) for a batch [N,H,W,3] uint8
+    with H, W multiples of 16: libjpeg's quantised DCT coefficients, int16 [N, H/16 * W/16, 6, 64] — per MCU the
+    blocks Y00 Y01 Y10 Y11 Cb Cr in zigzag order, what utils.jpeg_host.write_file turns into the file."""
+    n, h, w = _hwc(x, "jpeg_fdct_quant.x")
+    if h % 16 or w % 16:
+        raise ValueError(f"jpeg_fdct_quant: whole 16x16 MCUs only, got {h}x{w}")
+    shape = (n, (h // 16) * (w // 16), 6, 64)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.int16, device=x.device)
+    elif out.dtype != torch.int16 or out.numel() != n * shape[1] * 384 or not out.is_contiguous():
+        raise ValueError("jpeg_fdct_quant.out: expected a contiguous int16 tensor of N*MCUs*384 elements")
+    _lib.call("lf_jpeg_fdct_quant_u8", x.data_ptr(), out.data_ptr(), n, h, w, int(quality), _stream())
+    return out.view(shape)
+
+
 # ---------------------------------------------------------------------------
 # geometric ops (Pillow semantics)
 # ---------------------------------------------------------------------------

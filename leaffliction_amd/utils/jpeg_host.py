@@ -1,0 +1,48 @@
+"""The host half of the JPEG encoder: libleafcodec.so (csrc/lf_jpeg_host.cpp built on its own, no HIP
+runtime behind it) through ctypes.  It turns the quantised coefficients `ops.jpeg_fdct_quant_u8` leaves in
+scan order into the complete file Pillow's `Image.save(path, quality=q)` writes for the same pixels
+(srcs/utils/image_utils.py:49-56): markers, Annex K Huffman coding, byte stuffing.  Loaded by the codec
+worker processes, which never touch the GPU."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent.parent / "libleafcodec.so"
+_LIB: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C leaffliction_amd/csrc`")
+        lib = C.CDLL(str(LIB_PATH))
+        lib.lf_jpeg_file_bound.argtypes = [C.c_int, C.c_int]
+        lib.lf_jpeg_file_bound.restype = C.c_size_t
+        lib.lf_jpeg_write_file.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        lib.lf_jpeg_write_file.restype = C.c_long
+        _LIB = lib
+    return _LIB
+
+
+_SCRATCH: Optional[np.ndarray] = None
+
+
+def write_file(coef: np.ndarray, h: int, w: int, quality: int = 95) -> bytes:
+    """coef: int16 [H/16 * W/16 MCUs, 6, 64] (any shape with that many elements, C-contiguous)."""
+    global _SCRATCH
+    lib = load()
+    c = np.ascontiguousarray(coef, dtype=np.int16)
+    if h % 16 or w % 16 or c.size != (h // 16) * (w // 16) * 384:
+        raise ValueError(f"write_file: {c.size} coefficients do not make a {h}x{w} image of whole MCUs")
+    cap = int(lib.lf_jpeg_file_bound(h, w))
+    if _SCRATCH is None or _SCRATCH.size < cap:
+        _SCRATCH = np.empty(cap, dtype=np.uint8)
+    n = int(lib.lf_jpeg_write_file(c.ctypes.data, h, w, int(quality), _SCRATCH.ctypes.data, cap))
+    if n < 0:
+        raise RuntimeError("lf_jpeg_write_file failed")
+    return _SCRATCH[:n].tobytes()

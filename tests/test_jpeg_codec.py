@@ -1,0 +1,106 @@
+"""JPEG encode: the oracle (oracle/jpeg_ref.py, libjpeg's integer pipeline restated) is pinned to the BYTES
+Pillow writes — Pillow is the reference's own encoder (srcs/utils/image_utils.py:49-56) and is installed —,
+the host entropy coder (libleafcodec.so) to the oracle and to Pillow, and (GPU) the coefficients of
+lf_jpeg_fdct_quant_u8 to the oracle's and the finished files to Pillow's, byte for byte."""
+import io
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import jpeg_ref as J
+
+
+def pil_bytes(a, quality=95):
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, format="JPEG", quality=quality)
+    return b.getvalue()
+
+
+def scene(h, w, seed):
+    r = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(xx / 17.0 + seed) * np.cos(yy / 23.0), 90 + 80 * np.cos(xx / 9.0),
+                    140 + 60 * np.sin((xx + yy) / 31.0)], -1) + r.normal(0, 3 + 4 * (seed % 3), (h, w, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def mcu_order(y, cb, cr):
+    """oracle planes of blocks -> [MCUs, 6, 64] in scan order"""
+    my, mx = cb.shape[:2]
+    out = np.zeros((my * mx, 6, 64), np.int16)
+    for i in range(my):
+        for j in range(mx):
+            m = out[i * mx + j]
+            m[0], m[1], m[2], m[3] = y[2 * i, 2 * j], y[2 * i, 2 * j + 1], y[2 * i + 1, 2 * j], y[2 * i + 1, 2 * j + 1]
+            m[4], m[5] = cb[i, j], cr[i, j]
+    return out
+
+
+CASES = [("noise", 32, 48, 0), ("scene", 64, 64, 1), ("scene", 224, 224, 2), ("flat", 16, 16, 3), ("extremes", 48, 32, 4)]
+
+
+def make(kind, h, w, seed):
+    rng = np.random.RandomState(seed)
+    if kind == "noise":
+        return rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    if kind == "flat":
+        return np.full((h, w, 3), 200, np.uint8)
+    if kind == "extremes":   # saturated checkerboards: the largest coefficients, long zero runs, 0xFF bytes to stuff
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = (((yy // 3 + xx // 5) % 2) * 255).astype(np.uint8)
+        return np.stack([a, 255 - a, np.where(xx < w // 2, a, 0).astype(np.uint8)], -1)
+    return scene(h, w, seed)
+
+
+@pytest.mark.parametrize("kind,h,w,seed", CASES)
+def test_oracle_writes_pillows_bytes(kind, h, w, seed):
+    a = make(kind, h, w, seed)
+    assert J.encode(a) == pil_bytes(a)
+
+
+@pytest.mark.parametrize("quality", [50, 75, 90, 100])
+def test_oracle_other_qualities(quality):
+    a = scene(48, 64, quality)
+    assert J.encode(a, quality) == pil_bytes(a, quality)
+
+
+@pytest.mark.parametrize("kind,h,w,seed", CASES)
+def test_host_entropy_coder_writes_pillows_bytes(kind, h, w, seed):
+    from leaffliction_amd.utils import jpeg_host
+    a = make(kind, h, w, seed)
+    coef = mcu_order(*J.quantised_coefficients(a))
+    assert jpeg_host.write_file(coef, h, w) == pil_bytes(a)
+
+
+def test_host_coder_rejects_bad_shapes():
+    from leaffliction_amd.utils import jpeg_host
+    with pytest.raises(ValueError):
+        jpeg_host.write_file(np.zeros((1, 6, 64), np.int16), 16, 32)
+    with pytest.raises(ValueError):
+        jpeg_host.write_file(np.zeros((1, 6, 64), np.int16), 17, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,h,w,seed", CASES + [("scene", 96, 208, 7), ("noise", 224, 224, 8)])
+def test_gpu_coefficients_and_files(cuda, kind, h, w, seed):
+    import torch
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    batch = np.stack([make(kind, h, w, seed + 10 * i) for i in range(3)])
+    coef = ops.jpeg_fdct_quant_u8(torch.from_numpy(batch).to(cuda)).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(coef[i], mcu_order(*J.quantised_coefficients(batch[i]))), i
+        assert jpeg_host.write_file(coef[i], h, w) == pil_bytes(batch[i]), i
+
+
+@pytest.mark.gpu
+def test_gpu_other_quality_and_bad_shape(cuda):
+    import torch
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    a = scene(64, 80, 5)
+    coef = ops.jpeg_fdct_quant_u8(torch.from_numpy(a[None]).to(cuda), quality=80).cpu().numpy()
+    assert jpeg_host.write_file(coef[0], 64, 80, 80) == pil_bytes(a, 80)
+    with pytest.raises(ValueError):
+        ops.jpeg_fdct_quant_u8(torch.zeros((1, 30, 32, 3), dtype=torch.uint8, device=cuda))
