@@ -6,6 +6,9 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 extern "C" {
 void lf_jpeg_quant_tables(int quality, uint8_t* lum64, uint8_t* chroma64);
@@ -79,57 +82,104 @@ struct Tables {
     }
 };
 
+// Bit writer in the manner of libjpeg-turbo's jchuff.c: a 64-bit accumulator, written out eight bytes at a
+// time, with the 0xFF -> 0xFF 0x00 stuffing taken off the fast path by one test on the whole word.
 struct Writer {
     uint8_t* p;
     uint8_t* end;
     uint64_t acc = 0;
-    int n = 0;   // bits held in acc
+    int free_bits = 64;
     bool overflow = false;
-    void put(unsigned code, int len) {
-        acc = (acc << len) | (code & ((1u << len) - 1u));
-        n += len;
-        while (n >= 8) {
-            const uint8_t byte = (uint8_t)(acc >> (n - 8));
-            if (p + 2 > end) {
-                overflow = true;
-                n -= 8;
-                continue;
+    void emit8(uint64_t v) {
+        if (p + 16 > end) {
+            overflow = true;
+            return;
+        }
+        if (v & 0x8080808080808080ull & ~(v + 0x0101010101010101ull)) {   // some byte may be 0xFF
+            for (int s = 56; s >= 0; s -= 8) {
+                const uint8_t byte = (uint8_t)(v >> s);
+                *p++ = byte;
+                if (byte == 0xFF) *p++ = 0;
             }
-            *p++ = byte;
-            if (byte == 0xFF) *p++ = 0;   // byte stuffing
-            n -= 8;
+        } else {
+            const uint64_t be = __builtin_bswap64(v);
+            memcpy(p, &be, 8);
+            p += 8;
         }
     }
-    void flush() {
-        if (n) put((1u << (8 - n)) - 1u, 8 - n);   // pad the last byte with ones
+    void put(uint64_t code, int len) {   // len <= 32; bits above len in `code` must be zero
+        free_bits -= len;
+        if (free_bits < 0) {
+            acc = (acc << (len + free_bits)) | (code >> -free_bits);
+            emit8(acc);
+            free_bits += 64;
+            acc = code;   // the bits already written sit above the valid ones and are shifted out later
+        } else {
+            acc = (acc << len) | code;
+        }
+    }
+    void flush() {   // whole bytes out, the last one padded with ones
+        int bits = 64 - free_bits;
+        if (p + 20 > end) {
+            overflow = true;
+            return;
+        }
+        uint64_t v = bits ? acc << free_bits : 0;   // valid bits at the top
+        while (bits > 0) {
+            uint8_t byte = (uint8_t)(v >> 56);
+            if (bits < 8) byte |= (uint8_t)(0xFFu >> bits);
+            *p++ = byte;
+            if (byte == 0xFF) *p++ = 0;
+            v <<= 8;
+            bits -= 8;
+        }
+        acc = 0;
+        free_bits = 64;
     }
 };
 
 inline int nbits_of(int a) { return a ? 32 - __builtin_clz((unsigned)a) : 0; }
 
+// bit k set <=> zz[k] != 0
+inline uint64_t nonzero_mask(const int16_t* zz) {
+#if defined(__SSE2__)
+    const __m128i zero = _mm_setzero_si128();
+    uint64_t m = 0;
+    for (int i = 0; i < 4; ++i) {
+        const __m128i a = _mm_cmpeq_epi16(_mm_loadu_si128(reinterpret_cast<const __m128i*>(zz + 16 * i)), zero);
+        const __m128i b = _mm_cmpeq_epi16(_mm_loadu_si128(reinterpret_cast<const __m128i*>(zz + 16 * i + 8)), zero);
+        m |= (uint64_t)(uint16_t)_mm_movemask_epi8(_mm_packs_epi16(a, b)) << (16 * i);
+    }
+    return ~m;
+#else
+    uint64_t m = 0;
+    for (int k = 0; k < 64; ++k) m |= (uint64_t)(zz[k] != 0) << k;
+    return m;
+#endif
+}
+
 inline int code_block(Writer& wr, const int16_t* zz, int last_dc, const Huff& dc, const Huff& ac) {
     const int diff = zz[0] - last_dc;
     int nb = nbits_of(diff < 0 ? -diff : diff);
-    wr.put(dc.code[nb], dc.len[nb]);
-    if (nb) wr.put((unsigned)(diff < 0 ? diff - 1 : diff), nb);
-    int run = 0;
-    for (int k = 1; k < 64; ++k) {
-        const int v = zz[k];
-        if (v == 0) {
-            ++run;
-            continue;
-        }
+    // a negative value is sent as value - 1 in nb bits
+    wr.put(((uint64_t)dc.code[nb] << nb) | ((unsigned)(diff + (diff >> 31)) & ((1u << nb) - 1u)), dc.len[nb] + nb);
+    uint64_t m = nonzero_mask(zz) & ~1ull;
+    int prev = 0;
+    while (m) {
+        const int k = __builtin_ctzll(m);
+        m &= m - 1;
+        int run = k - prev - 1;
+        prev = k;
         while (run > 15) {
             wr.put(ac.code[0xF0], ac.len[0xF0]);
             run -= 16;
         }
+        const int v = zz[k];
         nb = nbits_of(v < 0 ? -v : v);
         const int sym = (run << 4) | nb;
-        wr.put(ac.code[sym], ac.len[sym]);
-        wr.put((unsigned)(v < 0 ? v - 1 : v), nb);
-        run = 0;
+        wr.put(((uint64_t)ac.code[sym] << nb) | ((unsigned)(v + (v >> 31)) & ((1u << nb) - 1u)), ac.len[sym] + nb);
     }
-    if (run) wr.put(ac.code[0], ac.len[0]);
+    if (prev != 63) wr.put(ac.code[0], ac.len[0]);
     return zz[0];
 }
 
@@ -192,7 +242,7 @@ long lf_jpeg_write_file(const int16_t* coef, int h, int w, int quality, uint8_t*
     }
     static const uint8_t sos[14] = {0xFF, 0xDA, 0x00, 0x0C, 0x03, 0x01, 0x00, 0x02, 0x11, 0x03, 0x11, 0x00, 0x3F, 0x00};
     p = put_bytes(p, sos, 14);
-    Writer wr{p, out + cap - 2};
+    Writer wr{p, out + cap - 2};   // the two bytes of EOI stay free
     int last[3] = {0, 0, 0};
     const long mcus = (long)(h / 16) * (w / 16);
     for (long m = 0; m < mcus; ++m) {

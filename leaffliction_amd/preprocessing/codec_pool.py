@@ -13,7 +13,10 @@ pixels cross the process boundary through shared memory, never through pickles:
       reference's worker does), including the distortion's 150 k normal deviates, which are cast to
       uint8 by numpy itself (image_augmenter.py:121-123) into the NOISE slab;
   main process:  one H2D per (transform, size) group, batched kernels, D2H into the OUTPUT slab;
-  encode worker: slot of the OUTPUT slab -> JPEG quality 95 -> the task's output path.
+  encode worker: slot of the OUTPUT slab -> JPEG quality 95 -> the task's output path.  Images of whole
+      16x16 MCUs arrive as quantised DCT coefficients (colour conversion, 4:2:0 downsampling, DCT and
+      quantisation ran on the GPU, ops.jpeg_fdct_quant_u8) and the worker only Huffman-codes them
+      (libleafcodec.so): the same bytes Pillow would write, for a third of the host time.
 
 Only paths, shapes, seeds and a few floats are pickled.  Slots are fixed-size (an image that does
 not fit — a rotated copy of an unusually large original — falls back to a pickled array).
@@ -43,6 +46,8 @@ def _warm(_i: int) -> bool:
     """First job of every worker: pay the imports while the parent is still copying the originals."""
     from ..utils.image_utils import ImageLoader  # noqa: F401
     from .image_augmenter import draw_params  # noqa: F401
+    from ..utils import jpeg_host
+    jpeg_host.load()
     import time
     time.sleep(0.05)   # long enough that every worker of the pool takes one
     return True
@@ -80,13 +85,27 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[Tuple[str, str, int, int,
     return out
 
 
-def _encode_jobs(names: Dict[str, str], jobs: Sequence[Tuple[str, int, Tuple[int, int, int], Any]]):
-    """jobs: (output path, output offset, shape, inline array or None).  Returns one bool per job."""
+def _encode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
+    """jobs: (output path, output offset, shape, inline array or None[, "px" | "coef"]).  "coef": the slot
+    holds the image's quantised DCT coefficients (ops.jpeg_fdct_quant_u8, quality 95) and the worker's part
+    is the entropy coding (libleafcodec.so); otherwise pixels for Pillow.  Returns one bool per job."""
+    from pathlib import Path
+    from ..utils import jpeg_host
     from ..utils.image_utils import ImageLoader
     buf = _slabs(names)["out"].buf
     done = []
-    for path, off, shape, inline in jobs:
+    for job in jobs:
+        path, off, shape, inline = job[:4]
         try:
+            if len(job) > 4 and job[4] == "coef":
+                h, w = int(shape[0]), int(shape[1])
+                data = jpeg_host.write_file(np.frombuffer(buf, np.int16, h * w * 3 // 2, off), h, w, 95)
+                dst = Path(path)
+                dst.parent.mkdir(parents=True, exist_ok=True)
+                with open(dst, "wb") as f:
+                    f.write(data)
+                done.append(True)
+                continue
             arr = inline if inline is not None else np.frombuffer(
                 buf, np.uint8, int(np.prod(shape)), off).reshape(shape)
             ImageLoader.save_array(arr, path)
@@ -150,7 +169,9 @@ class CodecPool:
         return np.frombuffer(self.slabs[slab].buf, np.uint8, n, slot * self.slot_bytes).reshape(shape)
 
     def _split(self, jobs: List[Any]) -> List[List[Any]]:
-        per = max(1, -(-len(jobs) // self.workers))
+        # four pieces per worker: a piece that happens to hold several distortion tasks (150 k normal deviates
+        # each, 4x the cost of the decode next to it) no longer decides when the chunk is ready
+        per = max(1, -(-len(jobs) // (4 * self.workers)))
         return [jobs[i:i + per] for i in range(0, len(jobs), per)]
 
     def decode(self, tasks: Sequence[dict], first_slot: int) -> List[Future]:

@@ -37,6 +37,8 @@ from ..utils.system_info import get_optimal_worker_count
 logger = get_logger(__name__)
 
 CHUNK = 256  # tasks per GPU round
+RING = 4    # chunks of slots: two decoding ahead, one on the GPU, one encoding
+JPEG_QUALITY = 95  # ImageLoader.save_pil_image's default (srcs/utils/image_utils.py:50)
 
 
 class DatasetBalancer:
@@ -145,6 +147,7 @@ class DatasetBalancer:
         mirror, results land in a device mirror of the output slab and come back as ONE copy.
         Returns the encode jobs (path, offset, shape, inline array or None)."""
         import torch
+        from .. import ops
         n = len(chunk)
         device_path = self._mirror is not None
         if device_path:
@@ -175,8 +178,19 @@ class DatasetBalancer:
                     x = dev_in[idx, :h * w * 3].view(len(ks), h, w, 3)
                     res = apply_batch(op, x, prm)
                     if op != "rotate":
-                        dev_out[idx, :h * w * 3] = torch.stack(res).view(len(ks), -1)
-                        jobs += [(chunk[k]["output_path"], (base + k) * pool.slot_bytes, (h, w, 3), None) for k in ks]
+                        y = torch.stack(res)
+                        # whole-MCU images bound for .jpg files leave the GPU as quantised DCT coefficients (as many
+                        # bytes as the pixels): the worker's share of the encode is then the Huffman coding alone
+                        jpg = [Path(chunk[k]["output_path"]).suffix.lower() in (".jpg", ".jpeg") for k in ks]
+                        if h % 16 == 0 and w % 16 == 0 and all(jpg):
+                            coef = ops.jpeg_fdct_quant_u8(y, JPEG_QUALITY)
+                            dev_out[idx, :h * w * 3] = coef.view(torch.uint8).view(len(ks), -1)
+                            kind = "coef"
+                        else:
+                            dev_out[idx, :h * w * 3] = y.view(len(ks), -1)
+                            kind = "px"
+                        jobs += [(chunk[k]["output_path"], (base + k) * pool.slot_bytes, (h, w, 3), None, kind)
+                                 for k in ks]
                     else:
                         for o, k in zip(res, ks):
                             if o.numel() <= pool.slot_bytes:
@@ -230,7 +244,7 @@ class DatasetBalancer:
         slot = (2 * h0 * w0 * 3 + 4095) // 4096 * 4096
         t0 = time.perf_counter()
         pool = self._codec or CodecPool(self.workers)
-        pool.allocate(3 * n_chunk, slot)
+        pool.allocate(RING * n_chunk, slot)
         self._mirror = None
         try:
             import torch
@@ -238,9 +252,13 @@ class DatasetBalancer:
                 dev = torch.device("cuda", torch.cuda.current_device())
                 self._mirror = (torch.empty((n_chunk, slot), dtype=torch.uint8, device=dev),
                                 torch.empty((n_chunk, slot), dtype=torch.uint8, device=dev))
-            decoding = pool.decode(chunks[0], 0)
-            decoding[0].result()   # the workers are up (spawn + imports) once the first piece is back
+            # chunk i + 2 is queued for decoding before chunk i goes to the GPU: the workers always have a
+            # chunk's worth of work behind the one the main thread is waiting for
+            ahead = [pool.decode(chunks[0], 0)]
+            ahead[0][0].result()   # the workers are up (spawn + imports) once the first piece is back
             self.timings["codec_pool_start"] = time.perf_counter() - t0
+            if len(chunks) > 1:
+                ahead.append(pool.decode(chunks[1], n_chunk))
             encoding, enc_paths = [], []
             decoded = jobs = None
             tw = {"wait_decode": 0.0, "gpu_stage": 0.0, "wait_encode": 0.0}
@@ -248,10 +266,11 @@ class DatasetBalancer:
             self.timings["slabs_page_locked"] = float(self._mirror is not None)
             for i, chunk in enumerate(chunks):
                 ta = time.perf_counter()
-                decoded = [r for f in decoding for r in f.result()]
-                decoding = pool.decode(chunks[i + 1], ((i + 1) % 3) * n_chunk) if i + 1 < len(chunks) else []
+                decoded = [r for f in ahead.pop(0) for r in f.result()]
+                if i + 2 < len(chunks):
+                    ahead.append(pool.decode(chunks[i + 2], ((i + 2) % RING) * n_chunk))
                 tb = time.perf_counter()
-                jobs = self._gpu_stage(chunk, decoded, pool, (i % 3) * n_chunk)
+                jobs = self._gpu_stage(chunk, decoded, pool, (i % RING) * n_chunk)
                 tc = time.perf_counter()
                 self._collect(encoding, enc_paths)
                 td = time.perf_counter()
