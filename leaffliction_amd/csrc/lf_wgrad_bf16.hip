@@ -130,7 +130,11 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
     constexpr int NHU = STEM ? 0 : CIB * 8 * PH * 2 * HALO, HPT = (NHU + kT - 1) / kT;
     uvec rg[DPT][4], ry[DPT][4];
     uvec rx[XPT > 0 ? XPT : 1][4];
-    unsigned rh[HPT > 0 ? HPT : 1][4];   // raw loads: combining them at issue would wait for them at issue
+    // Halo columns, 2-byte loads: kept raw until they are used — combining channel pairs at issue puts the
+    // wait for ALL of the tile's loads at issue — except in the 2x2 sub-block variants, which are at their
+    // register budget (the two extra registers per unit spill: 64->64 @112 0.70 -> 0.80 ms)
+    constexpr bool RAWH = CIB * COB < 4;
+    unsigned rh[HPT > 0 ? HPT : 1][RAWH ? 4 : 2];
     float rs[STEM ? 27 : 1];
     unsigned dmask = 0, xmask = 0, hmask = 0;  // bit k: unit k lies inside the image
 
@@ -201,8 +205,13 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
                 hmask |= (ok ? 1u : 0u) << k;
                 if (!ok) continue;
                 const size_t o = (size_t)(ci0 + 4 * quad) * hw + (size_t)gy * p.w + gx;
+                if (RAWH) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rh[k][i] = xn[o + (size_t)i * hw];
+                    for (int i = 0; i < 4; ++i) rh[k][i] = xn[o + (size_t)i * hw];
+                } else {
+                    rh[k][0] = (unsigned)xn[o] | (unsigned)xn[o + hw] << 16;
+                    rh[k][1] = (unsigned)xn[o + 2 * hw] | (unsigned)xn[o + 3 * hw] << 16;
+                }
             }
         }
     };
@@ -331,7 +340,8 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (hmask >> k & 1u) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = up(rh[k][i]);
+                    for (int i = 0; i < 4; ++i)
+                        v[i] = RAWH ? up(rh[k][i]) : up(i & 1 ? rh[k][i >> 1] >> 16 : rh[k][i >> 1] & 0xffffu);
                     if (pro)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
