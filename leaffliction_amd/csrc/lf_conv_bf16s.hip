@@ -80,8 +80,12 @@ struct SShape {
     static constexpr int LDS = WBYTES + (PBYTES > EBYTES ? PBYTES : EBYTES);
 };
 
-template <int TAPS, int CI, int NCO, int TW, int TH, bool XBF>
-__global__ __launch_bounds__(kT, (SShape<TAPS, CI, NCO, TW, TH>::LDS <= 80 * 1024 ? 2 : 1))
+// RMW = false: a launch with no read-modify-write operand (no accumulate, no BatchNorm-backward mask): the
+// 32 registers those operands wait in are free, which is what lets three workgroups share a CU (12 waves at
+// <= 168 registers) where the filter bank and the patch are small enough.
+template <int TAPS, int CI, int NCO, int TW, int TH, bool XBF, bool RMW>
+__global__ __launch_bounds__(kT, (SShape<TAPS, CI, NCO, TW, TH>::LDS <= 52 * 1024 && !RMW)
+                                     ? 3 : (SShape<TAPS, CI, NCO, TW, TH>::LDS <= 80 * 1024 ? 2 : 1))
 void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     using S = SShape<TAPS, CI, NCO, TW, TH>;
     static_assert(TW * TH == 256 && TW % 8 == 0, "tile = 4 waves x 64 pixels, whole 8-pixel groups");
@@ -101,7 +105,8 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 31, kh = lane >> 5;
     const size_t hw = (size_t)p.h * p.w;
     const bool pro = p.in_scale != nullptr;
-    const bool stats = p.stat_part != nullptr, masked = p.stat_mask_y != nullptr;
+    const bool stats = p.stat_part != nullptr, masked = RMW && p.stat_mask_y != nullptr;
+    const bool accumulate = RMW && p.accumulate;
     const int tiles = p.tiles_x * p.tiles_y;
     const int first = blockIdx.x * p.items_per_wg;
     const int last = min(first + p.items_per_wg, p.items);
@@ -298,7 +303,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
         const int gy = ty0 + erow, gx = tx0 + ecol;
         const bool ok = gy < p.h && gx < p.w;  // the 8-pixel group is inside or outside as a whole (w % 8 == 0)
         const size_t po = ok ? (size_t)gy * p.w + gx : 0;
-        if (p.accumulate) {
+        if (accumulate) {
 #pragma unroll
             for (int cb = 0; cb < NCO; ++cb)
 #pragma unroll
@@ -358,7 +363,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
                 const lf::f32x4 a0 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg);
                 const lf::f32x4 a1 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg + 4);
                 float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                if (p.accumulate)
+                if (accumulate)
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         v[e] += up(rold[cb][j][e / 2] & 0xffffu);
@@ -456,20 +461,26 @@ SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
     return pl;
 }
 
-template <int TAPS, int CI, int NCO, int TW, int TH, bool XBF>
-int launch_s(const lf::ConvBf16TrainArgs& a, int wgs, hipStream_t s) {
+template <int TAPS, int CI, int NCO, int TW, int TH, bool XBF, bool RMW>
+int launch_s2(const lf::ConvBf16TrainArgs& a, int wgs, hipStream_t s) {
     using S = SShape<TAPS, CI, NCO, TW, TH>;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s_kernel<TAPS, CI, NCO, TW, TH, XBF>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s_kernel<TAPS, CI, NCO, TW, TH, XBF, RMW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess) {
             lf::set_error("lf_conv2d_bf16_train: cannot reserve %d bytes of LDS", S::LDS);
             return LF_ERR_LAUNCH;
         }
         raised = true;
     }
-    conv_bf16s_kernel<TAPS, CI, NCO, TW, TH, XBF><<<wgs, kT, S::LDS, s>>>(a);
+    conv_bf16s_kernel<TAPS, CI, NCO, TW, TH, XBF, RMW><<<wgs, kT, S::LDS, s>>>(a);
     return LF_OK;
+}
+
+template <int TAPS, int CI, int NCO, int TW, int TH, bool XBF>
+int launch_s(const lf::ConvBf16TrainArgs& a, int wgs, hipStream_t s) {
+    return (a.accumulate || a.stat_mask_y != nullptr) ? launch_s2<TAPS, CI, NCO, TW, TH, XBF, true>(a, wgs, s)
+                                                      : launch_s2<TAPS, CI, NCO, TW, TH, XBF, false>(a, wgs, s);
 }
 
 template <int TW, int TH>
