@@ -177,6 +177,20 @@ int lf_jpeg_fdct_quant_u8(const uint8_t* rgb, int16_t* coef, int n, int h, int w
 void lf_jpeg_quant_tables(int quality, uint8_t* lum64, uint8_t* chroma64);
 size_t lf_jpeg_file_bound(int h, int w);
 long lf_jpeg_write_file(const int16_t* coef, int h, int w, int quality, uint8_t* out, size_t cap);
+/* Decoding, the same split the other way round (Image.open(path).convert("RGB"), image_utils.py:19-33 — the
+ * balancer's input step and the loader's):
+ * lf_jpeg_read_file (HOST, also in libleafcodec.so): markers + Huffman decoding of a baseline 4:2:0 file of
+ *   whole MCUs -> coef (the layout above, still quantised; coef_cap in int16 elements) and qtab128 (the file's
+ *   luminance and chrominance tables, 64 uint16 each, row-major).  Returns 0; 1 when the file is of a kind it
+ *   does not cover (progressive, other samplings, grey, ragged size: decode with libjpeg); -1 when it is corrupt.
+ * lf_jpeg_idct_rgb_u8 (GPU): dequantisation + jidctint islow IDCT + h2v2 fancy upsampling + YCbCr->RGB for N
+ *   images of one size; image i's coefficients at coef + i*coef_stride bytes, its tables at qtab + i*qtab_stride. */
+int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef, size_t coef_cap, uint16_t* qtab128,
+                      int* h, int* w);
+size_t lf_jpeg_decode_workspace(int n, int h, int w);
+int lf_jpeg_idct_rgb_u8(const void* coef, size_t coef_stride, const void* qtab, size_t qtab_stride,
+                        uint8_t* rgb, int n, int h, int w, void* workspace, size_t ws_bytes,
+                        lf_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Geometric ops (Pillow semantics, bit-exact; coordinates in IEEE double)    */

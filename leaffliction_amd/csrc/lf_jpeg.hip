@@ -146,9 +146,215 @@ __global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------
+// Decoding: the pixel half of Image.open(path).convert("RGB") — jidctint.c jpeg_idct_islow with the
+// dequantisation folded in, jdsample.c h2v2_fancy_upsample (the default triangle filter), jdcolor.c
+// ycc_rgb_convert.  The Huffman decoding that comes before it is the host's (lf_jpeg_read_file).
+// ---------------------------------------------------------------------------
+// one 1-D pass of jpeg_idct_islow over m[0..7]
+template <int SHIFT>
+__device__ __forceinline__ void idct8(int* m) {
+    int z2 = m[2], z3 = m[6];
+    int z1 = (z2 + z3) * LF_FIX(0.541196100);
+    const int tmp2 = z1 + z3 * (-LF_FIX(1.847759065));
+    const int tmp3 = z1 + z2 * LF_FIX(0.765366865);
+    z2 = m[0];
+    z3 = m[4];
+    const int tmp0 = (z2 + z3) << kCB, tmp1 = (z2 - z3) << kCB;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    int t0 = m[7], t1 = m[5], t2 = m[3], t3 = m[1];
+    z1 = t0 + t3;
+    z2 = t1 + t2;
+    z3 = t0 + t2;
+    int z4 = t1 + t3;
+    const int z5 = (z3 + z4) * LF_FIX(1.175875602);
+    t0 *= LF_FIX(0.298631336);
+    t1 *= LF_FIX(2.053119869);
+    t2 *= LF_FIX(3.072711026);
+    t3 *= LF_FIX(1.501321110);
+    z1 *= -LF_FIX(0.899976223);
+    z2 *= -LF_FIX(2.562915447);
+    z3 = z3 * (-LF_FIX(1.961570560)) + z5;
+    z4 = z4 * (-LF_FIX(0.390180644)) + z5;
+    t0 += z1 + z3;
+    t1 += z2 + z4;
+    t2 += z2 + z3;
+    t3 += z1 + z4;
+    m[0] = descale(tmp10 + t3, SHIFT);
+    m[7] = descale(tmp10 - t3, SHIFT);
+    m[1] = descale(tmp11 + t2, SHIFT);
+    m[6] = descale(tmp11 - t2, SHIFT);
+    m[2] = descale(tmp12 + t1, SHIFT);
+    m[5] = descale(tmp12 - t1, SHIFT);
+    m[3] = descale(tmp13 + t0, SHIFT);
+    m[4] = descale(tmp13 - t0, SHIFT);
+}
+
+struct ZigPos {
+    uint8_t pos[64];   // row-major index -> zigzag position
+};
+
+// coefficients (zigzag, quantised) of four MCUs at a time -> Y plane and the two half-size chroma planes
+__global__ __launch_bounds__(kT) void jpeg_idct_kernel(const uint8_t* __restrict__ coef, size_t coef_stride,
+                                                       const uint8_t* __restrict__ qtab, size_t qtab_stride,
+                                                       uint8_t* __restrict__ yp, uint8_t* __restrict__ cbp,
+                                                       uint8_t* __restrict__ crp, int h, int w, int n_images, ZigPos zp) {
+    __shared__ __attribute__((aligned(16))) int16_t cin[6 * kGroup][64];
+    __shared__ int mid[6 * kGroup][64];
+    __shared__ uint16_t sq[2][64];
+    __shared__ uint8_t spos[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) spos[tid] = zp.pos[tid];
+    const int mcu_w = w / 16, mcu_h = h / 16, gw = (mcu_w + kGroup - 1) / kGroup;
+    const long groups = (long)n_images * mcu_h * gw;
+    long cur_img = -1;
+    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int gx = (int)(g % gw);
+        const long t1 = g / gw;
+        const int my = (int)(t1 % mcu_h);
+        const long n = t1 / mcu_h;
+        const int mx0 = gx * kGroup, nm = min(kGroup, mcu_w - mx0);
+        __syncthreads();
+        if (n != cur_img) {   // this image's two tables
+            if (tid < 128) sq[tid >> 6][tid & 63] = reinterpret_cast<const uint16_t*>(qtab + (size_t)n * qtab_stride)[tid];
+            cur_img = n;
+        }
+        const int blk = tid >> 3, k8 = tid & 7, mi = blk / 6, b = blk - 6 * mi;
+        const bool work = blk < 6 * nm;
+        if (work) {
+            const int16_t* src = reinterpret_cast<const int16_t*>(coef + (size_t)n * coef_stride) +
+                                 ((size_t)my * mcu_w + mx0) * (6 * 64);
+            reinterpret_cast<lf::u32x4*>(&cin[0][0])[tid] = reinterpret_cast<const lf::u32x4*>(src)[tid];
+        }
+        __syncthreads();
+        if (work) {   // column pass: column k8 of block blk
+            int d[8];
+            const uint16_t* q = sq[b < 4 ? 0 : 1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = (int)cin[blk][spos[8 * k + k8]] * (int)q[8 * k + k8];
+            idct8<kCB - kP1>(d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mid[blk][8 * k + k8] = d[k];
+        }
+        __syncthreads();
+        if (work) {   // row pass: row k8 of block blk -> eight samples
+            int d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = mid[blk][8 * k8 + k];
+            idct8<kCB + kP1 + 3>(d);
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lo |= (unsigned)min(max(d[k] + 128, 0), 255) << (8 * k);
+                hi |= (unsigned)min(max(d[k + 4] + 128, 0), 255) << (8 * k);
+            }
+            uint8_t* dst;
+            if (b < 4)
+                dst = yp + ((size_t)n * h + 16 * my + 8 * (b >> 1) + k8) * w + 16 * (mx0 + mi) + 8 * (b & 1);
+            else
+                dst = (b == 4 ? cbp : crp) + ((size_t)n * (h / 2) + 8 * my + k8) * (w / 2) + 8 * (mx0 + mi);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+        }
+    }
+}
+
+// one thread: four chroma samples of a row -> 2 x 8 output pixels (h2v2_fancy_upsample + ycc_rgb_convert)
+__global__ __launch_bounds__(kT) void jpeg_upsample_rgb_kernel(const uint8_t* __restrict__ yp,
+                                                               const uint8_t* __restrict__ cbp,
+                                                               const uint8_t* __restrict__ crp,
+                                                               uint8_t* __restrict__ rgb, int h, int w, size_t total) {
+    const int cw = w / 2, ch = h / 2, qw = cw / 4;
+    for (size_t t = (size_t)blockIdx.x * kT + threadIdx.x; t < total; t += (size_t)gridDim.x * kT) {
+        const int jq = (int)(t % qw);
+        const size_t r = t / qw;
+        const int i = (int)(r % ch);
+        const size_t n = r / ch;
+        const int j0 = 4 * jq;
+        const uint8_t* planes[2] = {cbp + n * (size_t)ch * cw, crp + n * (size_t)ch * cw};
+        int up[2][2][8];   // [plane][output row v][output column]
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const uint8_t* c0 = planes[pl] + (size_t)i * cw;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int inb = v == 0 ? max(i - 1, 0) : min(i + 1, ch - 1);
+                const uint8_t* c1 = planes[pl] + (size_t)inb * cw;
+                int cs[6];   // column sums of columns j0-1 .. j0+4 (the image's own edge stands in outside)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int j = min(max(j0 - 1 + k, 0), cw - 1);
+                    cs[k] = 3 * (int)c0[j] + (int)c1[j];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    up[pl][v][2 * k] = (3 * cs[k + 1] + cs[k] + 8) >> 4;
+                    up[pl][v][2 * k + 1] = (3 * cs[k + 1] + cs[k + 2] + 7) >> 4;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const size_t row = n * (size_t)h + 2 * i + v;
+            const uint2 yy = *reinterpret_cast<const uint2*>(yp + row * w + 8 * jq);
+            unsigned o[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int y = (int)(((k < 4 ? yy.x : yy.y) >> (8 * (k & 3))) & 255u);
+                const int xb = up[0][v][k] - 128, xr = up[1][v][k] - 128;
+                const int rr = min(max(y + ((91881 * xr + 32768) >> 16), 0), 255);
+                const int bb = min(max(y + ((116130 * xb + 32768) >> 16), 0), 255);
+                const int gg = min(max(y + ((-22554 * xb + 32768 - 46802 * xr) >> 16), 0), 255);
+                o[(3 * k) >> 2] |= (unsigned)rr << (8 * ((3 * k) & 3));
+                o[(3 * k + 1) >> 2] |= (unsigned)gg << (8 * ((3 * k + 1) & 3));
+                o[(3 * k + 2) >> 2] |= (unsigned)bb << (8 * ((3 * k + 2) & 3));
+            }
+            unsigned* dst = reinterpret_cast<unsigned*>(rgb + (row * w + 8 * jq) * 3);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dst[k] = o[k];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t lf_jpeg_decode_workspace(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    const size_t px = (size_t)n * h * w;
+    return ((px + 255) & ~(size_t)255) + 2 * ((px / 4 + 255) & ~(size_t)255);
+}
+
+int lf_jpeg_idct_rgb_u8(const void* coef, size_t coef_stride, const void* qtab, size_t qtab_stride, uint8_t* rgb,
+                        int n, int h, int w, void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(coef && qtab && rgb && workspace, "lf_jpeg_idct_rgb: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_jpeg_idct_rgb: bad dims n=%d h=%d w=%d", n, h, w);
+    LF_REQUIRE(h % 16 == 0 && w % 16 == 0, "lf_jpeg_idct_rgb: whole 16x16 MCUs only (%d x %d)", h, w);
+    LF_REQUIRE(coef_stride >= (size_t)h * w * 3 && coef_stride % 16 == 0 && (reinterpret_cast<size_t>(coef) & 15) == 0,
+               "lf_jpeg_idct_rgb: coefficients must be 16-byte aligned, stride a multiple of 16 and >= 3*h*w bytes");
+    LF_REQUIRE(qtab_stride >= 256 && qtab_stride % 2 == 0 && (reinterpret_cast<size_t>(qtab) & 1) == 0,
+               "lf_jpeg_idct_rgb: tables are 128 uint16 per image");
+    LF_REQUIRE((reinterpret_cast<size_t>(rgb) & 3) == 0, "lf_jpeg_idct_rgb: rgb must be 4-byte aligned");
+    LF_REQUIRE(ws_bytes >= lf_jpeg_decode_workspace(n, h, w) && (reinterpret_cast<size_t>(workspace) & 15) == 0,
+               "lf_jpeg_idct_rgb: workspace too small or misaligned");
+    static const uint8_t natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                        41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                        30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    ZigPos zp;
+    for (int i = 0; i < 64; ++i) zp.pos[natural[i]] = (uint8_t)i;
+    const size_t px = (size_t)n * h * w;
+    uint8_t* yp = static_cast<uint8_t*>(workspace);
+    uint8_t* cbp = yp + ((px + 255) & ~(size_t)255);
+    uint8_t* crp = cbp + ((px / 4 + 255) & ~(size_t)255);
+    hipStream_t s = lf::as_stream(stream);
+    const long groups = (long)n * (h / 16) * ((w / 16 + kGroup - 1) / kGroup);
+    const unsigned grid = (unsigned)(groups < 256 * 16 ? groups : 256 * 16);
+    jpeg_idct_kernel<<<grid, kT, 0, s>>>(static_cast<const uint8_t*>(coef), coef_stride, static_cast<const uint8_t*>(qtab),
+                                         qtab_stride, yp, cbp, crp, h, w, n, zp);
+    const size_t total = (size_t)n * (h / 2) * (w / 8);
+    jpeg_upsample_rgb_kernel<<<lf::stream_grid(total, kT, 256 * 32), kT, 0, s>>>(yp, cbp, crp, rgb, h, w, total);
+    return lf::check_launch("lf_jpeg_idct_rgb");
+}
 
 int lf_jpeg_fdct_quant_u8(const uint8_t* rgb, int16_t* coef, int n, int h, int w, int quality,
                           lf_stream_t stream) {

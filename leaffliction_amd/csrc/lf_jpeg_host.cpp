@@ -14,6 +14,7 @@ extern "C" {
 void lf_jpeg_quant_tables(int quality, uint8_t* lum64, uint8_t* chroma64);
 size_t lf_jpeg_file_bound(int h, int w);
 long lf_jpeg_write_file(const int16_t* coef, int h, int w, int quality, uint8_t* out, size_t cap);
+int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef, size_t coef_cap, uint16_t* qtab128, int* h, int* w);
 }
 
 namespace {
@@ -260,3 +261,267 @@ long lf_jpeg_write_file(const int16_t* coef, int h, int w, int quality, uint8_t*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Reading: markers + Huffman decoding of a baseline 4:2:0 file into the same coefficient layout the encoder
+// uses ([MCU][Y00 Y01 Y10 Y11 Cb Cr][64], zigzag order, still quantised) plus the file's two quantisation
+// tables; dequantisation, IDCT, upsampling and colour conversion are lf_jpeg_idct_rgb_u8's (GPU).
+// Everything this does not cover (progressive, other samplings, 12-bit, sizes that are not whole MCUs,
+// arithmetic coding) returns 1 and the caller decodes with libjpeg as before.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct DHuff {
+    bool present = false;
+    uint8_t look_len[1 << 12], look_sym[1 << 12];   // 12-bit lookahead: at quality 95 most AC codes are 10-16 bits long
+    int maxcode[18], valptr[17];
+    uint8_t vals[256];
+};
+
+bool build_decoder(DHuff& t, const uint8_t* bits, const uint8_t* vals, int nvals) {
+    memset(t.look_len, 0, sizeof(t.look_len));
+    memcpy(t.vals, vals, (size_t)nvals);
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        t.valptr[l] = k;
+        for (int i = 0; i < bits[l - 1]; ++i, ++k, ++code) {
+            if (k >= nvals || code >= (1 << l)) return false;
+            if (l <= 12) {
+                const int first = code << (12 - l);
+                for (int f = 0; f < (1 << (12 - l)); ++f) {
+                    t.look_len[first + f] = (uint8_t)l;
+                    t.look_sym[first + f] = vals[k];
+                }
+            }
+        }
+        t.maxcode[l] = bits[l - 1] ? code - 1 : -1;
+        code <<= 1;
+    }
+    t.maxcode[17] = 0x7fffffff;
+    // mincode folded into valptr: symbol index = valptr[l] + code - mincode[l]
+    code = 0;
+    k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        t.valptr[l] = k - code;   // so that index = valptr[l] + code
+        k += bits[l - 1];
+        code = (code + bits[l - 1]) << 1;
+    }
+    t.present = true;
+    return true;
+}
+
+struct Reader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t buf = 0;
+    int n = 0;
+    bool marker = false;   // ran into a marker: zeros are fed from here on
+    void fill() {
+        if (!marker && p + 8 <= end && n <= 56) {   // fast path: no 0xFF among the next eight bytes
+            uint64_t v;
+            memcpy(&v, p, 8);
+            v = __builtin_bswap64(v);
+            if (!(v & 0x8080808080808080ull & ~(v + 0x0101010101010101ull))) {
+                const int take = (64 - n) >> 3;   // whole bytes that fit: 1..8
+                const uint64_t kept = take == 8 ? v : v & ~(~0ull >> (8 * take));
+                buf |= kept >> n;
+                p += take;
+                n += 8 * take;
+                return;
+            }
+        }
+        while (n <= 56) {
+            unsigned b = 0;
+            if (!marker && p < end) {
+                b = *p;
+                if (b == 0xFF) {
+                    if (p + 1 < end && p[1] == 0x00) {
+                        p += 2;
+                    } else {
+                        marker = true;
+                        b = 0;
+                    }
+                } else {
+                    ++p;
+                }
+            }
+            buf |= (uint64_t)b << (56 - n);
+            n += 8;
+        }
+    }
+    unsigned peek(int k) { return (unsigned)(buf >> (64 - k)); }
+    void skip(int k) {
+        buf <<= k;
+        n -= k;
+    }
+    void reset() {
+        buf = 0;
+        n = 0;
+        marker = false;
+    }
+};
+
+inline int decode_symbol(Reader& r, const DHuff& t) {   // the caller keeps >= 32 bits in the buffer
+    const unsigned look = r.peek(12);
+    int l = t.look_len[look];
+    if (l) {
+        r.skip(l);
+        return t.look_sym[look];
+    }
+    int code = (int)r.peek(13);
+    for (l = 13; l <= 16; ++l) {
+        if (code <= t.maxcode[l]) {
+            r.skip(l);
+            return t.vals[(t.valptr[l] + code) & 255];
+        }
+        code = (int)r.peek(l + 1);
+    }
+    return -1;
+}
+
+inline int receive_extend(Reader& r, int s) {
+    const int v = (int)r.peek(s);
+    r.skip(s);
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+inline bool decode_block(Reader& r, int16_t* zz, int& pred, const DHuff& dc, const DHuff& ac) {
+    memset(zz, 0, 64 * sizeof(int16_t));
+    if (r.n < 32) r.fill();   // a code (<= 16 bits) and its value bits (<= 11) per refill
+    int s = decode_symbol(r, dc);
+    if (s < 0 || s > 11) return false;
+    if (s) pred += receive_extend(r, s);
+    zz[0] = (int16_t)pred;
+    for (int k = 1; k < 64;) {
+        if (r.n < 32) r.fill();
+        const int rs = decode_symbol(r, ac);
+        if (rs < 0) return false;
+        const int run = rs >> 4, size = rs & 15;
+        if (size == 0) {
+            if (run != 15) break;   // EOB
+            k += 16;
+            continue;
+        }
+        k += run;
+        if (k > 63) return false;
+        zz[k++] = (int16_t)receive_extend(r, size);
+    }
+    return true;
+}
+
+inline unsigned be16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
+
+}  // namespace
+
+extern "C" int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef, size_t coef_cap, uint16_t* qtab128,
+                                 int* h_out, int* w_out) {
+    if (!data || !coef || !qtab128 || !h_out || !w_out || len < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
+    uint16_t qt[4][64];
+    bool have_q[4] = {false, false, false, false};
+    DHuff dc[4], ac[4];
+    int h = 0, w = 0, restart = 0;
+    int comp_id[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
+    bool have_sof = false;
+    size_t pos = 2;
+    while (pos + 4 <= len) {
+        if (data[pos] != 0xFF) return -1;
+        const unsigned m = data[pos + 1];
+        if (m == 0xFF) {   // fill byte
+            ++pos;
+            continue;
+        }
+        pos += 2;
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) return -1;   // EOI before any scan
+        if (pos + 2 > len) return -1;
+        const size_t seg = be16(data + pos);
+        if (seg < 2 || pos + seg > len) return -1;
+        const uint8_t* q = data + pos + 2;
+        const size_t n = seg - 2;
+        if (m == 0xDB) {
+            size_t i = 0;
+            while (i < n) {
+                const int pq = q[i] >> 4, tq = q[i] & 15;
+                if (tq > 3) return -1;
+                if (pq != 0) return 1;   // 16-bit tables: not baseline
+                if (i + 65 > n) return -1;
+                for (int k = 0; k < 64; ++k) qt[tq][kNatural[k]] = q[i + 1 + k];   // stored row-major
+                have_q[tq] = true;
+                i += 65;
+            }
+        } else if (m == 0xC4) {
+            size_t i = 0;
+            while (i < n) {
+                if (i + 17 > n) return -1;
+                const int tc = q[i] >> 4, th = q[i] & 15;
+                if (tc > 1 || th > 3) return -1;
+                int total = 0;
+                for (int k = 0; k < 16; ++k) total += q[i + 1 + k];
+                if (total > 256 || i + 17 + total > n) return -1;
+                if (!build_decoder(tc ? ac[th] : dc[th], q + i + 1, q + i + 17, total)) return -1;
+                i += 17 + total;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (n < 15 || q[0] != 8) return 1;
+            h = (int)be16(q + 1);
+            w = (int)be16(q + 3);
+            if (q[5] != 3) return 1;   // grey or CMYK: libjpeg's business
+            for (int c = 0; c < 3; ++c) {
+                comp_id[c] = q[6 + 3 * c];
+                const int hv = q[7 + 3 * c];
+                comp_q[c] = q[8 + 3 * c];
+                if (hv != (c == 0 ? 0x22 : 0x11) || comp_q[c] > 3) return 1;   // 4:2:0 only
+            }
+            if (h <= 0 || w <= 0 || h % 16 || w % 16) return 1;
+            have_sof = true;
+        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+            return 1;   // progressive, lossless, arithmetic
+        } else if (m == 0xDD) {
+            if (n < 2) return -1;
+            restart = (int)be16(q);
+        } else if (m == 0xDA) {
+            if (!have_sof || n < 10 || q[0] != 3) return have_sof ? 1 : -1;
+            int td[3], ta[3];
+            for (int c = 0; c < 3; ++c) {
+                if (q[1 + 2 * c] != comp_id[c]) return 1;   // components in another order
+                td[c] = q[2 + 2 * c] >> 4;
+                ta[c] = q[2 + 2 * c] & 15;
+                if (td[c] > 3 || ta[c] > 3 || !dc[td[c]].present || !ac[ta[c]].present || !have_q[comp_q[c]]) return -1;
+            }
+            if (q[7] != 0 || q[8] != 63) return 1;
+            const long mcus = (long)(h / 16) * (w / 16);
+            if ((size_t)mcus * 384 > coef_cap) return -1;
+            for (int k = 0; k < 64; ++k) {
+                qtab128[k] = qt[comp_q[0]][k];
+                qtab128[64 + k] = qt[comp_q[1]][k];
+                if (qt[comp_q[2]][k] != qt[comp_q[1]][k]) return 1;   // Cb and Cr with different tables
+            }
+            Reader r{data + pos + seg, data + len};
+            int pred[3] = {0, 0, 0};
+            int until_restart = restart;
+            for (long mcu = 0; mcu < mcus; ++mcu) {
+                if (restart && until_restart == 0) {
+                    // byte-align, expect RSTn
+                    const uint8_t* mp = r.p;
+                    while (mp + 1 < r.end && mp < r.p + 8 && !(mp[0] == 0xFF && mp[1] >= 0xD0 && mp[1] <= 0xD7)) ++mp;
+                    if (!(mp + 1 < r.end && mp[0] == 0xFF && mp[1] >= 0xD0 && mp[1] <= 0xD7)) return -1;
+                    r.p = mp + 2;
+                    r.reset();
+                    pred[0] = pred[1] = pred[2] = 0;
+                    until_restart = restart;
+                }
+                int16_t* b = coef + mcu * 384;
+                for (int k = 0; k < 4; ++k)
+                    if (!decode_block(r, b + 64 * k, pred[0], dc[td[0]], ac[ta[0]])) return -1;
+                if (!decode_block(r, b + 256, pred[1], dc[td[1]], ac[ta[1]])) return -1;
+                if (!decode_block(r, b + 320, pred[2], dc[td[2]], ac[ta[2]])) return -1;
+                if (restart) --until_restart;
+            }
+            *h_out = h;
+            *w_out = w;
+            return 0;
+        }
+        pos += seg;
+    }
+    return -1;
+}

@@ -285,6 +285,24 @@ def jpeg_fdct_quant_u8(x: torch.Tensor, quality: int = 95, out: Optional[torch.T
     return out.view(shape)
 
 
+def jpeg_idct_rgb_u8(slots: torch.Tensor, h: int, w: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The pixel half of Image.open(path).convert("RGB") (image_utils.py:19-33) for N images of one size whose
+    files utils.jpeg_host.read_file_into has Huffman-decoded: `slots` uint8 [N, slot_bytes], each row = the
+    file's two quantisation tables (256 bytes) then its quantised coefficients (3*h*w bytes).  Returns RGB
+    [N, h, w, 3] uint8 — Pillow's pixels, bit for bit."""
+    _chk(slots, _U8, "jpeg_idct_rgb.slots", 2)
+    n, stride = slots.shape
+    if h % 16 or w % 16 or stride < 256 + 3 * h * w or stride % 16 or slots.stride(0) != stride:
+        raise ValueError(f"jpeg_idct_rgb: {h}x{w} images need contiguous rows of >= {256 + 3 * h * w} bytes (multiple of 16)")
+    if out is None:
+        out = torch.empty((n, h, w, 3), dtype=_U8, device=slots.device)
+    nbytes = int(_lib.load().lf_jpeg_decode_workspace(n, h, w))
+    ws = torch.empty(nbytes, dtype=_U8, device=slots.device)
+    _lib.call("lf_jpeg_idct_rgb_u8", slots.data_ptr() + 256, stride, slots.data_ptr(), stride, out.data_ptr(),
+              n, h, w, ws.data_ptr(), nbytes, _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------
 # geometric ops (Pillow semantics)
 # ---------------------------------------------------------------------------

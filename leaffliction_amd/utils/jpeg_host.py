@@ -25,6 +25,9 @@ def load() -> C.CDLL:
         lib.lf_jpeg_file_bound.restype = C.c_size_t
         lib.lf_jpeg_write_file.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         lib.lf_jpeg_write_file.restype = C.c_long
+        lib.lf_jpeg_read_file.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.lf_jpeg_read_file.restype = C.c_int
         _LIB = lib
     return _LIB
 
@@ -46,3 +49,34 @@ def write_file(coef: np.ndarray, h: int, w: int, quality: int = 95) -> bytes:
     if n < 0:
         raise RuntimeError("lf_jpeg_write_file failed")
     return _SCRATCH[:n].tobytes()
+
+
+QTAB_BYTES = 256   # two tables of 64 uint16 (luminance, chrominance), row-major
+
+
+def read_file_into(data: bytes, dst: np.ndarray):
+    """Parse + Huffman-decode a baseline 4:2:0 JPEG into `dst` (uint8 view of a slab slot): the two
+    quantisation tables (256 bytes) followed by the quantised coefficients [MCUs, 6, 64] int16 in zigzag order.
+    Returns (h, w), or None when the file is not of that kind (the caller decodes it with libjpeg) or does not fit."""
+    lib = load()
+    if dst.dtype != np.uint8 or not dst.flags["C_CONTIGUOUS"] or dst.size < QTAB_BYTES + 768:
+        return None
+    h, w = C.c_int(0), C.c_int(0)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    base = dst.ctypes.data
+    rc = lib.lf_jpeg_read_file(buf.ctypes.data, buf.size, base + QTAB_BYTES, (dst.size - QTAB_BYTES) // 2, base,
+                               C.byref(h), C.byref(w))
+    return (h.value, w.value) if rc == 0 else None
+
+
+def read_file(data: bytes):
+    """(coef int16 [MCUs, 6, 64], qtab uint16 [2, 64], h, w) or None — convenience form of read_file_into."""
+    slot = np.zeros(QTAB_BYTES + 3 * 4096 * 4096 // 16, dtype=np.uint8) if len(data) > (1 << 22) else \
+        np.zeros(QTAB_BYTES + 3 * 1024 * 1024, dtype=np.uint8)
+    hw = read_file_into(data, slot)
+    if hw is None:
+        return None
+    h, w = hw
+    n = (h // 16) * (w // 16)
+    coef = slot[QTAB_BYTES:QTAB_BYTES + n * 768].view(np.int16).reshape(n, 6, 64).copy()
+    return coef, slot[:QTAB_BYTES].view(np.uint16).reshape(2, 64).copy(), h, w

@@ -254,3 +254,85 @@ def encode(rgb: np.ndarray, quality: int = 95) -> bytes:
     h, w, _ = rgb.shape
     y, cb, cr = quantised_coefficients(rgb, quality)
     return headers(h, w, quality) + entropy_code(y, cb, cr) + b"\xff\xd9"
+
+
+# ---------------------------------------------------------------------------
+# Decoder side (libjpeg(-turbo) as Pillow drives it for Image.open(path).convert("RGB")): jidctint.c
+# jpeg_idct_islow with the dequantisation folded in, jdsample.c h2v2_fancy_upsample (triangle filter, the
+# default do_fancy_upsampling), jdcolor.c ycc_rgb_convert.  PINNED: tests compare with Pillow's decoded pixels.
+# ---------------------------------------------------------------------------
+def idct_islow(coef_rowmajor: np.ndarray, q_rowmajor: np.ndarray) -> np.ndarray:
+    """One 8x8 block: quantised coefficients (row-major int) x quantisation table -> samples 0..255."""
+    CB, P1 = 13, 2
+    F = {k: int(v * (1 << CB) + 0.5) for k, v in dict(
+        a=0.298631336, b=0.390180644, c=0.541196100, d=0.765366865, e=0.899976223, f=1.175875602, g=1.501321110,
+        h=1.847759065, i=1.961570560, j=2.053119869, k=2.562915447, l=3.072711026).items()}
+    d = (coef_rowmajor.astype(np.int64) * q_rowmajor.astype(np.int64)).reshape(8, 8)
+
+    def one_pass(m, shift):   # 1-D IDCT along axis 0 of each column of m: m[k, col]
+        z2, z3 = m[2], m[6]
+        z1 = (z2 + z3) * F["c"]
+        tmp2 = z1 + z3 * (-F["h"])
+        tmp3 = z1 + z2 * F["d"]
+        z2, z3 = m[0], m[4]
+        tmp0 = (z2 + z3) << CB
+        tmp1 = (z2 - z3) << CB
+        tmp10, tmp13, tmp11, tmp12 = tmp0 + tmp3, tmp0 - tmp3, tmp1 + tmp2, tmp1 - tmp2
+        t0, t1, t2, t3 = m[7], m[5], m[3], m[1]
+        z1, z2, z3, z4 = t0 + t3, t1 + t2, t0 + t2, t1 + t3
+        z5 = (z3 + z4) * F["f"]
+        t0, t1, t2, t3 = t0 * F["a"], t1 * F["j"], t2 * F["l"], t3 * F["g"]
+        z1, z2 = z1 * (-F["e"]), z2 * (-F["k"])
+        z3, z4 = z3 * (-F["i"]) + z5, z4 * (-F["b"]) + z5
+        t0, t1, t2, t3 = t0 + z1 + z3, t1 + z2 + z4, t2 + z2 + z3, t3 + z1 + z4
+        half = 1 << (shift - 1)
+        out = [tmp10 + t3, tmp11 + t2, tmp12 + t1, tmp13 + t0, tmp13 - t0, tmp12 - t1, tmp11 - t2, tmp10 - t3]
+        return np.stack([(v + half) >> shift for v in out])
+
+    ws = one_pass(d, CB - P1)                 # pass 1: columns (ws[row_out, col])
+    res = one_pass(ws.T, CB + P1 + 3).T       # pass 2: rows
+    return np.clip(res + 128, 0, 255).astype(np.uint8)
+
+
+def h2v2_fancy_upsample(p: np.ndarray) -> np.ndarray:
+    """jdsample.c h2v2_fancy_upsample: [h, w] -> [2h, 2w]; the image's first / last row and column stand in
+    for their missing neighbours."""
+    q = p.astype(np.int64)
+    h, w = q.shape
+    up = np.vstack([q[:1], q[:-1]])      # row above (row 0: itself)
+    dn = np.vstack([q[1:], q[-1:]])      # row below (last row: itself)
+    out = np.zeros((2 * h, 2 * w), dtype=np.int64)
+    for v, nb in ((0, up), (1, dn)):
+        cs = q * 3 + nb                                     # column sums, 16x scale after the horizontal step
+        last = np.hstack([cs[:, :1], cs[:, :-1]])
+        nxt = np.hstack([cs[:, 1:], cs[:, -1:]])
+        out[v::2, 0::2] = (cs * 3 + last + 8) >> 4
+        out[v::2, 1::2] = (cs * 3 + nxt + 7) >> 4
+    return out.astype(np.uint8)
+
+
+def ycc_to_rgb(y: np.ndarray, cb: np.ndarray, cr: np.ndarray) -> np.ndarray:
+    """jdcolor.c ycc_rgb_convert (SCALEBITS 16)."""
+    half = 1 << 15
+    yy, xb, xr = y.astype(np.int64), cb.astype(np.int64) - 128, cr.astype(np.int64) - 128
+    r = yy + ((_fix(1.40200) * xr + half) >> 16)
+    b = yy + ((_fix(1.77200) * xb + half) >> 16)
+    g = yy + ((-_fix(0.34414) * xb + half - _fix(0.71414) * xr) >> 16)
+    return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
+
+
+def decode_coefficients(y, cb, cr, quality: int = 95) -> np.ndarray:
+    """Zigzag-ordered quantised coefficients (as quantised_coefficients returns them) -> RGB [H, W, 3]."""
+    ql, qc = quant_tables(quality)
+    inv = np.argsort(ZIGZAG)   # row-major index -> zigzag position
+
+    def plane(co, q):
+        by, bx = co.shape[:2]
+        out = np.zeros((by * 8, bx * 8), dtype=np.uint8)
+        for i in range(by):
+            for j in range(bx):
+                out[8 * i:8 * i + 8, 8 * j:8 * j + 8] = idct_islow(co[i, j][inv], q)
+        return out
+
+    yp = plane(y, ql)
+    return ycc_to_rgb(yp, h2v2_fancy_upsample(plane(cb, qc)), h2v2_fancy_upsample(plane(cr, qc)))

@@ -104,3 +104,64 @@ def test_gpu_other_quality_and_bad_shape(cuda):
     assert jpeg_host.write_file(coef[0], 64, 80, 80) == pil_bytes(a, 80)
     with pytest.raises(ValueError):
         ops.jpeg_fdct_quant_u8(torch.zeros((1, 30, 32, 3), dtype=torch.uint8, device=cuda))
+
+
+# ---- reading -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,h,w,seed", CASES)
+def test_oracle_decoder_stages_give_pillows_pixels(kind, h, w, seed):
+    a = make(kind, h, w, seed)
+    want = np.asarray(Image.open(io.BytesIO(pil_bytes(a))).convert("RGB"))
+    assert np.array_equal(J.decode_coefficients(*J.quantised_coefficients(a)), want)
+
+
+def _save(a, **kw):
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, format="JPEG", **kw)
+    return b.getvalue()
+
+
+@pytest.mark.parametrize("kw", [dict(quality=95), dict(quality=60), dict(quality=95, optimize=True),
+                                dict(quality=85, restart_marker_rows=1), dict(quality=90, restart_marker_blocks=3)])
+def test_host_reader_recovers_the_coefficients(kw):
+    """Files written by Pillow itself (standard and optimised Huffman tables, restart markers): the reader's
+    coefficients and tables are the encoder's."""
+    from leaffliction_amd.utils import jpeg_host
+    a = scene(64, 96, 11)
+    got = jpeg_host.read_file(_save(a, **kw))
+    assert got is not None
+    coef, qtab, h, w = got
+    q = kw["quality"]
+    assert (h, w) == (64, 96)
+    assert np.array_equal(coef, mcu_order(*J.quantised_coefficients(a, q)))
+    ql, qc = J.quant_tables(q)
+    assert np.array_equal(qtab[0], ql) and np.array_equal(qtab[1], qc)
+
+
+def test_host_reader_declines_what_it_does_not_cover():
+    from leaffliction_amd.utils import jpeg_host
+    a = scene(64, 64, 12)
+    assert jpeg_host.read_file(_save(a, quality=90, subsampling=0)) is None          # 4:4:4
+    assert jpeg_host.read_file(_save(a, quality=90, progressive=True)) is None
+    assert jpeg_host.read_file(_save(a[..., 0], quality=90)) is None                   # greyscale
+    assert jpeg_host.read_file(_save(a[:50, :60], quality=90)) is None                # not whole MCUs
+    assert jpeg_host.read_file(b"not a jpeg at all") is None
+    assert jpeg_host.read_file(_save(a, quality=90)[:400]) is None                     # truncated
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,kw", [(224, 224, dict(quality=95)), (64, 96, dict(quality=70, optimize=True)),
+                                    (48, 208, dict(quality=85, restart_marker_rows=1)), (16, 16, dict(quality=95)),
+                                    (256, 256, dict(quality=88))])
+def test_gpu_decode_gives_pillows_pixels(cuda, h, w, kw):
+    """file -> host Huffman decoding -> GPU IDCT / upsampling / colour == Image.open(file).convert("RGB")."""
+    import torch
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    files = [_save(make("scene" if i else "noise", h, w, 20 + i), **kw) for i in range(3)]
+    stride = (256 + 3 * h * w + 4095) // 4096 * 4096
+    slots = np.zeros((3, stride), np.uint8)
+    for i, f in enumerate(files):
+        assert jpeg_host.read_file_into(f, slots[i]) == (h, w)
+    got = ops.jpeg_idct_rgb_u8(torch.from_numpy(slots).to(cuda), h, w).cpu().numpy()
+    for i, f in enumerate(files):
+        assert np.array_equal(got[i], np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))), i
