@@ -8,7 +8,9 @@ threads cannot feed that: 16 threads reached 1.8 k images/s on a box whose 16 co
 reference's own process pool at 10.8 k images/s.  So the codec work goes to processes as well, and
 pixels cross the process boundary through shared memory, never through pickles:
 
-  decode worker: JPEG -> RGB uint8 written straight into the task's slot of the INPUT slab; the
+  decode worker: JPEG -> RGB uint8 written straight into the task's slot of the INPUT slab — or, for a
+      baseline 4:2:0 file of whole MCUs when the GPU path is on, only its Huffman decoding: quantisation tables
+      + coefficients into the slot, the IDCT / upsampling / colour conversion being the GPU's; the
       task's random parameters are drawn there too (a fresh seeded RNG per task, exactly what the
       reference's worker does), including the distortion's 150 k normal deviates, which are cast to
       uint8 by numpy itself (image_augmenter.py:121-123) into the NOISE slab;
@@ -53,18 +55,30 @@ def _warm(_i: int) -> bool:
     return True
 
 
-def _decode_jobs(names: Dict[str, str], jobs: Sequence[Tuple[str, str, int, int, int, int]]):
-    """jobs: (source path, transform, seed, input offset, noise offset, slot bytes).  Returns per job
-    ("ok", shape, params) | ("big", array, params) | ("err", message)."""
-    from ..utils.image_utils import ImageLoader
+def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
+    """jobs: (source path, transform, seed, input offset, noise offset, slot bytes[, want coefficients]).
+    Returns per job ("ok", shape, params) | ("coef", shape, params) | ("big", array, params) | ("err", message).
+    "coef": the file was a baseline 4:2:0 JPEG of whole MCUs and the slot holds its quantisation tables and
+    Huffman-decoded coefficients (libleafcodec.so); the GPU finishes the decoding (ops.jpeg_idct_rgb_u8)."""
+    from ..utils import jpeg_host
+    from ..utils.image_utils import ImageLoader, _checked
     from .image_augmenter import draw_params
     out = []
     slabs = _slabs(names)
     buf_in, buf_noise = slabs["in"].buf, slabs["noise"].buf
-    for path, op, seed, off, noff, cap in jobs:
+    for job in jobs:
+        path, op, seed, off, noff, cap = job[:6]
         try:
-            arr = ImageLoader.load_as_array(path)
-            h, w, _c = arr.shape
+            arr, coef_hw = None, None
+            if len(job) > 6 and job[6]:
+                with open(_checked(path, what="Image"), "rb") as f:   # the loader's own checks (image_utils.py:19-33)
+                    data = f.read()
+                coef_hw = jpeg_host.read_file_into(data, np.frombuffer(buf_in, np.uint8, cap, off))
+            if coef_hw is None:
+                arr = ImageLoader.load_as_array(path)
+                h, w, _c = arr.shape
+            else:
+                h, w = coef_hw
             params = None
             if seed:   # seed 0 = "unseeded" in the reference: drawn by the parent from its global streams
                 params = draw_params(op, w, h, random.Random(seed), np.random.RandomState(seed))
@@ -75,7 +89,9 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[Tuple[str, str, int, int,
                         params["noise8"] = None      # in the noise slab, at this task's slot
                     else:
                         params["noise8"] = n8
-            if arr.nbytes <= cap:
+            if arr is None:
+                out.append(("coef", (h, w, 3), params))
+            elif arr.nbytes <= cap:
                 np.frombuffer(buf_in, np.uint8, arr.nbytes, off)[:] = arr.reshape(-1)
                 out.append(("ok", arr.shape, params))
             else:
@@ -174,9 +190,9 @@ class CodecPool:
         per = max(1, -(-len(jobs) // (4 * self.workers)))
         return [jobs[i:i + per] for i in range(0, len(jobs), per)]
 
-    def decode(self, tasks: Sequence[dict], first_slot: int) -> List[Future]:
+    def decode(self, tasks: Sequence[dict], first_slot: int, coefficients: bool = False) -> List[Future]:
         jobs = [(t["source_img"], t["transform_name"], t["seed"], (first_slot + k) * self.slot_bytes,
-                 (first_slot + k) * self.slot_bytes, self.slot_bytes) for k, t in enumerate(tasks)]
+                 (first_slot + k) * self.slot_bytes, self.slot_bytes, coefficients) for k, t in enumerate(tasks)]
         return [self.pool.submit(_decode_jobs, self.names, part) for part in self._split(jobs)]
 
     def encode(self, jobs: List[Tuple[str, int, Tuple[int, int, int], Optional[np.ndarray]]]) -> List[Future]:

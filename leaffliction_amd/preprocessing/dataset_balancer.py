@@ -150,8 +150,11 @@ class DatasetBalancer:
         from .. import ops
         n = len(chunk)
         device_path = self._mirror is not None
+        t_in = time.perf_counter()
         if device_path:
             dev_in, dev_out = self._mirror
+            # whole slots in one contiguous copy each way: a strided (used-bytes-only) copy between the page-locked
+            # slab and the device goes through a pageable temporary in torch and measured 8x slower
             dev_in[:n].copy_(pool.tensor("in", base, n), non_blocking=True)
         groups: Dict[tuple, List[int]] = {}
         images: List[Optional[np.ndarray]] = [None] * n
@@ -161,21 +164,28 @@ class DatasetBalancer:
                 logger.error(f"Failed to process {payload}")
                 self.failed += 1
                 continue
-            img = pool.view("in", base + k, payload) if status == "ok" else payload
-            h, w, _ = img.shape
+            if status == "coef":   # pixels do not exist on the host: the GPU finishes the decoding
+                img = None
+                h, w, _ = payload
+            else:
+                img = pool.view("in", base + k, payload) if status == "ok" else payload
+                h, w, _ = img.shape
             if prm is None:
                 prm = draw_params(task["transform_name"], w, h)
             elif "noise8" in prm and prm["noise8"] is None:
-                prm["noise8"] = pool.view("noise", base + k, img.shape)
+                prm["noise8"] = pool.view("noise", base + k, (h, w, 3))
             images[k], params[k] = img, prm
             groups.setdefault((task["transform_name"], h, w, status), []).append(k)
         jobs: List[tuple] = []
         for (op, h, w, status), ks in groups.items():
             prm = [params[k] for k in ks]
             try:
-                if device_path and status == "ok":
+                if device_path and status in ("ok", "coef"):
                     idx = torch.tensor(ks, dtype=torch.int64, device=dev_in.device)
-                    x = dev_in[idx, :h * w * 3].view(len(ks), h, w, 3)
+                    if status == "coef":
+                        x = ops.jpeg_idct_rgb_u8(dev_in[idx], h, w)
+                    else:
+                        x = dev_in[idx, :h * w * 3].view(len(ks), h, w, 3)
                     res = apply_batch(op, x, prm)
                     if op != "rotate":
                         y = torch.stack(res)
@@ -213,8 +223,12 @@ class DatasetBalancer:
                     jobs.append((chunk[k]["output_path"], (base + k) * pool.slot_bytes, tuple(r.shape), None))
                 else:
                     jobs.append((chunk[k]["output_path"], 0, tuple(r.shape), r))
+        t_ops = time.perf_counter()
         if device_path:
             pool.tensor("out", base, n).copy_(dev_out[:n])   # synchronous: the encoders may start
+        t_out = time.perf_counter()
+        self.timings["gpu_stage_host_ops"] = self.timings.get("gpu_stage_host_ops", 0.0) + (t_ops - t_in)
+        self.timings["gpu_stage_sync_d2h"] = self.timings.get("gpu_stage_sync_d2h", 0.0) + (t_out - t_ops)
         return jobs
 
     def _collect(self, futures, paths: List[str]) -> None:
@@ -252,13 +266,14 @@ class DatasetBalancer:
                 dev = torch.device("cuda", torch.cuda.current_device())
                 self._mirror = (torch.empty((n_chunk, slot), dtype=torch.uint8, device=dev),
                                 torch.empty((n_chunk, slot), dtype=torch.uint8, device=dev))
+            gpu_decode = self._mirror is not None   # workers Huffman-decode only; IDCT .. colour on the GPU
             # chunk i + 2 is queued for decoding before chunk i goes to the GPU: the workers always have a
             # chunk's worth of work behind the one the main thread is waiting for
-            ahead = [pool.decode(chunks[0], 0)]
+            ahead = [pool.decode(chunks[0], 0, gpu_decode)]
             ahead[0][0].result()   # the workers are up (spawn + imports) once the first piece is back
             self.timings["codec_pool_start"] = time.perf_counter() - t0
             if len(chunks) > 1:
-                ahead.append(pool.decode(chunks[1], n_chunk))
+                ahead.append(pool.decode(chunks[1], n_chunk, gpu_decode))
             encoding, enc_paths = [], []
             decoded = jobs = None
             tw = {"wait_decode": 0.0, "gpu_stage": 0.0, "wait_encode": 0.0}
@@ -268,7 +283,7 @@ class DatasetBalancer:
                 ta = time.perf_counter()
                 decoded = [r for f in ahead.pop(0) for r in f.result()]
                 if i + 2 < len(chunks):
-                    ahead.append(pool.decode(chunks[i + 2], ((i + 2) % RING) * n_chunk))
+                    ahead.append(pool.decode(chunks[i + 2], ((i + 2) % RING) * n_chunk, gpu_decode))
                 tb = time.perf_counter()
                 jobs = self._gpu_stage(chunk, decoded, pool, (i % RING) * n_chunk)
                 tc = time.perf_counter()
