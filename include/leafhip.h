@@ -177,6 +177,14 @@ int lf_jpeg_fdct_quant_u8(const uint8_t* rgb, int16_t* coef, int n, int h, int w
 void lf_jpeg_quant_tables(int quality, uint8_t* lum64, uint8_t* chroma64);
 size_t lf_jpeg_file_bound(int h, int w);
 long lf_jpeg_write_file(const int16_t* coef, int h, int w, int quality, uint8_t* out, size_t cap);
+/* The entropy coding on the GPU as well: lf_jpeg_entropy_u8 turns the coefficients of N images (image i at
+ * coef + i*coef_stride bytes, the layout above) into their Huffman-coded, byte-stuffed scans: row i of `out`
+ * (out_stride bytes) = int32 length, then the bytes; length -1 when a scan does not fit its row.
+ * lf_jpeg_wrap_scan (HOST, also in libleafcodec.so) puts the markers around such a scan: the complete file. */
+size_t lf_jpeg_entropy_workspace(int n, size_t out_stride);
+int lf_jpeg_entropy_u8(const void* coef, size_t coef_stride, uint8_t* out, size_t out_stride, int n, int h,
+                       int w, void* workspace, size_t ws_bytes, lf_stream_t stream);
+long lf_jpeg_wrap_scan(const uint8_t* scan, size_t scan_len, int h, int w, int quality, uint8_t* out, size_t cap);
 /* Decoding, the same split the other way round (Image.open(path).convert("RGB"), image_utils.py:19-33 — the
  * balancer's input step and the loader's):
  * lf_jpeg_read_file (HOST, also in libleafcodec.so): markers + Huffman decoding of a baseline 4:2:0 file of

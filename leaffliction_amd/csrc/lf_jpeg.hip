@@ -315,9 +315,206 @@ __global__ __launch_bounds__(kT) void jpeg_upsample_rgb_kernel(const uint8_t* __
     }
 }
 
+// ---------------------------------------------------------------------------
+// Entropy coding on the GPU (jchuff.c with the Annex K tables): one workgroup per image.  Every thread takes
+// a contiguous run of the scan's blocks, (1) adds up their code lengths, (2) a workgroup scan turns the sums
+// into bit offsets, (3) the thread writes its run's bits MSB-first into a zeroed word array — whole words
+// with plain stores, the first and last word of a run (shared with the neighbours) with atomicOr —, (4) the
+// last byte is padded with ones, 0xFF bytes are counted, scanned, and the stream is copied out with the
+// 0x00 stuffing.  Output row: int32 length (or -1: did not fit), then the scan's bytes.
+// ---------------------------------------------------------------------------
+struct HuffTab {
+    uint32_t dc[2][16];    // (code << 8) | length
+    uint32_t ac[2][256];
+};
+
+constexpr int kEB = 256;
+
+template <bool EMIT>
+struct BitSink {
+    unsigned long long acc = 0;
+    int fill = 0;
+    size_t w = 0;
+    bool first = true;
+    unsigned total = 0;
+    uint32_t* words = nullptr;
+    __device__ __forceinline__ void put(unsigned bits, int len) {
+        if (!EMIT) {
+            total += (unsigned)len;
+            return;
+        }
+        acc |= (unsigned long long)bits << (64 - fill - len);
+        fill += len;
+        if (fill >= 32) {
+            const uint32_t word = (uint32_t)(acc >> 32);
+            if (first) {
+                atomicOr(&words[w], word);
+                first = false;
+            } else {
+                words[w] = word;
+            }
+            ++w;
+            acc <<= 32;
+            fill -= 32;
+        }
+    }
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void code_block_gpu(BitSink<EMIT>& bs, const int16_t* __restrict__ blk, int pred,
+                                               const uint32_t* __restrict__ dc, const uint32_t* __restrict__ ac) {
+    lf::u32x4 q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = reinterpret_cast<const lf::u32x4*>(blk)[i];
+    auto at = [&](int k) -> int {
+        const unsigned wd = q[k >> 3][(k >> 1) & 3];
+        return (int)(short)((k & 1) ? wd >> 16 : wd & 0xffffu);
+    };
+    const int diff = at(0) - pred;
+    int nb = diff ? 32 - __clz(diff < 0 ? -diff : diff) : 0;
+    unsigned e = dc[nb];
+    bs.put(((e >> 8) << nb) | ((unsigned)(diff + (diff >> 31)) & ((1u << nb) - 1u)), (int)(e & 255u) + nb);
+    int run = 0;
+#pragma unroll
+    for (int k = 1; k < 64; ++k) {
+        const int v = at(k);
+        if (v == 0) {
+            ++run;
+        } else {
+            while (run > 15) {
+                bs.put(ac[0xF0] >> 8, (int)(ac[0xF0] & 255u));
+                run -= 16;
+            }
+            nb = 32 - __clz(v < 0 ? -v : v);
+            e = ac[(run << 4) | nb];
+            bs.put(((e >> 8) << nb) | ((unsigned)(v + (v >> 31)) & ((1u << nb) - 1u)), (int)(e & 255u) + nb);
+            run = 0;
+        }
+    }
+    if (run) bs.put(ac[0] >> 8, (int)(ac[0] & 255u));
+}
+
+// exclusive scan of one value per thread over the workgroup; returns the exclusive prefix, `total` the sum
+__device__ __forceinline__ unsigned wg_exclusive_scan(unsigned v, unsigned* lds, unsigned& total) {
+    const int tid = threadIdx.x;
+    lds[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < kEB; off <<= 1) {
+        const unsigned add = tid >= off ? lds[tid - off] : 0u;
+        __syncthreads();
+        lds[tid] += add;
+        __syncthreads();
+    }
+    total = lds[kEB - 1];
+    const unsigned excl = lds[tid] - v;
+    __syncthreads();
+    return excl;
+}
+
+__global__ __launch_bounds__(kEB) void jpeg_entropy_kernel(const uint8_t* __restrict__ coef_base, size_t coef_stride,
+                                                           uint32_t* __restrict__ tmp, size_t tmp_words,
+                                                           uint8_t* __restrict__ out, size_t out_stride, int nblocks,
+                                                           HuffTab tab) {
+    __shared__ uint32_t sdc[2][16], sac[2][256];
+    __shared__ unsigned scan[kEB];
+    const int tid = threadIdx.x;
+    const size_t n = blockIdx.x;
+    const int16_t* coef = reinterpret_cast<const int16_t*>(coef_base + n * coef_stride);
+    uint32_t* tw = tmp + n * tmp_words;
+    uint8_t* orow = out + n * out_stride;
+    if (tid < 32) sdc[tid >> 4][tid & 15] = tab.dc[tid >> 4][tid & 15];
+    for (int i = tid; i < 512; i += kEB) sac[i >> 8][i & 255] = tab.ac[i >> 8][i & 255];
+    for (size_t i = tid; i < tmp_words; i += kEB) tw[i] = 0u;
+    __syncthreads();
+    const int per = (nblocks + kEB - 1) / kEB;
+    const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
+    auto pred_of = [&](int b) -> int {   // DC of the previous block of the same component in scan order
+        const int k6 = b % 6;
+        const int pb = k6 == 0 ? b - 3 : (k6 < 4 ? b - 1 : b - 6);
+        return pb >= 0 ? (int)coef[(size_t)pb * 64] : 0;
+    };
+    BitSink<false> count;
+    for (int b = b0; b < b1; ++b) {
+        const int t = (b % 6) < 4 ? 0 : 1;
+        code_block_gpu<false>(count, coef + (size_t)b * 64, pred_of(b), sdc[t], sac[t]);
+    }
+    unsigned total_bits = 0;
+    const unsigned start = wg_exclusive_scan(count.total, scan, total_bits);
+    const size_t nbytes = ((size_t)total_bits + 7) / 8;
+    if (nbytes > tmp_words * 4 || nbytes + 4 > out_stride) {   // uniform: the whole workgroup leaves
+        if (tid == 0) *reinterpret_cast<int*>(orow) = -1;
+        return;
+    }
+    BitSink<true> bs;
+    bs.words = tw;
+    bs.w = start >> 5;
+    bs.fill = (int)(start & 31u);
+    for (int b = b0; b < b1; ++b) {
+        const int t = (b % 6) < 4 ? 0 : 1;
+        code_block_gpu<true>(bs, coef + (size_t)b * 64, pred_of(b), sdc[t], sac[t]);
+    }
+    if (bs.fill > 0 && b1 > b0) atomicOr(&tw[bs.w], (uint32_t)(bs.acc >> 32));
+    if (tid == 0 && (total_bits & 7u)) {   // pad the last byte with ones
+        const unsigned pad = 8u - (total_bits & 7u), at = total_bits & 31u;
+        atomicOr(&tw[total_bits >> 5], ((1u << pad) - 1u) << (32u - at - pad));
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- 0xFF -> 0xFF 0x00
+    const size_t chunk = (nbytes + kEB - 1) / kEB;
+    const size_t i0 = min((size_t)tid * chunk, nbytes), i1 = min(i0 + chunk, nbytes);
+    auto byte_at = [&](size_t i) -> unsigned {
+        return (__hip_atomic_load(&tw[i >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (24 - 8 * (i & 3))) & 255u;
+    };
+    unsigned ff = 0;
+    for (size_t i = i0; i < i1; ++i) ff += byte_at(i) == 0xFFu;
+    unsigned total_ff = 0;
+    const unsigned before = wg_exclusive_scan(ff, scan, total_ff);
+    if (4 + nbytes + total_ff > out_stride) {
+        if (tid == 0) *reinterpret_cast<int*>(orow) = -1;
+        return;
+    }
+    uint8_t* dst = orow + 4 + i0 + before;
+    for (size_t i = i0; i < i1; ++i) {
+        const unsigned bv = byte_at(i);
+        *dst++ = (uint8_t)bv;
+        if (bv == 0xFFu) *dst++ = 0;
+    }
+    if (tid == 0) *reinterpret_cast<int*>(orow) = (int)(nbytes + total_ff);
+}
+
 }  // namespace
 
+extern "C" void lf_jpeg_std_huffman(uint32_t* dc32, uint32_t* ac512);   // lf_jpeg_host.cpp
+
 extern "C" {
+
+size_t lf_jpeg_entropy_workspace(int n, size_t out_stride) {
+    return n > 0 ? (size_t)n * ((out_stride + 3) / 4) * 4 : 0;
+}
+
+int lf_jpeg_entropy_u8(const void* coef, size_t coef_stride, uint8_t* out, size_t out_stride, int n, int h, int w,
+                       void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(coef && out && workspace, "lf_jpeg_entropy: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0, "lf_jpeg_entropy: bad dims n=%d h=%d w=%d", n, h, w);
+    LF_REQUIRE(coef_stride >= (size_t)h * w * 3 && coef_stride % 16 == 0 && (reinterpret_cast<size_t>(coef) & 15) == 0,
+               "lf_jpeg_entropy: coefficients must be 16-byte aligned with a stride >= 3*h*w bytes");
+    LF_REQUIRE(out_stride >= 1024 && out_stride % 4 == 0 && (reinterpret_cast<size_t>(out) & 3) == 0,
+               "lf_jpeg_entropy: output rows are 4-byte aligned and at least 1 KiB");
+    LF_REQUIRE(ws_bytes >= lf_jpeg_entropy_workspace(n, out_stride) && (reinterpret_cast<size_t>(workspace) & 3) == 0,
+               "lf_jpeg_entropy: workspace too small");
+    LF_REQUIRE(n <= 1 << 20, "lf_jpeg_entropy: batch too large");
+    static const HuffTab tab = []() {
+        HuffTab t;
+        lf_jpeg_std_huffman(&t.dc[0][0], &t.ac[0][0]);
+        return t;
+    }();
+    const int nblocks = (h / 16) * (w / 16) * 6;
+    jpeg_entropy_kernel<<<n, kEB, 0, lf::as_stream(stream)>>>(static_cast<const uint8_t*>(coef), coef_stride,
+                                                             static_cast<uint32_t*>(workspace), (out_stride + 3) / 4, out,
+                                                             out_stride, nblocks, tab);
+    return lf::check_launch("lf_jpeg_entropy");
+}
 
 size_t lf_jpeg_decode_workspace(int n, int h, int w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;

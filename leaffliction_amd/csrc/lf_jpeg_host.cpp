@@ -193,6 +193,15 @@ inline uint8_t* put_bytes(uint8_t* p, const void* src, size_t n) {
 
 extern "C" {
 
+// (code << 8 | length) of the Annex K tables, for the GPU entropy coder: dc32[2][16], ac512[2][256]
+void lf_jpeg_std_huffman(uint32_t* dc32, uint32_t* ac512) {
+    static const Tables tb;
+    for (int t = 0; t < 2; ++t) {
+        for (int i = 0; i < 16; ++i) dc32[16 * t + i] = ((uint32_t)tb.dc[t].code[i] << 8) | tb.dc[t].len[i];
+        for (int i = 0; i < 256; ++i) ac512[256 * t + i] = ((uint32_t)tb.ac[t].code[i] << 8) | tb.ac[t].len[i];
+    }
+}
+
 void lf_jpeg_quant_tables(int quality, uint8_t* lum64, uint8_t* chroma64) {
     const int q = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
     const int scale = q < 50 ? 5000 / q : 200 - 2 * q;   // jpeg_quality_scaling
@@ -209,12 +218,42 @@ size_t lf_jpeg_file_bound(int h, int w) {
     return (size_t)1024 + (size_t)h * w * 3 / 2 * 8;
 }
 
+static uint8_t* write_headers(uint8_t* p, int h, int w, int quality);
+
+long lf_jpeg_wrap_scan(const uint8_t* scan, size_t scan_len, int h, int w, int quality, uint8_t* out, size_t cap) {
+    if (!scan || !out || h <= 0 || w <= 0 || h % 16 || w % 16 || h > 65535 || w > 65535 || cap < 1024 + scan_len) return -1;
+    uint8_t* p = write_headers(out, h, w, quality);
+    memcpy(p, scan, scan_len);
+    p += scan_len;
+    *p++ = 0xFF;
+    *p++ = 0xD9;
+    return (long)(p - out);
+}
+
 long lf_jpeg_write_file(const int16_t* coef, int h, int w, int quality, uint8_t* out, size_t cap) {
     static const Tables tb;
     if (!coef || !out || h <= 0 || w <= 0 || h % 16 || w % 16 || h > 65535 || w > 65535 || cap < 1024) return -1;
+    uint8_t* p = write_headers(out, h, w, quality);
+    Writer wr{p, out + cap - 2};   // the two bytes of EOI stay free
+    int last[3] = {0, 0, 0};
+    const long mcus = (long)(h / 16) * (w / 16);
+    for (long m = 0; m < mcus; ++m) {
+        const int16_t* b = coef + m * 6 * 64;
+        for (int k = 0; k < 4; ++k) last[0] = code_block(wr, b + 64 * k, last[0], tb.dc[0], tb.ac[0]);
+        last[1] = code_block(wr, b + 64 * 4, last[1], tb.dc[1], tb.ac[1]);
+        last[2] = code_block(wr, b + 64 * 5, last[2], tb.dc[1], tb.ac[1]);
+    }
+    wr.flush();
+    if (wr.overflow) return -1;
+    p = wr.p;
+    *p++ = 0xFF;
+    *p++ = 0xD9;
+    return (long)(p - out);
+}
+
+static uint8_t* write_headers(uint8_t* p, int h, int w, int quality) {
     uint8_t lum[64], chr[64];
     lf_jpeg_quant_tables(quality, lum, chr);
-    uint8_t* p = out;
     static const uint8_t soi_app0[] = {0xFF, 0xD8, 0xFF, 0xE0, 0x00, 0x10, 'J', 'F', 'I', 'F', 0x00,
                                        0x01, 0x01, 0x00, 0x00, 0x01, 0x00, 0x01, 0x00, 0x00};
     p = put_bytes(p, soi_app0, sizeof(soi_app0));
@@ -243,21 +282,7 @@ long lf_jpeg_write_file(const int16_t* coef, int h, int w, int quality, uint8_t*
     }
     static const uint8_t sos[14] = {0xFF, 0xDA, 0x00, 0x0C, 0x03, 0x01, 0x00, 0x02, 0x11, 0x03, 0x11, 0x00, 0x3F, 0x00};
     p = put_bytes(p, sos, 14);
-    Writer wr{p, out + cap - 2};   // the two bytes of EOI stay free
-    int last[3] = {0, 0, 0};
-    const long mcus = (long)(h / 16) * (w / 16);
-    for (long m = 0; m < mcus; ++m) {
-        const int16_t* b = coef + m * 6 * 64;
-        for (int k = 0; k < 4; ++k) last[0] = code_block(wr, b + 64 * k, last[0], tb.dc[0], tb.ac[0]);
-        last[1] = code_block(wr, b + 64 * 4, last[1], tb.dc[1], tb.ac[1]);
-        last[2] = code_block(wr, b + 64 * 5, last[2], tb.dc[1], tb.ac[1]);
-    }
-    wr.flush();
-    if (wr.overflow) return -1;
-    p = wr.p;
-    *p++ = 0xFF;
-    *p++ = 0xD9;
-    return (long)(p - out);
+    return p;
 }
 
 }  // extern "C"

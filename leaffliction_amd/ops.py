@@ -285,6 +285,26 @@ def jpeg_fdct_quant_u8(x: torch.Tensor, quality: int = 95, out: Optional[torch.T
     return out.view(shape)
 
 
+def jpeg_entropy_u8(coef: torch.Tensor, h: int, w: int, out: Optional[torch.Tensor] = None,
+                    out_stride: Optional[int] = None) -> torch.Tensor:
+    """The Huffman coding of Image.save (Annex K tables, byte stuffing) for the coefficients jpeg_fdct_quant_u8
+    made: int16 [N, MCUs, 6, 64] -> uint8 [N, out_stride], row = int32 length (-1: did not fit) then the scan;
+    utils.jpeg_host.wrap_scan puts the markers around it."""
+    n = coef.shape[0]
+    if coef.dtype != torch.int16 or not coef.is_contiguous() or coef.numel() != n * (h // 16) * (w // 16) * 384:
+        raise ValueError("jpeg_entropy.coef: expected the contiguous int16 output of jpeg_fdct_quant_u8")
+    stride = int(out_stride or (4 + 3 * h * w + 4095) // 4096 * 4096)
+    if out is None:
+        out = torch.empty((n, stride), dtype=_U8, device=coef.device)
+    elif out.dtype != _U8 or tuple(out.shape) != (n, stride) or not out.is_contiguous():
+        raise ValueError("jpeg_entropy.out: expected a contiguous uint8 [N, out_stride] tensor")
+    nbytes = int(_lib.load().lf_jpeg_entropy_workspace(n, stride))
+    ws = torch.empty(nbytes, dtype=_U8, device=coef.device)
+    _lib.call("lf_jpeg_entropy_u8", coef.data_ptr(), 3 * h * w, out.data_ptr(), stride, n, h, w, ws.data_ptr(),
+              nbytes, _stream())
+    return out
+
+
 def jpeg_idct_rgb_u8(slots: torch.Tensor, h: int, w: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The pixel half of Image.open(path).convert("RGB") (image_utils.py:19-33) for N images of one size whose
     files utils.jpeg_host.read_file_into has Huffman-decoded: `slots` uint8 [N, slot_bytes], each row = the

@@ -16,9 +16,9 @@ pixels cross the process boundary through shared memory, never through pickles:
       uint8 by numpy itself (image_augmenter.py:121-123) into the NOISE slab;
   main process:  one H2D per (transform, size) group, batched kernels, D2H into the OUTPUT slab;
   encode worker: slot of the OUTPUT slab -> JPEG quality 95 -> the task's output path.  Images of whole
-      16x16 MCUs arrive as quantised DCT coefficients (colour conversion, 4:2:0 downsampling, DCT and
-      quantisation ran on the GPU, ops.jpeg_fdct_quant_u8) and the worker only Huffman-codes them
-      (libleafcodec.so): the same bytes Pillow would write, for a third of the host time.
+      16x16 MCUs arrive as finished JPEG scans (colour conversion, 4:2:0 downsampling, DCT, quantisation,
+      Huffman coding and byte stuffing ran on the GPU: ops.jpeg_fdct_quant_u8, ops.jpeg_entropy_u8) and the
+      worker only adds the markers: the same bytes Pillow would write.
 
 Only paths, shapes, seeds and a few floats are pickled.  Slots are fixed-size (an image that does
 not fit — a rotated copy of an unusually large original — falls back to a pickled array).
@@ -102,9 +102,10 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
 
 
 def _encode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
-    """jobs: (output path, output offset, shape, inline array or None[, "px" | "coef"]).  "coef": the slot
-    holds the image's quantised DCT coefficients (ops.jpeg_fdct_quant_u8, quality 95) and the worker's part
-    is the entropy coding (libleafcodec.so); otherwise pixels for Pillow.  Returns one bool per job."""
+    """jobs: (output path, output offset, shape, inline array or None[, "px" | "coef" | "scan"]).  "scan": the
+    slot holds the image's finished JPEG scan (ops.jpeg_fdct_quant_u8 + ops.jpeg_entropy_u8, quality 95) and the
+    worker adds the markers; "coef": its quantised DCT coefficients, the worker Huffman-codes them
+    (libleafcodec.so); otherwise pixels for Pillow.  Returns one bool per job."""
     from pathlib import Path
     from ..utils import jpeg_host
     from ..utils.image_utils import ImageLoader
@@ -113,9 +114,15 @@ def _encode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
     for job in jobs:
         path, off, shape, inline = job[:4]
         try:
-            if len(job) > 4 and job[4] == "coef":
+            if len(job) > 4 and job[4] in ("coef", "scan"):
                 h, w = int(shape[0]), int(shape[1])
-                data = jpeg_host.write_file(np.frombuffer(buf, np.int16, h * w * 3 // 2, off), h, w, 95)
+                if job[4] == "scan":   # the GPU's entropy coder has been over it: int32 length, then the scan
+                    n = int(np.frombuffer(buf, np.int32, 1, off)[0])
+                    if n < 0:
+                        raise RuntimeError("the coded scan did not fit its slot")
+                    data = jpeg_host.wrap_scan(np.frombuffer(buf, np.uint8, n, off + 4), h, w, 95)
+                else:
+                    data = jpeg_host.write_file(np.frombuffer(buf, np.int16, h * w * 3 // 2, off), h, w, 95)
                 dst = Path(path)
                 dst.parent.mkdir(parents=True, exist_ok=True)
                 with open(dst, "wb") as f:

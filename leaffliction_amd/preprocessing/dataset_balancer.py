@@ -189,13 +189,14 @@ class DatasetBalancer:
                     res = apply_batch(op, x, prm)
                     if op != "rotate":
                         y = torch.stack(res)
-                        # whole-MCU images bound for .jpg files leave the GPU as quantised DCT coefficients (as many
-                        # bytes as the pixels): the worker's share of the encode is then the Huffman coding alone
+                        # whole-MCU images bound for .jpg files leave the GPU as finished JPEG scans (colour conversion,
+                        # downsampling, DCT, quantisation, Huffman coding, byte stuffing): the worker adds the
+                        # markers and writes the file
                         jpg = [Path(chunk[k]["output_path"]).suffix.lower() in (".jpg", ".jpeg") for k in ks]
                         if h % 16 == 0 and w % 16 == 0 and all(jpg):
                             coef = ops.jpeg_fdct_quant_u8(y, JPEG_QUALITY)
-                            dev_out[idx, :h * w * 3] = coef.view(torch.uint8).view(len(ks), -1)
-                            kind = "coef"
+                            dev_out[idx] = ops.jpeg_entropy_u8(coef, h, w, out_stride=pool.slot_bytes)
+                            kind = "scan"
                         else:
                             dev_out[idx, :h * w * 3] = y.view(len(ks), -1)
                             kind = "px"

@@ -32,6 +32,9 @@ class DataParallel:
             kw = {}
             if backend == "nccl" and device is not None:
                 kw["device_id"] = device
+            if os.environ.get("LEAFFLICTION_DIST_TIMEOUT"):
+                from datetime import timedelta
+                kw["timeout"] = timedelta(seconds=float(os.environ["LEAFFLICTION_DIST_TIMEOUT"]))
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
 
     # -- the one exchange step of the training path

@@ -25,6 +25,8 @@ def load() -> C.CDLL:
         lib.lf_jpeg_file_bound.restype = C.c_size_t
         lib.lf_jpeg_write_file.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         lib.lf_jpeg_write_file.restype = C.c_long
+        lib.lf_jpeg_wrap_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        lib.lf_jpeg_wrap_scan.restype = C.c_long
         lib.lf_jpeg_read_file.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.lf_jpeg_read_file.restype = C.c_int
@@ -80,3 +82,14 @@ def read_file(data: bytes):
     n = (h // 16) * (w // 16)
     coef = slot[QTAB_BYTES:QTAB_BYTES + n * 768].view(np.int16).reshape(n, 6, 64).copy()
     return coef, slot[:QTAB_BYTES].view(np.uint16).reshape(2, 64).copy(), h, w
+
+
+def wrap_scan(scan: np.ndarray, h: int, w: int, quality: int = 95) -> bytes:
+    """Markers around a Huffman-coded scan made on the GPU (ops.jpeg_entropy_u8): the complete file."""
+    lib = load()
+    sc = np.ascontiguousarray(scan, dtype=np.uint8)
+    out = np.empty(sc.size + 1024, dtype=np.uint8)
+    n = int(lib.lf_jpeg_wrap_scan(sc.ctypes.data, sc.size, h, w, int(quality), out.ctypes.data, out.size))
+    if n < 0:
+        raise RuntimeError("lf_jpeg_wrap_scan failed")
+    return out[:n].tobytes()

@@ -96,5 +96,8 @@ def init_from_env():
                 kw["device_id"] = torch.device("cuda", dev)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        if os.environ.get("LEAFFLICTION_DIST_TIMEOUT"):   # seconds; the default (30 min) turns a lost rank into a stall
+            from datetime import timedelta
+            kw["timeout"] = timedelta(seconds=float(os.environ["LEAFFLICTION_DIST_TIMEOUT"]))
         dist.init_process_group(backend, rank=int(os.environ.get("RANK", "0")), world_size=world, **kw)
     return current()

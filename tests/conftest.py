@@ -14,6 +14,16 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test limit (pytest-timeout; a no-op without the plugin)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The multi-process tests (gloo ranks, codec worker pools) get a hard limit: a lost rank or worker must
+    fail the test, not stall the run for the process group's 30-minute default."""
+    for item in items:
+        if item.fspath.basename in ("test_sharded_paths.py", "test_dp_fit.py", "test_host_logic.py", "test_pipeline_gpu.py"):
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(600))
 
 
 @pytest.fixture(scope="session")

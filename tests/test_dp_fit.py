@@ -86,7 +86,7 @@ def _free_port():
 
 def _fit_worker(rank, world, port, root, n_items, batch, out_dir):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
-                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LEAFFLICTION_DIST_TIMEOUT": "180"})
     from leaffliction_amd.train.parallel import DataParallel
     from leaffliction_amd.train.utils import CosineDecay
     dp = DataParallel(backend="gloo")
@@ -178,7 +178,7 @@ def test_early_stopping_restores_best_without_stopping():
 # ------------------------------------------------------------------ GPU: the real model
 def _gpu_fit_worker(rank, world, port, root, n_items, batch, out_dir, dup):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
-                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LEAFFLICTION_DIST_TIMEOUT": "180"})
     torch.cuda.set_device(0)
     from leaffliction_amd.train.parallel import DataParallel
     from leaffliction_amd.train.utils import CosineDecay

@@ -104,7 +104,7 @@ def test_metrics_match_sklearn():
 # ----------------------------------------------------------------- gloo, world_size 2
 def _dp_worker(rank, world, port, out_dir):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
-                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LEAFFLICTION_DIST_TIMEOUT": "180"})
     from leaffliction_amd.train.parallel import DataParallel
     dp = DataParallel(backend="gloo")
     assert dp.active and dp.world == world

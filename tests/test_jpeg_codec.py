@@ -165,3 +165,29 @@ def test_gpu_decode_gives_pillows_pixels(cuda, h, w, kw):
     got = ops.jpeg_idct_rgb_u8(torch.from_numpy(slots).to(cuda), h, w).cpu().numpy()
     for i, f in enumerate(files):
         assert np.array_equal(got[i], np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,h,w,seed", CASES + [("scene", 96, 208, 7), ("noise", 224, 224, 8), ("scene", 256, 256, 9)])
+def test_gpu_entropy_coder_writes_pillows_bytes(cuda, kind, h, w, seed):
+    """pixels -> GPU colour / DCT / quantisation -> GPU Huffman coding and byte stuffing -> markers == Pillow's file."""
+    import torch
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    batch = np.stack([make(kind, h, w, seed + 10 * i) for i in range(3)])
+    coef = ops.jpeg_fdct_quant_u8(torch.from_numpy(batch).to(cuda))
+    rows = ops.jpeg_entropy_u8(coef, h, w).cpu().numpy()
+    for i in range(3):
+        n = int(rows[i, :4].view(np.int32)[0])
+        assert n > 0
+        assert jpeg_host.wrap_scan(rows[i, 4:4 + n], h, w) == pil_bytes(batch[i]), i
+
+
+@pytest.mark.gpu
+def test_gpu_entropy_coder_reports_a_row_that_is_too_small(cuda):
+    import torch
+    from leaffliction_amd import ops
+    a = make("noise", 64, 64, 3)
+    coef = ops.jpeg_fdct_quant_u8(torch.from_numpy(a[None]).to(cuda))
+    rows = ops.jpeg_entropy_u8(coef, 64, 64, out_stride=1024).cpu().numpy()
+    assert int(rows[0, :4].view(np.int32)[0]) == -1

@@ -90,7 +90,7 @@ def _free_port():
 
 def _join(rank, world, port, gpu):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
-                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LEAFFLICTION_DIST_TIMEOUT": "180",
                        "LEAFFLICTION_DIST_BACKEND": "gloo"})
     if not gpu:
         os.environ["CUDA_VISIBLE_DEVICES"] = ""
