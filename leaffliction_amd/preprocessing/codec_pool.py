@@ -149,7 +149,19 @@ class CodecPool:
         self.names: Dict[str, str] = {}
         # spawn, not fork: the parent has an initialised HIP runtime that a forked child must not inherit
         self.pool = ProcessPoolExecutor(max_workers=self.workers, mp_context=get_context("spawn"))
-        self._warming = [self.pool.submit(_warm, i) for i in range(self.workers)]
+        # A spawned child re-imports the parent's __main__ (bench.py, a CLI: torch and all, 1-2 s of CPU per
+        # worker) before it can run anything.  Nothing these workers run lives in __main__, so the main module is
+        # hidden from multiprocessing's preparation data while the processes are started.
+        import sys
+        main = sys.modules.get("__main__")
+        saved = (getattr(main, "__file__", None), getattr(main, "__spec__", None)) if main is not None else None
+        try:
+            if main is not None:
+                main.__file__, main.__spec__ = None, None
+            self._warming = [self.pool.submit(_warm, i) for i in range(self.workers)]
+        finally:
+            if main is not None:
+                main.__file__, main.__spec__ = saved
 
     def allocate(self, slots: int, slot_bytes: int) -> None:
         self.slots, self.slot_bytes = int(slots), int(slot_bytes)
@@ -198,7 +210,7 @@ class CodecPool:
         return [jobs[i:i + per] for i in range(0, len(jobs), per)]
 
     def decode(self, tasks: Sequence[dict], first_slot: int, coefficients: bool = False) -> List[Future]:
-        jobs = [(t["source_img"], t["transform_name"], t["seed"], (first_slot + k) * self.slot_bytes,
+        jobs = [(t.get("read_img", t["source_img"]), t["transform_name"], t["seed"], (first_slot + k) * self.slot_bytes,
                  (first_slot + k) * self.slot_bytes, self.slot_bytes, coefficients) for k, t in enumerate(tasks)]
         return [self.pool.submit(_decode_jobs, self.names, part) for part in self._split(jobs)]
 

@@ -91,7 +91,32 @@ class DatasetBalancer:
         logger.info(f"Preparing target directory: {self.target_dir}")
         if self.target_dir.exists():
             shutil.rmtree(self.target_dir)
-        shutil.copytree(self.source_dir, self.target_dir)
+        # The tree is laid out first (directories and EMPTY files, in copytree's own order, so that the target's
+        # directory order — the order `random.choice` indexes into — is the one a plain copy gives), the bytes
+        # follow on a thread while the workers already decode from the source tree (`read_img`): the copy of the
+        # originals was a quarter of the whole job.  execute_balancing joins the thread before the manifest.
+        pending: List[tuple] = []
+
+        def placeholder(src, dst):
+            open(dst, "wb").close()
+            pending.append((src, dst))
+            return dst
+
+        shutil.copytree(self.source_dir, self.target_dir, copy_function=placeholder)
+
+        def fill():
+            for src, dst in pending:
+                shutil.copy2(src, dst)
+
+        import threading
+        self._copying = threading.Thread(target=fill, name="copy-originals", daemon=True)
+        self._copying.start()
+
+    def _join_copy(self) -> None:
+        t = getattr(self, "_copying", None)
+        if t is not None:
+            t.join()
+            self._copying = None
 
     def _images_by_class(self) -> Dict[str, List[Path]]:
         """class name -> its images in the target tree, `*.JPG` before `*.jpg`, each in glob
@@ -120,6 +145,8 @@ class DatasetBalancer:
                     source_img = random.choice(source_images)
                     new_name = source_img.stem + f"_aug_{transform_name}_{i + 1}" + source_img.suffix
                     tasks.append({"source_img": str(source_img),
+                                  "read_img": str(self.source_dir / source_img.relative_to(self.target_dir))
+                                  if source_img.is_relative_to(self.target_dir) else str(source_img),
                                   "output_path": str(class_dir / new_name),
                                   "transform_name": transform_name,
                                   "class_name": class_name,
@@ -254,7 +281,7 @@ class DatasetBalancer:
         from PIL import Image
         n_chunk = min(CHUNK, len(share))
         chunks = [share[b:b + n_chunk] for b in range(0, len(share), n_chunk)]
-        with Image.open(share[0]["source_img"]) as probe:
+        with Image.open(share[0].get("read_img", share[0]["source_img"])) as probe:
             w0, h0 = probe.size
         slot = (2 * h0 * w0 * 3 + 4095) // 4096 * 4096
         t0 = time.perf_counter()
@@ -332,6 +359,10 @@ class DatasetBalancer:
         self.completed, self.failed = rk.sum_ints([self.completed, self.failed])
         rk.barrier()  # every share's files are on disk before the tree is listed
         logger.info(f"Augmentation complete: {self.completed} images generated, {self.failed} failed")
+        t3 = time.perf_counter()
+        self._join_copy()
+        self.timings["copy_originals_tail"] = time.perf_counter() - t3
+        rk.barrier()
         t3 = time.perf_counter()
         if rk.rank == 0:
             self._generate_augmented_manifest()
