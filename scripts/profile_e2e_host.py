@@ -28,7 +28,9 @@ if __name__ == "__main__":
         bal.execute_balancing()
         pr.disable()
         print({k: round(v, 2) for k, v in bal.timings.items()})
-        pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+        st = pstats.Stats(pr)
+        st.sort_stats("cumulative").print_stats(30)
+        st.sort_stats("tottime").print_stats(45)
     finally:
         os.chdir("/")
         shutil.rmtree(tmp, ignore_errors=True)
