@@ -27,6 +27,11 @@
 // dot-product kernel (lf_augment.hip) spends ~400 vector instructions; 332 us, 3.7 TB/s of image bytes.
 // What bounds it now is not the memory system: each wave issues 36 % of its cycles and waits the rest
 // (dependent MFMA chains, one workgroup barrier per 32 rows, 14 waves per CU at 124 registers).
+// Ablations on the same batch (development builds, results wrong by construction): without the workgroup barrier
+// 400 us (slower), without the vertical pass 338 us, without global loads 278 us, without global stores 293 us,
+// without either 271 us, without either and without the vertical pass 119 us: the arithmetic alone (271 us) and
+// the barrier-paced memory traffic alone (~330 us) each nearly fill the 348 us — both have to shrink for the
+// kernel to move.
 // Nontemporal loads / stores measured slower (2.9 against 3.5 TB/s): neighbouring column groups share their
 // 32-byte margins through the L2.
 #include "lf_common.h"
