@@ -95,3 +95,43 @@ def test_training_step_fullsize_reproducible(cuda):
     assert torch.equal(p1, p2) and torch.equal(g1, g2)
     assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
     assert 0.5 < l1[0] < 8.0                                 # random init: a few nats, not an overflow
+
+
+def test_blur_mask_jpeg_fullsize_properties(cuda):
+    """Round-2 kernels at batch size: the i8-MFMA blur commutes with mirror images (symmetric taps, reflect-101
+    borders) and equals the dot-product kernels where both apply; the slotted histogram equals the per-wave one;
+    the JPEG halves invert each other the way libjpeg's do (decode(encode(x)) is what Pillow's round trip gives)."""
+    import io
+
+    from PIL import Image
+
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n = 768
+    x = torch.randint(0, 256, (n, S, S, 3), dtype=torch.uint8, generator=g).to(cuda)
+    for k in (5, 15):
+        b = ops.gauss_blur_u8(x, k, 0.0)
+        assert torch.equal(ops.gauss_blur_u8(x.flip(1), k, 0.0), b.flip(1))      # upside down
+        assert torch.equal(ops.gauss_blur_u8(x.flip(2), k, 0.0), b.flip(2))      # mirrored
+        # a ragged crop goes to the dot-product kernel; its interior (far from the crop's borders) must agree
+        c = ops.gauss_blur_u8(x[:8, :220, :219].contiguous(), k, 0.0)
+        assert torch.equal(c[:, 16:200, 16:200], b[:8, 16:200, 16:200])
+    big, small = ops.hist_u8(x), torch.cat([ops.hist_u8(x[i:i + 256]) for i in range(0, n, 256)])
+    assert torch.equal(big, small)                                               # >= 512 images: slotted table
+    coef = ops.jpeg_fdct_quant_u8(x[:512])
+    rows = ops.jpeg_entropy_u8(coef, S, S).cpu().numpy()
+    lens = rows[:, :4].copy().view(np.int32)[:, 0]
+    assert (lens > 0).all()
+    files = [jpeg_host.wrap_scan(rows[i, 4:4 + lens[i]], S, S) for i in (0, 255, 511)]
+    stride = (256 + 3 * S * S + 4095) // 4096 * 4096
+    slots = np.zeros((3, stride), np.uint8)
+    for i, f in enumerate(files):
+        assert jpeg_host.read_file_into(f, slots[i]) == (S, S)
+    back = ops.jpeg_idct_rgb_u8(torch.from_numpy(slots).to(cuda), S, S).cpu().numpy()
+    xs = x[[0, 255, 511]].cpu().numpy()
+    for i, f in enumerate(files):
+        b = io.BytesIO()
+        Image.fromarray(xs[i]).save(b, format="JPEG", quality=95)
+        assert b.getvalue() == f                                                  # Pillow's file
+        assert np.array_equal(back[i], np.asarray(Image.open(io.BytesIO(f)).convert("RGB")))   # Pillow's pixels
