@@ -76,8 +76,11 @@ struct SShape {
     static constexpr int WBYTES = CH * TAPS * 2 * COUT * 16;
     static constexpr int PBYTES = (PPIX * ROWB + 15) / 16 * 16;
     static constexpr int EBYTES = 32 * 256 * 4;             // fp32 accumulators of one 32-channel block
-    // the epilogue's transpose buffer reuses the patch (dead once the tile's MFMAs are done)
-    static constexpr int LDS = WBYTES + (PBYTES > EBYTES ? PBYTES : EBYTES);
+    // The epilogue's transpose buffer has its own LDS where two workgroups per CU still fit (then a wave may write
+    // its accumulators while slower waves are still reading the patch: no barrier in front of the epilogue);
+    // otherwise it reuses the patch, which is dead once every wave is through the tile's MFMAs.
+    static constexpr bool SEP_LE = WBYTES + PBYTES + EBYTES <= 80 * 1024;
+    static constexpr int LDS = SEP_LE ? WBYTES + PBYTES + EBYTES : WBYTES + (PBYTES > EBYTES ? PBYTES : EBYTES);
 };
 
 // RMW = false: a launch with no read-modify-write operand (no accumulate, no BatchNorm-backward mask): the
@@ -97,7 +100,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* lw = lds;
     unsigned char* lp = lds + S::WBYTES;
-    float* le = reinterpret_cast<float*>(lp);  // [32 channels][256 pixels], over the patch
+    float* le = reinterpret_cast<float*>(S::SEP_LE ? lp + S::PBYTES : lp);  // [32 channels][256 pixels]
     __shared__ float lsc[2 * CI];
     __shared__ float lst[2 * COUT];
     __shared__ float los[2 * COUT];
@@ -279,8 +282,10 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     const int f0 = 64 * wv + 2 * px;
     const int prow = f0 / TW, pcol = f0 - prow * TW;
     const unsigned pp0 = (unsigned)(prow * PW + pcol);
-    // epilogue geometry: thread = (pixel group eg of 8 consecutive flat positions, channel ec + 8*j)
-    const int eg = tid & 31, ec = tid >> 5;
+    // epilogue geometry: thread = (pixel group eg of 8 consecutive flat positions, channel ec + 8*j), the groups
+    // of a wave being the 64 positions whose accumulators the wave itself holds: what a wave reads back from `le`
+    // it has written itself, so the transposition needs no workgroup barrier
+    const int eg = 8 * wv + (lane & 7), ec = lane >> 3;
     const int erow = (8 * eg) / TW, ecol = (8 * eg) - erow * TW;
 
     f32x16 acc[NB][NCO];
@@ -350,13 +355,14 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
         // -> thread (8 pixels, 4 channels); then 16-byte stores and the sums of the rounded values
 #pragma unroll
         for (int cb = 0; cb < NCO; ++cb) {
-            __syncthreads();  // every wave is done with the patch (cb = 0) / with the previous block in `le`
+            if (!S::SEP_LE && cb == 0) __syncthreads();  // `le` lies over the patch: every wave must be done with it
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cl = 8 * (r >> 2) + 4 * kh + (r & 3);
                 *reinterpret_cast<float2*>(le + cl * 256 + 64 * wv + 2 * px) = make_float2(acc[0][cb][r], acc[1][cb][r]);
             }
-            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own LDS writes (no other wave reads them)
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int cl = 8 * j + ec, co = cb * 32 + cl;
@@ -406,21 +412,40 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
                 s1[cb][j] += a;
                 s2[cb][j] += b;
             }
+            __builtin_amdgcn_wave_barrier();   // the reads above stay in front of the next block's writes
         }
     }
     if (stats) {
-        // one partial per workgroup: a channel's pixel groups are the 32 lanes of one half-wave
+        // one partial per workgroup: a channel's pixel groups are 8 lanes (lane & 7) in each of the four waves
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lp);   // [4 waves][COUT][2], over the patch (dead now)
 #pragma unroll
         for (int cb = 0; cb < NCO; ++cb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float a = half_sum32(s1[cb][j]), b = half_sum32(s2[cb][j]);
-                if (eg == 31) {
-                    float* dst = p.stat_part + ((size_t)(cb * 32 + 8 * j + ec) * (size_t)p.stat_tiles + blockIdx.x) * 2;
-                    dst[0] = a;
-                    dst[1] = b;
+                float a = s1[cb][j], b = s2[cb][j];
+#pragma unroll
+                for (int m = 1; m < 8; m <<= 1) {
+                    a += __shfl_xor(a, m, 64);
+                    b += __shfl_xor(b, m, 64);
+                }
+                if ((lane & 7) == 0) {
+                    red[(wv * COUT + cb * 32 + 8 * j + ec) * 2] = a;
+                    red[(wv * COUT + cb * 32 + 8 * j + ec) * 2 + 1] = b;
                 }
             }
+        __syncthreads();
+        for (int c = tid; c < COUT; c += kT) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {   // fixed order: deterministic
+                a += red[(v * COUT + c) * 2];
+                b += red[(v * COUT + c) * 2 + 1];
+            }
+            float* dst = p.stat_part + ((size_t)c * (size_t)p.stat_tiles + blockIdx.x) * 2;
+            dst[0] = a;
+            dst[1] = b;
+        }
     }
 }
 

@@ -13,11 +13,12 @@ def main():
     cin = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     cout = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     hw = int(sys.argv[3]) if len(sys.argv) > 3 else 224
+    hh = int(sys.argv[4]) if len(sys.argv) > 4 else hw     # height (plane stride = hh * hw elements)
     n, dev = 256, torch.device("cuda:0")
     bf = torch.bfloat16
-    x = torch.randn(n, cin, hw, hw, device=dev).to(bf)
-    y = torch.randn(n, cout, hw, hw, device=dev).to(bf)
-    out = torch.zeros(n, cout, hw, hw, device=dev, dtype=bf)
+    x = torch.randn(n, cin, hh, hw, device=dev).to(bf)
+    y = torch.randn(n, cout, hh, hw, device=dev).to(bf)
+    out = torch.zeros(n, cout, hh, hw, device=dev, dtype=bf)
     wp = nn.conv2d_bf16_weights(torch.randn(cin, 9, cout, device=dev) * 0.05, 3)
     sc, sh = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1
     msc, msh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
@@ -43,7 +44,7 @@ def main():
         ms = e0.elapsed_time(e1) / 10
         base = (x.numel() + out.numel()) * 2
         extra = (out.numel() * 2 if kw.get("accumulate") else 0) + (y.numel() * 2 if "mask_y" in kw else 0)
-        print(f"{name:34s} {ms * 1e3:8.1f} us   {(base + extra) / ms / 1e9:7.1f} GB/s algorithmic")
+        print(f"{name:34s} {ms * 1e3:8.1f} us   {(base + extra) / ms / 1e9:7.2f} TB/s algorithmic   {ms * 1e6 / (n * hh * hw):.4f} ns/pixel")
 
 
 if __name__ == "__main__":
