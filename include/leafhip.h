@@ -163,11 +163,12 @@ int lf_inclusive_mask_u8(const uint8_t* rgb, uint8_t* mask, int n, int h, int w,
 /* JPEG encode (the file Pillow's Image.save(path, quality=q) writes)          */
 /* ------------------------------------------------------------------------- */
 /* Replaces ImageLoader.save_pil_image / save_array (srcs/utils/image_utils.py:49-56; the balancer's output
- * step, dataset_balancer.py:201-207) for images of whole 16x16 MCUs: baseline, 4:2:0, Annex K Huffman
+ * step, dataset_balancer.py:201-207) for images of any size: baseline, 4:2:0, Annex K Huffman
  * tables, JFIF 1.01 — libjpeg-turbo's integer pipeline restated (jccolor, jcsample h2v2, jfdctint,
  * jcdctmgr, jchuff, jcmarker), so the bytes equal Pillow's.
- * lf_jpeg_fdct_quant_u8 (GPU): rgb [N,H,W,3] -> coef int16 [N][H/16 * W/16 MCUs][Y00 Y01 Y10 Y11 Cb Cr][64],
- *   quantised, in zigzag order (3*H*W bytes per image, 16-byte aligned).
+ * lf_jpeg_fdct_quant_u8 (GPU): rgb [N,H,W,3] -> coef int16 [N][ceil(H/16) * ceil(W/16) MCUs][Y00 Y01 Y10 Y11 Cb Cr][64],
+ *   quantised, in zigzag order (768 bytes per MCU, 16-byte aligned).  Sizes that are not whole MCUs are padded as
+ *   libjpeg pads them (replicated edges, dummy blocks: jcprepct.c, jcsample.c, jccoefct.c).
  * lf_jpeg_write_file (HOST, no GPU call in it; also exported by libleafcodec.so for the codec worker
  *   processes): one image's coefficients -> the complete file in `out`; returns its length, -1 on bad
  *   arguments or if `cap` (take lf_jpeg_file_bound) is too small.

@@ -53,6 +53,11 @@ __device__ __forceinline__ void fdct8(int* d) {
     d[1] = descale(u7 + z1 + z4, SH);
 }
 
+// RAGGED: sizes that are not whole MCUs, padded as libjpeg pads them — samples replicated to the right (at
+// full resolution, before the chroma box filter) and downwards (the last luminance row; the last chroma row), and
+// luminance blocks wholly outside the image turned into dummies (no AC, the DC of the previous block of their MCU;
+// jccoefct.c compress_data).  Byte loads instead of 12-byte groups: rows are not 4-byte aligned.
+template <bool RAGGED>
 __global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __restrict__ rgb,
                                                              int16_t* __restrict__ coef, int h, int w, int n_images,
                                                              JpegQuant q) {
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __re
         sdiv[1][tid] = q.div[1][tid];
         spos[tid] = q.pos[tid];
     }
-    const int mcu_w = w / 16, mcu_h = h / 16, gw = (mcu_w + kGroup - 1) / kGroup;
+    const int mcu_w = (w + 15) / 16, mcu_h = (h + 15) / 16, gw = (mcu_w + kGroup - 1) / kGroup;
     const long groups = (long)n_images * mcu_h * gw;
     for (long g = blockIdx.x; g < groups; g += gridDim.x) {
         const int gx = (int)(g % gw);
@@ -80,9 +85,23 @@ __global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __re
         {   // ---- four pixels per thread: RGB -> Y, Cb, Cr (jccolor.c, SCALEBITS 16)
             const int row = tid >> 4, x = (tid & 15) * 4;
             if (x < 16 * nm) {
-                const uint8_t* p = rgb + ((n * h + 16 * my + row) * (size_t)w + 16 * mx0 + x) * 3;
-                const unsigned* p4 = reinterpret_cast<const unsigned*>(p);   // 12-byte groups of a 4-pixel-aligned column
-                const unsigned wd[3] = {p4[0], p4[1], p4[2]};
+                unsigned wd[3];
+                if (RAGGED) {   // right / bottom edge replicated
+                    const uint8_t* rp = rgb + (n * h + min(16 * my + row, h - 1)) * (size_t)w * 3;
+                    wd[0] = wd[1] = wd[2] = 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint8_t* px = rp + (size_t)min(16 * mx0 + x + k, w - 1) * 3;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) wd[(3 * k + c) >> 2] |= (unsigned)px[c] << (8 * ((3 * k + c) & 3));
+                    }
+                } else {
+                    const uint8_t* p = rgb + ((n * h + 16 * my + row) * (size_t)w + 16 * mx0 + x) * 3;
+                    const unsigned* p4 = reinterpret_cast<const unsigned*>(p);   // 12-byte groups of a 4-pixel-aligned column
+                    wd[0] = p4[0];
+                    wd[1] = p4[1];
+                    wd[2] = p4[2];
+                }
                 unsigned yy = 0, cb = 0, cr = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -100,9 +119,11 @@ __global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __re
         }
         __syncthreads();
         for (int i = tid; i < 2 * 8 * 8 * kGroup; i += kT) {   // ---- h2v2_downsample, bias 1, 2, 1, 2 ...
-            const int pl = i / (8 * 8 * kGroup), r = (i / (8 * kGroup)) & 7, c = i % (8 * kGroup);
+            const int pl = i / (8 * 8 * kGroup), r0 = (i / (8 * kGroup)) & 7, c = i % (8 * kGroup);
+            // below the image the last CHROMA row repeats (its second source row is already the replicated one)
+            const int r = RAGGED ? min(r0, (h + 1) / 2 - 1 - 8 * my) : r0;
             const uint8_t(*P)[16 * kGroup] = pl ? scr : scb;
-            sc[pl][r][c] = (uint8_t)((P[2 * r][2 * c] + P[2 * r][2 * c + 1] + P[2 * r + 1][2 * c] + P[2 * r + 1][2 * c + 1] +
+            sc[pl][r0][c] = (uint8_t)((P[2 * r][2 * c] + P[2 * r][2 * c + 1] + P[2 * r + 1][2 * c] + P[2 * r + 1][2 * c + 1] +
                                       1 + (c & 1)) >> 2);
         }
         __syncthreads();
@@ -139,6 +160,25 @@ __global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __re
             }
         }
         __syncthreads();
+        if (RAGGED) {
+            if (tid < nm) {   // dummy luminance blocks of MCU tid, in buffer order Y00 Y01 Y10 Y11
+                const int mx = mx0 + tid;
+                const bool col1 = 2 * mx + 1 < (w + 7) / 8, row1 = 2 * my + 1 < (h + 7) / 8;
+                int16_t(*b)[64] = &outb[6 * tid];
+                auto dummy = [&](int blk, int16_t dc) {
+                    for (int k = 1; k < 64; ++k) b[blk][k] = 0;
+                    b[blk][0] = dc;
+                };
+                if (!col1) dummy(1, b[0][0]);
+                if (row1) {
+                    if (!col1) dummy(3, b[2][0]);
+                } else {
+                    dummy(2, b[1][0]);
+                    dummy(3, b[1][0]);
+                }
+            }
+            __syncthreads();
+        }
         if (work) {   // 16 bytes per lane, 768 contiguous bytes per MCU
             int16_t* dst = coef + ((n * mcu_h + my) * (size_t)mcu_w + mx0) * (6 * 64);
             reinterpret_cast<lf::u32x4*>(dst)[tid] = reinterpret_cast<const lf::u32x4*>(&outb[0][0])[tid];
@@ -496,9 +536,10 @@ size_t lf_jpeg_entropy_workspace(int n, size_t out_stride) {
 int lf_jpeg_entropy_u8(const void* coef, size_t coef_stride, uint8_t* out, size_t out_stride, int n, int h, int w,
                        void* workspace, size_t ws_bytes, lf_stream_t stream) {
     LF_REQUIRE(coef && out && workspace, "lf_jpeg_entropy: null buffer");
-    LF_REQUIRE(n > 0 && h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0, "lf_jpeg_entropy: bad dims n=%d h=%d w=%d", n, h, w);
-    LF_REQUIRE(coef_stride >= (size_t)h * w * 3 && coef_stride % 16 == 0 && (reinterpret_cast<size_t>(coef) & 15) == 0,
-               "lf_jpeg_entropy: coefficients must be 16-byte aligned with a stride >= 3*h*w bytes");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_jpeg_entropy: bad dims n=%d h=%d w=%d", n, h, w);
+    const size_t mcus = (size_t)((h + 15) / 16) * ((w + 15) / 16);
+    LF_REQUIRE(coef_stride >= mcus * 768 && coef_stride % 16 == 0 && (reinterpret_cast<size_t>(coef) & 15) == 0,
+               "lf_jpeg_entropy: coefficients must be 16-byte aligned with a stride >= 768 bytes per MCU");
     LF_REQUIRE(out_stride >= 1024 && out_stride % 4 == 0 && (reinterpret_cast<size_t>(out) & 3) == 0,
                "lf_jpeg_entropy: output rows are 4-byte aligned and at least 1 KiB");
     LF_REQUIRE(ws_bytes >= lf_jpeg_entropy_workspace(n, out_stride) && (reinterpret_cast<size_t>(workspace) & 3) == 0,
@@ -509,7 +550,7 @@ int lf_jpeg_entropy_u8(const void* coef, size_t coef_stride, uint8_t* out, size_
         lf_jpeg_std_huffman(&t.dc[0][0], &t.ac[0][0]);
         return t;
     }();
-    const int nblocks = (h / 16) * (w / 16) * 6;
+    const int nblocks = (int)mcus * 6;
     jpeg_entropy_kernel<<<n, kEB, 0, lf::as_stream(stream)>>>(static_cast<const uint8_t*>(coef), coef_stride,
                                                              static_cast<uint32_t*>(workspace), (out_stride + 3) / 4, out,
                                                              out_stride, nblocks, tab);
@@ -557,10 +598,10 @@ int lf_jpeg_fdct_quant_u8(const uint8_t* rgb, int16_t* coef, int n, int h, int w
                           lf_stream_t stream) {
     LF_REQUIRE(rgb && coef, "lf_jpeg_fdct_quant: null buffer");
     LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_jpeg_fdct_quant: bad dims n=%d h=%d w=%d", n, h, w);
-    LF_REQUIRE(h % 16 == 0 && w % 16 == 0, "lf_jpeg_fdct_quant: whole 16x16 MCUs only (%d x %d)", h, w);
     LF_REQUIRE(h <= 65535 && w <= 65535, "lf_jpeg_fdct_quant: JPEG dimensions are 16-bit");
     LF_REQUIRE(quality >= 1 && quality <= 100, "lf_jpeg_fdct_quant: quality %d", quality);
-    LF_REQUIRE((reinterpret_cast<size_t>(rgb) & 3) == 0 && (reinterpret_cast<size_t>(coef) & 15) == 0,
+    const bool ragged = h % 16 != 0 || w % 16 != 0;
+    LF_REQUIRE((ragged || (reinterpret_cast<size_t>(rgb) & 3) == 0) && (reinterpret_cast<size_t>(coef) & 15) == 0,
                "lf_jpeg_fdct_quant: rgb must be 4-byte and coef 16-byte aligned");
     JpegQuant q;
     uint8_t tabs[2][64];
@@ -573,9 +614,12 @@ int lf_jpeg_fdct_quant_u8(const uint8_t* rgb, int16_t* coef, int n, int h, int w
         q.div[1][i] = (uint16_t)(tabs[1][i] << 3);
         q.pos[natural[i]] = (uint8_t)i;
     }
-    const long groups = (long)n * (h / 16) * ((w / 16 + kGroup - 1) / kGroup);
+    const long groups = (long)n * ((h + 15) / 16) * (((w + 15) / 16 + kGroup - 1) / kGroup);
     const unsigned grid = (unsigned)(groups < 256 * 16 ? groups : 256 * 16);
-    jpeg_fdct_quant_kernel<<<grid, kT, 0, lf::as_stream(stream)>>>(rgb, coef, h, w, n, q);
+    if (ragged)
+        jpeg_fdct_quant_kernel<true><<<grid, kT, 0, lf::as_stream(stream)>>>(rgb, coef, h, w, n, q);
+    else
+        jpeg_fdct_quant_kernel<false><<<grid, kT, 0, lf::as_stream(stream)>>>(rgb, coef, h, w, n, q);
     return lf::check_launch("lf_jpeg_fdct_quant");
 }
 

@@ -215,13 +215,13 @@ void lf_jpeg_quant_tables(int quality, uint8_t* lum64, uint8_t* chroma64) {
 size_t lf_jpeg_file_bound(int h, int w) {
     // markers (623 bytes) + at most 26 bits per coefficient (16-bit code + 10 value bits... the DC takes
     // 9 + 11), every byte possibly stuffed: 8 bytes per coefficient is far above anything the coder emits
-    return (size_t)1024 + (size_t)h * w * 3 / 2 * 8;
+    return (size_t)1024 + (size_t)((h + 15) / 16) * ((w + 15) / 16) * 384 * 8;
 }
 
 static uint8_t* write_headers(uint8_t* p, int h, int w, int quality);
 
 long lf_jpeg_wrap_scan(const uint8_t* scan, size_t scan_len, int h, int w, int quality, uint8_t* out, size_t cap) {
-    if (!scan || !out || h <= 0 || w <= 0 || h % 16 || w % 16 || h > 65535 || w > 65535 || cap < 1024 + scan_len) return -1;
+    if (!scan || !out || h <= 0 || w <= 0 || h > 65535 || w > 65535 || cap < 1024 + scan_len) return -1;
     uint8_t* p = write_headers(out, h, w, quality);
     memcpy(p, scan, scan_len);
     p += scan_len;
@@ -232,11 +232,11 @@ long lf_jpeg_wrap_scan(const uint8_t* scan, size_t scan_len, int h, int w, int q
 
 long lf_jpeg_write_file(const int16_t* coef, int h, int w, int quality, uint8_t* out, size_t cap) {
     static const Tables tb;
-    if (!coef || !out || h <= 0 || w <= 0 || h % 16 || w % 16 || h > 65535 || w > 65535 || cap < 1024) return -1;
+    if (!coef || !out || h <= 0 || w <= 0 || h > 65535 || w > 65535 || cap < 1024) return -1;
     uint8_t* p = write_headers(out, h, w, quality);
     Writer wr{p, out + cap - 2};   // the two bytes of EOI stay free
     int last[3] = {0, 0, 0};
-    const long mcus = (long)(h / 16) * (w / 16);
+    const long mcus = (long)((h + 15) / 16) * ((w + 15) / 16);   // ragged sizes: the caller's coefficients include libjpeg's padding
     for (long m = 0; m < mcus; ++m) {
         const int16_t* b = coef + m * 6 * 64;
         for (int k = 0; k < 4; ++k) last[0] = code_block(wr, b + 64 * k, last[0], tb.dc[0], tb.ac[0]);

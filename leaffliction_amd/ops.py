@@ -271,12 +271,10 @@ def inclusive_mask_u8(x: torch.Tensor, green_hue_range=(25, 100)) -> torch.Tenso
 
 def jpeg_fdct_quant_u8(x: torch.Tensor, quality: int = 95, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The pixel half of Image.save(path, quality=quality) (image_utils.py:49-56) for a batch [N,H,W,3] uint8
-    with H, W multiples of 16: libjpeg's quantised DCT coefficients, int16 [N, H/16 * W/16, 6, 64] — per MCU the
+    : libjpeg's quantised DCT coefficients, int16 [N, ceil(H/16) * ceil(W/16), 6, 64] — per MCU the
     blocks Y00 Y01 Y10 Y11 Cb Cr in zigzag order, what utils.jpeg_host.write_file turns into the file."""
     n, h, w = _hwc(x, "jpeg_fdct_quant.x")
-    if h % 16 or w % 16:
-        raise ValueError(f"jpeg_fdct_quant: whole 16x16 MCUs only, got {h}x{w}")
-    shape = (n, (h // 16) * (w // 16), 6, 64)
+    shape = (n, -(-h // 16) * -(-w // 16), 6, 64)   # ragged sizes carry libjpeg's padding (replicated edges, dummy blocks)
     if out is None:
         out = torch.empty(shape, dtype=torch.int16, device=x.device)
     elif out.dtype != torch.int16 or out.numel() != n * shape[1] * 384 or not out.is_contiguous():
@@ -291,16 +289,17 @@ def jpeg_entropy_u8(coef: torch.Tensor, h: int, w: int, out: Optional[torch.Tens
     made: int16 [N, MCUs, 6, 64] -> uint8 [N, out_stride], row = int32 length (-1: did not fit) then the scan;
     utils.jpeg_host.wrap_scan puts the markers around it."""
     n = coef.shape[0]
-    if coef.dtype != torch.int16 or not coef.is_contiguous() or coef.numel() != n * (h // 16) * (w // 16) * 384:
+    mcus = -(-h // 16) * -(-w // 16)
+    if coef.dtype != torch.int16 or not coef.is_contiguous() or coef.numel() != n * mcus * 384:
         raise ValueError("jpeg_entropy.coef: expected the contiguous int16 output of jpeg_fdct_quant_u8")
-    stride = int(out_stride or (4 + 3 * h * w + 4095) // 4096 * 4096)
+    stride = int(out_stride or (4 + mcus * 768 + 4095) // 4096 * 4096)
     if out is None:
         out = torch.empty((n, stride), dtype=_U8, device=coef.device)
     elif out.dtype != _U8 or tuple(out.shape) != (n, stride) or not out.is_contiguous():
         raise ValueError("jpeg_entropy.out: expected a contiguous uint8 [N, out_stride] tensor")
     nbytes = int(_lib.load().lf_jpeg_entropy_workspace(n, stride))
     ws = torch.empty(nbytes, dtype=_U8, device=coef.device)
-    _lib.call("lf_jpeg_entropy_u8", coef.data_ptr(), 3 * h * w, out.data_ptr(), stride, n, h, w, ws.data_ptr(),
+    _lib.call("lf_jpeg_entropy_u8", coef.data_ptr(), mcus * 768, out.data_ptr(), stride, n, h, w, ws.data_ptr(),
               nbytes, _stream())
     return out
 

@@ -42,8 +42,8 @@ def write_file(coef: np.ndarray, h: int, w: int, quality: int = 95) -> bytes:
     global _SCRATCH
     lib = load()
     c = np.ascontiguousarray(coef, dtype=np.int16)
-    if h % 16 or w % 16 or c.size != (h // 16) * (w // 16) * 384:
-        raise ValueError(f"write_file: {c.size} coefficients do not make a {h}x{w} image of whole MCUs")
+    if h <= 0 or w <= 0 or c.size != -(-h // 16) * -(-w // 16) * 384:
+        raise ValueError(f"write_file: {c.size} coefficients do not make the MCUs of a {h}x{w} image")
     cap = int(lib.lf_jpeg_file_bound(h, w))
     if _SCRATCH is None or _SCRATCH.size < cap:
         _SCRATCH = np.empty(cap, dtype=np.uint8)

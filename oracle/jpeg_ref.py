@@ -8,7 +8,7 @@ coefficients), jchuff.c with the Annex K tables, jcmarker.c marker order.  4:2:0
 
 PINNED: Pillow (libjpeg-turbo) is installed here, so tests/test_jpeg_oracle.py compares `encode()` with the
 BYTES Pillow writes, and every stage with the coefficients Pillow's own decoder reads back.
-Image sizes must be multiples of 16 (whole MCUs); other sizes stay with libjpeg in the product as well.
+Ragged sizes follow libjpeg's padding (edge replication, dummy blocks); the DEcoder stages here cover whole MCUs only.
 """
 from __future__ import annotations
 
@@ -137,13 +137,32 @@ def blocks_of(plane: np.ndarray) -> np.ndarray:
 
 
 def quantised_coefficients(rgb: np.ndarray, quality: int = 95):
-    """(Y [H/8, W/8, 64], Cb [H/16, W/16, 64], Cr): quantised coefficients in ZIGZAG order, int16."""
+    """(Y [2*My, 2*Mx, 64], Cb [My, Mx, 64], Cr): quantised coefficients in ZIGZAG order, int16, for the
+    My x Mx = ceil(H/16) x ceil(W/16) MCUs of the scan.  Ragged sizes as libjpeg pads them: samples are
+    replicated to the right (full resolution, before the chroma box filter) and downwards (the last luminance row;
+    the last full-resolution row up to an even count, then the last chroma row), and luminance blocks that lie
+    wholly outside the image are dummies — no AC, the DC of the previous block of their MCU (jccoefct.c)."""
     h, w, _ = rgb.shape
-    if h % 16 or w % 16:
-        raise ValueError("whole MCUs only")
+    my, mx = -(-h // 16), -(-w // 16)
+    hb, wb = -(-h // 8), -(-w // 8)          # luminance blocks that hold image samples
     ql, qc = quant_tables(quality)
     y, cb, cr = rgb_to_ycc(rgb)
-    planes = (y, h2v2_downsample(cb), h2v2_downsample(cr))
+    yi = np.minimum(np.arange(16 * my), h - 1)
+    xi = np.minimum(np.arange(16 * mx), w - 1)
+    ypad = y[yi][:, xi]
+    # chroma: columns replicated at full resolution, rows to an even count, then the last CHROMA row repeated
+    ch = -(-h // 2)
+    crow = np.minimum(np.arange(8 * my), ch - 1)
+    r0, r1 = 2 * crow, np.minimum(2 * crow + 1, h - 1)
+    c0, c1 = np.minimum(2 * np.arange(8 * mx), w - 1), np.minimum(2 * np.arange(8 * mx) + 1, w - 1)
+    bias = 1 + (np.arange(8 * mx) & 1)
+
+    def chroma(p):
+        q = p.astype(np.int64)
+        s4 = q[r0][:, c0] + q[r0][:, c1] + q[r1][:, c0] + q[r1][:, c1]
+        return ((s4 + bias) >> 2).astype(np.uint8)
+
+    planes = (ypad, chroma(cb), chroma(cr))
     out = []
     for plane, q in zip(planes, (ql, qc, qc)):
         bl = blocks_of(plane.astype(np.int64) - 128)
@@ -156,6 +175,21 @@ def quantised_coefficients(rgb: np.ndarray, quality: int = 95):
                 v = (a + (div >> 1)) // div
                 co[i, j] = (np.sign(c) * v)[ZIGZAG]
         out.append(co.astype(np.int16))
+    yc = out[0]
+    for i in range(my):          # dummy luminance blocks, MCU by MCU in buffer order Y00 Y01 Y10 Y11
+        for j in range(mx):
+            col1, row1 = 2 * j + 1 < wb, 2 * i + 1 < hb
+            if not col1:
+                yc[2 * i, 2 * j + 1] = 0
+                yc[2 * i, 2 * j + 1, 0] = yc[2 * i, 2 * j, 0]
+            if row1:
+                if not col1:
+                    yc[2 * i + 1, 2 * j + 1] = 0
+                    yc[2 * i + 1, 2 * j + 1, 0] = yc[2 * i + 1, 2 * j, 0]
+            else:
+                yc[2 * i + 1, 2 * j] = 0
+                yc[2 * i + 1, 2 * j + 1] = 0
+                yc[2 * i + 1, 2 * j, 0] = yc[2 * i + 1, 2 * j + 1, 0] = yc[2 * i, 2 * j + 1, 0]
     return tuple(out)
 
 

@@ -103,7 +103,7 @@ def test_gpu_other_quality_and_bad_shape(cuda):
     coef = ops.jpeg_fdct_quant_u8(torch.from_numpy(a[None]).to(cuda), quality=80).cpu().numpy()
     assert jpeg_host.write_file(coef[0], 64, 80, 80) == pil_bytes(a, 80)
     with pytest.raises(ValueError):
-        ops.jpeg_fdct_quant_u8(torch.zeros((1, 30, 32, 3), dtype=torch.uint8, device=cuda))
+        ops.jpeg_idct_rgb_u8(torch.zeros((1, 4096), dtype=torch.uint8, device=cuda), 30, 32)   # decoding: whole MCUs only
 
 
 # ---- reading -------------------------------------------------------------------------------------------
@@ -191,3 +191,37 @@ def test_gpu_entropy_coder_reports_a_row_that_is_too_small(cuda):
     coef = ops.jpeg_fdct_quant_u8(torch.from_numpy(a[None]).to(cuda))
     rows = ops.jpeg_entropy_u8(coef, 64, 64, out_stride=1024).cpu().numpy()
     assert int(rows[0, :4].view(np.int32)[0]) == -1
+
+
+# ---- ragged sizes (rotated outputs): libjpeg's padding ----------------------------------------------------
+RAGGED = [(17, 23), (30, 50), (100, 75), (225, 225), (224, 230), (8, 8), (1, 1), (16, 33), (31, 16), (47, 47), (291, 283)]
+
+
+def mcu_order_ragged(y, cb, cr):
+    return mcu_order(y, cb, cr)   # the oracle already returns 2*My x 2*Mx luminance blocks
+
+
+@pytest.mark.parametrize("h,w", RAGGED)
+def test_oracle_and_host_coder_on_ragged_sizes(h, w):
+    from leaffliction_amd.utils import jpeg_host
+    for a in (scene(h, w, h + w), np.random.RandomState(h * w).randint(0, 256, (h, w, 3)).astype(np.uint8)):
+        want = pil_bytes(a)
+        assert J.encode(a) == want
+        assert jpeg_host.write_file(mcu_order_ragged(*J.quantised_coefficients(a)), h, w) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", RAGGED)
+def test_gpu_encoder_on_ragged_sizes(cuda, h, w):
+    import torch
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    batch = np.stack([scene(h, w, h + w + i) if i else np.random.RandomState(h + w).randint(0, 256, (h, w, 3)).astype(np.uint8)
+                      for i in range(3)])
+    coef = ops.jpeg_fdct_quant_u8(torch.from_numpy(batch).to(cuda))
+    rows = ops.jpeg_entropy_u8(coef, h, w).cpu().numpy()
+    coef = coef.cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(coef[i], mcu_order_ragged(*J.quantised_coefficients(batch[i]))), i
+        n = int(rows[i, :4].view(np.int32)[0])
+        assert n > 0 and jpeg_host.wrap_scan(rows[i, 4:4 + n], h, w) == pil_bytes(batch[i]), i
