@@ -201,6 +201,11 @@ int lf_jpeg_idct_rgb_u8(const void* coef, size_t coef_stride, const void* qtab, 
                         uint8_t* rgb, int n, int h, int w, void* workspace, size_t ws_bytes,
                         lf_stream_t stream);
 
+/* HOST (also in libleafcodec.so): np.random.RandomState(seed).normal(loc, scale, n) — the distortion op's noise
+ * plane (srcs/preprocessing/image_augmenter.py:121-123) — from MT19937 and numpy's legacy polar Gaussian with
+ * libm's log / sqrt: out64 (optional) the float64 values, bit for bit; out8 (optional) their numpy astype(uint8). */
+int lf_legacy_normal_u8(uint32_t seed, double loc, double scale, size_t n, uint8_t* out8, double* out64);
+
 /* ------------------------------------------------------------------------- */
 /* Geometric ops (Pillow semantics, bit-exact; coordinates in IEEE double)    */
 /* ------------------------------------------------------------------------- */

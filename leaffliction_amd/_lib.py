@@ -45,6 +45,7 @@ SIGNATURES = {
     "lf_jpeg_entropy_workspace": [c_int, c_size_t],
     "lf_jpeg_entropy_u8": [P, c_size_t, P, c_size_t, c_int, c_int, c_int, P, c_size_t, P],
     "lf_jpeg_wrap_scan": [P, c_size_t, c_int, c_int, c_int, P, c_size_t],
+    "lf_legacy_normal_u8": [C.c_uint32, c_double, c_double, c_size_t, P, P],
     "lf_jpeg_decode_workspace": [c_int, c_int, c_int],
     "lf_jpeg_idct_rgb_u8": [P, c_size_t, P, c_size_t, P, c_int, c_int, c_int, P, c_size_t, P],
     "lf_inclusive_mask_workspace": [c_int, c_int, c_int],

@@ -80,7 +80,21 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
             else:
                 h, w = coef_hw
             params = None
-            if seed:   # seed 0 = "unseeded" in the reference: drawn by the parent from its global streams
+            if seed and op == "distortion" and 0 < seed < 2 ** 32:
+                # RandomState(seed).normal(0, 5, (h, w, 3)).astype(uint8) and then random.Random(seed).uniform(0, 2)
+                # (image_augmenter.py:121-127): the noise plane comes from libleafcodec's restatement of numpy's
+                # legacy stream (bit-equal, tests/test_jpeg_codec.py; 2.6 ms against numpy's 3.4 ms for 224 x 224 x 3)
+                from .image_augmenter import NOISE_LEVEL
+                params = {"cutoff": random.Random(seed).uniform(0, 2)}
+                nbytes = h * w * 3
+                if nbytes <= cap:
+                    jpeg_host.legacy_normal_u8(seed, 0.0, float(NOISE_LEVEL), np.frombuffer(buf_noise, np.uint8, nbytes, noff))
+                    params["noise8"] = None      # in the noise slab, at this task's slot
+                else:
+                    n8 = np.empty((h, w, 3), np.uint8)
+                    jpeg_host.legacy_normal_u8(seed, 0.0, float(NOISE_LEVEL), n8)
+                    params["noise8"] = n8
+            elif seed:   # seed 0 = "unseeded" in the reference: drawn by the parent from its global streams
                 params = draw_params(op, w, h, random.Random(seed), np.random.RandomState(seed))
                 if op == "distortion":
                     n8 = params.pop("noise").astype(np.uint8)   # numpy's own cast, as the reference does next

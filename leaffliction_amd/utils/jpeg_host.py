@@ -27,6 +27,8 @@ def load() -> C.CDLL:
         lib.lf_jpeg_write_file.restype = C.c_long
         lib.lf_jpeg_wrap_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         lib.lf_jpeg_wrap_scan.restype = C.c_long
+        lib.lf_legacy_normal_u8.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.lf_legacy_normal_u8.restype = C.c_int
         lib.lf_jpeg_read_file.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.lf_jpeg_read_file.restype = C.c_int
@@ -93,3 +95,20 @@ def wrap_scan(scan: np.ndarray, h: int, w: int, quality: int = 95) -> bytes:
     if n < 0:
         raise RuntimeError("lf_jpeg_wrap_scan failed")
     return out[:n].tobytes()
+
+
+def legacy_normal_u8(seed: int, loc: float, scale: float, out: np.ndarray) -> None:
+    """out[...] = np.random.RandomState(seed).normal(loc, scale, out.shape).astype(np.uint8), made in C (the same
+    MT19937 stream, numpy's legacy polar Gaussian, libm's log and sqrt): `out` is a contiguous uint8 array."""
+    if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or not (0 <= int(seed) < 2 ** 32):
+        raise ValueError("legacy_normal_u8: a contiguous uint8 array and a 32-bit seed")
+    if load().lf_legacy_normal_u8(int(seed), float(loc), float(scale), out.size, out.ctypes.data, None) != 0:
+        raise RuntimeError("lf_legacy_normal_u8 failed")
+
+
+def legacy_normal_f64(seed: int, loc: float, scale: float, n: int) -> np.ndarray:
+    """The float64 values behind legacy_normal_u8 (tests compare them with numpy's bit for bit)."""
+    out = np.empty(int(n), dtype=np.float64)
+    if load().lf_legacy_normal_u8(int(seed), float(loc), float(scale), out.size, None, out.ctypes.data) != 0:
+        raise RuntimeError("lf_legacy_normal_u8 failed")
+    return out

@@ -18,12 +18,12 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """The multi-process tests (gloo ranks, codec worker pools) get a hard limit: a lost rank or worker must
-    fail the test, not stall the run for the process group's 30-minute default."""
+    """Every test gets a hard limit (pytest-timeout, thread method: it also fires when the main thread is blocked
+    inside a C call): a lost rank or codec worker must fail the test, not stall the run for the process group's
+    30-minute default."""
     for item in items:
-        if item.fspath.basename in ("test_sharded_paths.py", "test_dp_fit.py", "test_host_logic.py", "test_pipeline_gpu.py"):
-            if item.get_closest_marker("timeout") is None:
-                item.add_marker(pytest.mark.timeout(600))
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(420, method="thread"))
 
 
 @pytest.fixture(scope="session")

@@ -225,3 +225,17 @@ def test_gpu_encoder_on_ragged_sizes(cuda, h, w):
         assert np.array_equal(coef[i], mcu_order_ragged(*J.quantised_coefficients(batch[i]))), i
         n = int(rows[i, :4].view(np.int32)[0])
         assert n > 0 and jpeg_host.wrap_scan(rows[i, 4:4 + n], h, w) == pil_bytes(batch[i]), i
+
+
+# ---- the distortion op's noise plane in C -----------------------------------------------------------------
+@pytest.mark.parametrize("seed", [1, 7, 12345, 999999, 2 ** 31 + 5, 0])
+def test_legacy_normal_equals_numpy(seed):
+    """np.random.RandomState(seed).normal(0, 5, n): the float64 stream bit for bit, and its uint8 cast."""
+    from leaffliction_amd.utils import jpeg_host
+    n = 224 * 224 * 3 if seed != 7 else 1001     # odd counts leave half a pair unused
+    want = np.random.RandomState(seed).normal(0, 5, n)
+    got = jpeg_host.legacy_normal_f64(seed, 0.0, 5.0, n)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    out = np.empty(n, np.uint8)
+    jpeg_host.legacy_normal_u8(seed, 0.0, 5.0, out)
+    assert np.array_equal(out, want.astype(np.uint8))
