@@ -130,16 +130,9 @@ class KernelTimer:
 
 
 def usable_cores() -> int:
-    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU
-    box shows every core of the host but grants a share of them)."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
-        if quota != "max":
-            n = max(1, min(n, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return n
+    """Cores this process may actually use (affinity mask capped by the cgroup CPU quota)."""
+    from leaffliction_amd.utils.system_info import get_available_cores
+    return get_available_cores()
 
 
 def cpu_baseline(seconds_budget: float = 25.0):
@@ -463,6 +456,67 @@ def inference_throughput(model, dev, batch=1024, iters=5):
     return out
 
 
+def predict_end_to_end(dev, n_files=4096):
+    """BASELINE configs[4] as a user of `predict -batch` sees it: JPEG files -> labels (Predictor.predict_batch: codec
+    worker processes Huffman-decode, the GPU does the rest of the decoding and the bf16 forward pass), next to the
+    reference's way of feeding the same model — `ImageLoader.load_as_array` in a loop on one core (predictor.py's own
+    loop, srcs/predict/predictor.py) — on a bounded sample."""
+    import shutil
+    import tempfile
+
+    from leaffliction_amd.model.cnn import LeafCNN
+    from leaffliction_amd.predict.predictor import Predictor
+    tmp = Path(tempfile.mkdtemp(prefix="lf_pred_"))
+    cwd = os.getcwd()
+    pred = None
+    try:
+        src = tmp / "images"
+        _e2e_make_dataset(src, dev, usable_cores())
+        files = sorted(str(p) for p in src.rglob("*.JPG"))[:n_files]
+        os.chdir(tmp)
+        model = LeafCNN(num_classes=NUM_CLASSES, img_size=IMG, widths=WIDTHS, drop_block=0.15, drop_top=0.40, l2_reg=1e-4,
+                        augment=True, use_se=True, seed=42, device=dev)
+        model.norm.mean[:] = 0.5
+        model.norm.variance[:] = 1.0 / 12.0
+        learn = tmp / "artifacts" / "models"
+        learn.mkdir(parents=True)
+        model.save(str(learn / "leaf_cnn.keras"))
+        (learn / "meta.json").write_text(json.dumps({"model_file": str(learn / "leaf_cnn.keras"),
+                                                     "labels": [f"class_{i}" for i in range(NUM_CLASSES)],
+                                                     "data": {"img_size": IMG}}))
+        os.environ["LEAFFLICTION_INFER_DTYPE"] = "bf16"
+        pred = Predictor(learn)
+        pred.load()
+        pred.predict_batch(files[:256])            # warm-up: worker start-up, activation buffers
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = pred.predict_batch(files)
+        torch.cuda.synchronize()
+        sec = time.perf_counter() - t0
+        serial = files[:384]
+        keep = Predictor.POOL_MIN
+        Predictor.POOL_MIN = 10 ** 9
+        try:
+            t0 = time.perf_counter()
+            ref = pred.predict_batch(serial)
+            sec_ref = time.perf_counter() - t0
+        finally:
+            Predictor.POOL_MIN = keep
+        same = all(a["top_prediction"] == b["top_prediction"] for a, b in zip(out, ref))
+        return {"images_per_sec": round(len(out) / sec, 1), "files": len(out), "seconds": round(sec, 2),
+                "dtype": "bf16", "includes": "file reads, JPEG decode (Huffman on host cores, the rest on the GPU), "
+                                             "forward pass, per-file result records with the decoded pixels",
+                "sequential_loop": {"images_per_sec": round(len(ref) / sec_ref, 1), "files": len(ref),
+                                    "kind": "the reference's loop: one Pillow decode after the other, same model"},
+                "same_labels_as_sequential_loop": bool(same)}
+    finally:
+        if pred is not None:
+            pred.close()
+        os.environ.pop("LEAFFLICTION_INFER_DTYPE", None)
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -724,6 +778,8 @@ def main() -> None:
             out["train_bf16"] = bf16
         if world == 1 and not args.no_inference:
             out["inference"] = inference_throughput(model, dev)
+            if not args.no_e2e:
+                out["inference"]["predict_end_to_end"] = predict_end_to_end(dev)
         if not args.no_augment and world == 1:
             del model
             torch.cuda.empty_cache()

@@ -6,10 +6,21 @@ import platform
 
 
 def get_available_cores() -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (a container shows every core of its host but is granted a share of them; sizing a worker
+    pool by the host count oversubscribes the share and pays hundreds of process spawns)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def get_optimal_worker_count() -> int:

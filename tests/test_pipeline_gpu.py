@@ -312,3 +312,42 @@ def test_predict_in_bf16_mode_gives_the_same_confusion_matrix(cuda, tmp_path, mo
     p32 = np.array([list(r["all_probabilities"].values()) for r in results["f32"]])
     p16 = np.array([list(r["all_probabilities"].values()) for r in results["bf16"]])
     assert 0 < np.abs(p32 - p16).max() < 3e-2
+
+
+def test_pooled_predict_batch_equals_the_sequential_loop(cuda, tmp_path, monkeypatch):
+    """predict_batch over >= 64 files decodes in codec worker processes + on the GPU: same results, order and
+    skipping as the one-by-one loop — on files it Huffman-decodes itself (whole MCUs), files it leaves to Pillow
+    (ragged size, 4:4:4), native sizes that need the LANCZOS resize, and one file that cannot be read."""
+    from PIL import Image
+
+    from leaffliction_amd.cli import train as train_cli
+    from leaffliction_amd.predict.predictor import Predictor
+    monkeypatch.chdir(tmp_path)
+    colour_tree(tmp_path / "images", 24, 64)
+    man = tmp_path / "artifacts/datasets/manifest_split.json"
+    write_split_manifest(tmp_path / "images", man)
+    train_cli.main(["--manifest", str(man), "--epochs", "1", "--batch-size", "8", "--img-size", "64",
+                    "--no-mixed-precision", "--seed", "42"])
+    rng = np.random.RandomState(0)
+    files = tmp_path / "batch"
+    files.mkdir()
+    paths = []
+    for i in range(90):
+        h, w = [(64, 64), (96, 80), (70, 50), (128, 128)][i % 4]
+        a = np.clip(rng.normal(128, 40, (h, w, 3)) + (60 if i % 2 else -60) * np.array([1, -1, 0]), 0, 255).astype(np.uint8)
+        p = files / f"im_{i:03d}.jpg"
+        Image.fromarray(a).save(p, quality=90, **({"subsampling": 0} if i % 7 == 3 else {}))
+        paths.append(str(p))
+    (files / "broken.jpg").write_bytes(b"\xff\xd8 not really a jpeg")
+    paths.insert(17, str(files / "broken.jpg"))
+    pred = Predictor(tmp_path / "artifacts/models")
+    pred.load()
+    pooled = pred.predict_batch(paths)
+    monkeypatch.setattr(Predictor, "POOL_MIN", 10 ** 9)
+    serial = pred.predict_batch(paths)
+    assert len(pooled) == len(serial) == 90
+    for a, b in zip(pooled, serial):
+        assert str(a["image_path"]) == str(b["image_path"]) and a["top_prediction"] == b["top_prediction"]
+        assert np.array_equal(a["original_array"], b["original_array"])
+        pa, pb = np.array(list(a["all_probabilities"].values())), np.array(list(b["all_probabilities"].values()))
+        assert np.abs(pa - pb).max() < 1e-6
