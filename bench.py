@@ -503,12 +503,35 @@ def predict_end_to_end(dev, n_files=4096):
         finally:
             Predictor.POOL_MIN = keep
         same = all(a["top_prediction"] == b["top_prediction"] for a, b in zip(out, ref))
+        # the training loader's side of the same step: filling ManifestSequence's HBM dataset cache (cache=True)
+        from leaffliction_amd.dataio.manifest import ManifestItem
+        from leaffliction_amd.dataio.sequence import ManifestSequence
+        items = [ManifestItem(str(i), "p", "c", "c", "train", Path(f)) for i, f in enumerate(files)]
+        t0 = time.perf_counter()
+        seq = ManifestSequence(items, None, IMG, BATCH, False, 0, cache=True)
+        torch.cuda.synchronize()
+        sec_fill = time.perf_counter() - t0
+        keep = ManifestSequence.POOL_MIN
+        ManifestSequence.POOL_MIN = 10 ** 9
+        try:
+            t0 = time.perf_counter()
+            seq_host = ManifestSequence(items[:384], None, IMG, BATCH, False, 0, cache=True)
+            torch.cuda.synchronize()
+            sec_fill_host = time.perf_counter() - t0
+        finally:
+            ManifestSequence.POOL_MIN = keep
+        same_cache = bool(torch.equal(seq._cache_dev[:384], seq_host._cache_dev))
         return {"images_per_sec": round(len(out) / sec, 1), "files": len(out), "seconds": round(sec, 2),
                 "dtype": "bf16", "includes": "file reads, JPEG decode (Huffman on host cores, the rest on the GPU), "
                                              "forward pass, per-file result records with the decoded pixels",
                 "sequential_loop": {"images_per_sec": round(len(ref) / sec_ref, 1), "files": len(ref),
                                     "kind": "the reference's loop: one Pillow decode after the other, same model"},
-                "same_labels_as_sequential_loop": bool(same)}
+                "same_labels_as_sequential_loop": bool(same),
+                "loader_cache_fill": {"images_per_sec": round(len(items) / sec_fill, 1), "files": len(items),
+                                      "includes": "codec worker start-up, file reads, JPEG decode, upload into the "
+                                                  "HBM-resident uint8 dataset (ManifestSequence cache=True)",
+                                      "host_loop_images_per_sec": round(384 / sec_fill_host, 1),
+                                      "same_pixels_as_host_loop": same_cache}}
     finally:
         if pred is not None:
             pred.close()

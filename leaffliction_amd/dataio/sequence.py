@@ -12,7 +12,9 @@ NHWC host array instead).  For data-parallel training pass `rank`/`world`: every
 the same permutation and takes the rank-strided slice of each global batch.  With
 `cache=True` (and device batches) the resized uint8 dataset lives in HBM — 150 KB per 224x224
 image, so even 100 k images are 15 GB of the 288 GB — and a batch is one gather kernel; there
-is no per-step decode, host stack or PCIe upload.
+is no per-step decode, host stack or PCIe upload.  Device batches of `POOL_MIN` files or more
+(and the filling of that cache) go through `dataio/device_decode.py`: codec worker processes
+Huffman-decode the JPEGs, the GPU finishes the decoding and resizes — Pillow's pixels, bit for bit.
 """
 from __future__ import annotations
 
@@ -56,6 +58,7 @@ class ManifestSequence:
         self.rank, self.world = int(rank), max(1, int(world))
         self._cache_u8: Dict[int, np.ndarray] = {}
         self._cache_dev = None  # uint8 device tensor [N,S,S,3] (cache=True, device batches)
+        self._decoder = None    # DeviceDecoder (device batches of POOL_MIN files or more)
         if self.shuffle:
             self.rng.shuffle(self.indexes)
         if self.cache:
@@ -125,6 +128,37 @@ class ManifestSequence:
             fresh = {}
         return np.stack([self._cache_u8[i] if i in self._cache_u8 else fresh[i] for i in idxs])
 
+    POOL_MIN = 64   # below this many files the worker pool costs more than it saves
+
+    def _load_dev(self, idxs: List[int]):
+        """uint8 device tensor [B,S,S,3] for the given item indexes: pooled decode + GPU JPEG back end
+        when the batch is large enough, else the host path and one upload.  An unreadable file raises,
+        as the reference's loader does (image_utils.py:19-33)."""
+        import torch
+        if self.transform is not None or len(idxs) < self.POOL_MIN or any(i in self._cache_u8 for i in idxs):
+            return torch.from_numpy(self._load_u8(idxs)).cuda()
+        from .device_decode import DeviceDecoder
+        if self._decoder is None:
+            self._decoder = DeviceDecoder(self.workers if self.workers > 1 else None)
+        parts = []
+        for _first, _kept, x, _nat, errors in self._decoder.chunks([self.items[i].src for i in idxs], self.img_size):
+            if errors:
+                raise OSError(f"Cannot load image {errors[0][1]}")
+            parts.append(x)
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+    def close(self) -> None:
+        """Stop the decoder's worker processes (idempotent; also done when the sequence is collected)."""
+        dec, self._decoder = self._decoder, None
+        if dec is not None:
+            dec.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 — interpreter shutdown
+            pass
+
     def _build_cache(self) -> None:
         step = max(64, self.batch_size)
         dev_ok = not self.as_numpy and len(self.items) > 0
@@ -141,11 +175,13 @@ class ManifestSequence:
         self._cache_dev = torch.empty((len(self.items), S, S, 3), dtype=torch.uint8, device="cuda")
         keep, self.cache = self.cache, False  # _load_u8 must not also fill the host cache
         try:
+            step = max(step, 4096)
             for b in range(0, len(self.items), step):
                 e = min(b + step, len(self.items))
-                self._cache_dev[b:e].copy_(torch.from_numpy(self._load_u8(list(range(b, e)))))
+                self._cache_dev[b:e].copy_(self._load_dev(list(range(b, e))))
         finally:
             self.cache = keep
+            self.close()   # the cache is complete: nothing is decoded after this
 
     def batch_indexes(self, idx: int) -> List[int]:
         start = idx * self.batch_size
@@ -173,13 +209,18 @@ class ManifestSequence:
             if self.label2idx is None:
                 return X
             return X, np.asarray([self._label(i) for i in batch_idx])
-        x_u8 = self._load_u8(batch_idx) if batch_idx else np.zeros(
-            (0, self.img_size, self.img_size, 3), np.uint8)
+        if self.as_numpy or not batch_idx:
+            x_u8 = self._load_u8(batch_idx) if batch_idx else np.zeros(
+                (0, self.img_size, self.img_size, 3), np.uint8)
+            if not self.as_numpy:
+                import torch
+                x_u8 = torch.from_numpy(x_u8).cuda()
+        else:
+            x_u8 = self._load_dev(batch_idx)
         if self.as_numpy:
             X = x_u8.astype(np.float32) / 255.0  # normalize_array (image_utils.py:117-130)
         else:
-            import torch
-            X = torch.from_numpy(x_u8).cuda()
+            X = x_u8
         if self.label2idx is None:
             return X
         y = np.asarray([self._label(i) for i in batch_idx])

@@ -25,7 +25,7 @@ class Predictor:
         self.learnings_dir = Path(learnings_dir)
         self.model_loader = None
         self._initialized = False
-        self._codec = None   # (CodecPool, slot_bytes, chunk, pinned, device staging) of the pooled batch path
+        self._codec = None   # DeviceDecoder of the pooled batch path
 
     def load(self):
         self.model_loader = ModelLoader(self.learnings_dir)
@@ -66,90 +66,25 @@ class Predictor:
     POOL_MIN = 64   # below this many files the worker pool costs more than it saves
 
     def _predict_batch_pooled(self, paths: List[Path]) -> List[Dict[str, Any]]:
-        """The batch path with the decoding spread out: codec worker processes Huffman-decode the files into
-        page-locked slabs (or decode them whole with Pillow when they are not baseline 4:2:0 JPEGs of whole MCUs),
-        the GPU does dequantisation / IDCT / upsampling / colour, the LANCZOS resize and the forward pass, chunk
-        after chunk with the next chunk's files already being read.  Same results, same order, same skipping of
-        unreadable files as the sequential loop (the pixels are Pillow's, bit for bit: tests/test_jpeg_codec.py)."""
+        """The batch path with the decoding spread out (dataio/device_decode.py: codec worker processes
+        Huffman-decode the files, the GPU finishes the JPEG decoding and resizes) and the forward pass run chunk
+        after chunk.  Same results, same order, same skipping of unreadable files as the sequential loop
+        (the pixels are Pillow's, bit for bit: tests/test_jpeg_codec.py)."""
         import torch
-        from PIL import Image
 
-        from .. import ops
-        from ..preprocessing.codec_pool import CodecPool
-        from ..utils.system_info import get_optimal_worker_count
-        S = self.model_loader.img_size
+        from ..dataio.device_decode import DeviceDecoder
         model = self.model_loader.model
-        dev = torch.device("cuda", torch.cuda.current_device())
-        n_chunk = 256
-        w0 = h0 = S
-        for p in paths[:8]:   # slot size from the first readable file (larger images travel as pickled arrays)
-            try:
-                with Image.open(p) as probe:
-                    w0, h0 = probe.size
-                break
-            except Exception:  # noqa: BLE001
-                continue
-        slot = (256 + h0 * w0 * 3 + 4095) // 4096 * 4096
-        if self._codec is not None and (self._codec[1] < slot or self._codec[2] < n_chunk):
-            self.close()
-        if self._codec is None:   # the worker processes and their slabs outlive the call: starting them costs
-            pool = CodecPool(get_optimal_worker_count())   # as much as decoding a thousand files
-            pool.allocate(3 * n_chunk, slot)
-            self._codec = (pool, slot, n_chunk, pool.pin(),
-                           torch.empty((n_chunk, slot), dtype=torch.uint8, device=dev))
-        pool, slot, n_chunk, pinned, dev_in = self._codec
-        chunks = [paths[b:b + n_chunk] for b in range(0, len(paths), n_chunk)]
+        if self._codec is None:
+            self._codec = DeviceDecoder()
         results: List[Dict[str, Any]] = []
-        try:
-
-            def submit(i):
-                tasks = [{"source_img": str(p), "transform_name": "", "seed": 0} for p in chunks[i]]
-                return pool.decode(tasks, (i % 3) * n_chunk, True)
-
-            ahead = [submit(0)] + ([submit(1)] if len(chunks) > 1 else [])
-            for i, chunk in enumerate(chunks):
-                decoded = [r for f in ahead.pop(0) for r in f.result()]
-                if i + 2 < len(chunks):
-                    ahead.append(submit(i + 2))
-                n, base = len(chunk), (i % 3) * n_chunk
-                host = pool.tensor("in", base, n)
-                dev_in[:n].copy_(host if pinned else host.clone(), non_blocking=pinned)
-                groups: Dict[tuple, List[int]] = {}
-                big: Dict[int, np.ndarray] = {}
-                for k, (status, payload, _prm) in enumerate(decoded):
-                    if status == "err":
-                        logger.error(f"Error processing image {payload}")
-                        continue
-                    if status == "big":
-                        big[k] = payload
-                        groups.setdefault(("big",) + tuple(payload.shape[:2]), []).append(k)
-                    else:
-                        groups.setdefault((status,) + tuple(payload[:2]), []).append(k)
-                originals: Dict[int, np.ndarray] = {}
-                x = torch.empty((n, S, S, 3), dtype=torch.uint8, device=dev)
-                for (status, h, w), ks in groups.items():
-                    idx = torch.tensor(ks, dtype=torch.int64, device=dev)
-                    if status == "coef":
-                        px = ops.jpeg_idct_rgb_u8(dev_in[idx], h, w)
-                    elif status == "ok":
-                        px = dev_in[idx, :h * w * 3].view(len(ks), h, w, 3)
-                    else:
-                        px = torch.from_numpy(np.stack([big[k] for k in ks])).to(dev)
-                    x[idx] = px if (h, w) == (S, S) else ops.resize_lanczos_u8(px.contiguous(), S)
-                    host_px = px.cpu().numpy()
-                    for j, k in enumerate(ks):
-                        originals[k] = host_px[j]
-                valid = sorted(originals)
-                if not valid:
-                    continue
-                vi = torch.tensor(valid, dtype=torch.int64, device=dev)
-                probs = torch.cat([model.predict_device(x[vi][b:b + 1024]).clone()
-                                   for b in range(0, len(valid), 1024)]).cpu().numpy()
-                results += [self._result(chunk[k], originals[k], probs[j]) for j, k in enumerate(valid)]
-        except BaseException:
-            decoded = host = None
-            self.close()   # a failed chunk may leave jobs in flight on the slabs: start afresh next time
-            raise
+        for _first, kept, x, natives, errors in self._codec.chunks(paths, self.model_loader.img_size, keep_native=True):
+            for _k, message in errors:
+                logger.error(f"Error processing image {message}")
+            if not kept:
+                continue
+            probs = torch.cat([model.predict_device(x[b:b + 1024]).clone()
+                               for b in range(0, len(kept), 1024)]).cpu().numpy()
+            results += [self._result(paths[k], natives[k], probs[j]) for j, k in enumerate(kept)]
         if not results:
             logger.warning("No valid images to predict.")
         return results
@@ -158,7 +93,7 @@ class Predictor:
         """Stop the codec workers of the pooled batch path and release their slabs (idempotent)."""
         codec, self._codec = self._codec, None
         if codec is not None:
-            codec[0].close()
+            codec.close()
 
     def __del__(self):
         try:

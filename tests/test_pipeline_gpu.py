@@ -351,3 +351,39 @@ def test_pooled_predict_batch_equals_the_sequential_loop(cuda, tmp_path, monkeyp
         assert np.array_equal(a["original_array"], b["original_array"])
         pa, pb = np.array(list(a["all_probabilities"].values())), np.array(list(b["all_probabilities"].values()))
         assert np.abs(pa - pb).max() < 1e-6
+
+
+def test_pooled_loader_batches_and_cache_equal_the_host_loader(cuda, tmp_path, monkeypatch):
+    """Device batches of >= POOL_MIN files (and the HBM cache's filling) are decoded by the codec workers + the
+    GPU JPEG back end: same uint8 batches as Pillow decode + host stack, over mixed native sizes, 4:4:4 and
+    progressive files; an unreadable file raises as the reference's loader does."""
+    import torch
+    from PIL import Image
+
+    from leaffliction_amd.dataio.manifest import ManifestItem
+    from leaffliction_amd.dataio.sequence import ManifestSequence
+    rng = np.random.RandomState(3)
+    items = []
+    for i in range(150):
+        h, w = [(64, 64), (96, 80), (70, 50), (48, 48)][i % 4]
+        a = leaf_like(h, w, i) if i % 3 else rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        p = tmp_path / (f"im_{i:03d}.jpg" if i % 11 == 5 else f"im_{i:03d}.JPG")
+        Image.fromarray(a).save(p, quality=95, progressive=(i % 11 == 5), **({"subsampling": 0} if i % 7 == 3 else {}))
+        items.append(ManifestItem(f"id{i}", "plant", f"c{i % 3}", f"c{i % 3}", "train", p))
+    l2i = {"c0": 0, "c1": 1, "c2": 2}
+    pooled = ManifestSequence(items, l2i, 48, 75, True, 5, num_classes=3)
+    monkeypatch.setattr(ManifestSequence, "POOL_MIN", 10 ** 9)
+    host = ManifestSequence(items, l2i, 48, 75, True, 5, num_classes=3)
+    monkeypatch.undo()
+    assert pooled.POOL_MIN == 64
+    for i in range(len(host)):
+        (xa, ya), (xb, yb) = host[i], pooled[i]
+        assert xb.is_cuda and xb.dtype == torch.uint8 and torch.equal(xa, xb) and np.array_equal(ya, yb)
+    assert pooled._decoder is not None
+    pooled.close()
+    cached = ManifestSequence(items, l2i, 48, 75, False, 5, num_classes=3, cache=True)
+    assert cached._decoder is None and torch.equal(
+        cached._cache_dev, torch.cat([host._load_dev(list(range(b, min(b + 50, 150)))) for b in range(0, 150, 50)]))
+    Path(items[20].src).write_bytes(b"\xff\xd8 not a jpeg")
+    with pytest.raises(OSError):
+        ManifestSequence(items, l2i, 48, 150, False, 5, num_classes=3)[0]
