@@ -27,12 +27,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
 constexpr int kTW = 32;            // output tile width; height = 4 waves x NB rows
 constexpr int kPW = 40;           // patch row pitch in dwords: columns x0-4 .. x0+35
+constexpr int kKC = 2;             // 16-channel k-steps per staged chunk (32 input channels)
+constexpr int kMaxPrologueCin = 512;   // input channels a fused prologue (scale, shift) may have
 
 struct Bf16ConvArgs {
     const void* x;   // fp32 or bf16 NCHW (template XBF)
     const uint16_t* wprep;
     void* y;         // fp32 or bf16 NCHW (template YBF)
-    int n, cin, h, w, cout, chunks;
+    int n, cin, h, w, cout, chunks, chunks16;   // staged chunks (32 channels); 16-channel slices of wprep
     const float* in_scale;
     const float* in_shift;
     int in_relu;
@@ -85,20 +87,25 @@ __device__ __forceinline__ uint16_t bf16_down(float v) { return __builtin_bit_ca
 // (three or four workgroups per CU would need <= 168 / 128 registers: the spills cost more than the
 // occupancy brings — 40.4 k and 24.5 k img/s against 47.3 k for the whole forward pass)
 template <int TAPS, int NCO, int NB, bool XBF, bool YBF, bool TR = false, bool WIDE = false>
-__global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_bf16_kernel(Bf16ConvArgs p) {
     static_assert(!WIDE || (YBF && NCO == 2 && NB == 2), "the 16-byte epilogue: bf16 output, 32x8 tile");
     static_assert(!TR || YBF, "the training epilogue stores bf16");
     constexpr int kTH = 4 * NB;
     constexpr int R = TAPS == 9 ? 1 : 0, PH = kTH + 2 * R, KS = TAPS == 9 ? 3 : 1;
     // one LDS buffer: input patch | weight slice; the training epilogue's transpose buffer (fp32
     // [32 channels][256 pixels]) reuses it once the chunk loop is done
-    constexpr int kPatchB = 8 * PH * kPW * 4, kWlB = TAPS * NCO * 32 * 2 * 16;
+    constexpr int KC = kKC;   // 16-channel k-steps staged per barrier pair
+    constexpr int kPatchB = KC * 8 * PH * kPW * 4, kWlB = KC * TAPS * NCO * 32 * 2 * 16;
     constexpr bool kWide = WIDE;   // bf16 output, 32x8 tile, w % 8 == 0: 16-byte epilogue through LDS
     constexpr int kSmemB = (kWide && kPatchB + kWlB < 32 * 256 * 4) ? 32 * 256 * 4 : kPatchB + kWlB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kSmemB];
     uint32_t (*patch)[PH][kPW] = reinterpret_cast<uint32_t (*)[PH][kPW]>(smem);
     lf::u32x4* wl = reinterpret_cast<lf::u32x4*>(smem + kPatchB);
     __shared__ float eps[2][NCO * 32];  // epilogue scale / shift of this workgroup's output channels
+    // The prologue's per-channel scale / shift, read from LDS while staging: fetched from global memory there
+    // (one dependent round trip per staged channel pair, between the two barriers of every chunk) they were
+    // what the kernel waited for.
+    __shared__ float lsc[2][kMaxPrologueCin];
     // XCD-aware order (see lf_conv.hip): XCD k walks the k-th contiguous share of the
     // (tile, channel group, image) space, so tiles that share halo rows meet in one L2
     const unsigned gxy = gridDim.x * gridDim.y, gtotal = gxy * gridDim.z;
@@ -114,8 +121,6 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     const int co0 = cog * (NCO * 32);
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, px = lane & 31, half = lane >> 5;
     const size_t hw = (size_t)p.h * p.w;
-    const float* xn = static_cast<const float*>(p.x) + (XBF ? 0 : (size_t)n * p.cin * hw);
-    const uint16_t* xb = static_cast<const uint16_t*>(p.x) + (XBF ? (size_t)n * p.cin * hw : 0);
 
     f32x16 acc[NB][NCO];
 #pragma unroll
@@ -125,12 +130,18 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued
-    // before the MFMAs of chunk c and land in LDS after them, so their latency hides behind the
-    // matrix work instead of standing between two barriers.
-    constexpr int kPatchItems = 8 * PH * (kPW / 4);
+    // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before
+    // the MFMAs of chunk c and land in LDS after them.  A chunk is 32 input channels (two MFMA k-steps per
+    // tap): measured on 128->128 @56, batch 256 (scripts/microbench/conv_modes.py, ablation builds), the
+    // matrix phase alone takes 212 us and the loads + LDS stores alone 190 us, but with 16-channel chunks
+    // (31 KB in flight per workgroup, two workgroups per CU, one MFMA phase of ~0.5 us to land in) the two
+    // added up to 547 us: the L2 -> CU path needs more bytes in flight, for longer, to run at its rate.
+    // The loads are buffer loads: an offset past the end of the resource returns zero WITHOUT a memory
+    // access, which gives the image border, the channel padding and the chunk past the last for free and
+    // keeps every load unconditional.
+    constexpr int kPatchItems = KC * 8 * PH * (kPW / 4);
     constexpr int NP = (kPatchItems + kThreads - 1) / kThreads;
-    constexpr int kWItems = TAPS * NCO * 64;
+    constexpr int kWItems = KC * TAPS * NCO * 64;
     constexpr int NW = (kWItems + kThreads - 1) / kThreads;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     struct Raw {  // four pixels of one channel as loaded
@@ -139,11 +150,18 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     };
     Raw ra[NP], rb[NP];
     lf::u32x4 rw[NW];
+    constexpr unsigned kEl = XBF ? 2u : 4u;   // bytes per input element
+    const unsigned plane_b = (unsigned)hw * kEl;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(static_cast<const unsigned char*>(p.x)) + (size_t)n * p.cin * hw * kEl, 0,
+        (unsigned)p.cin * plane_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(p.wprep), 0, (unsigned)((size_t)p.chunks16 * TAPS * p.cout * 32), 0x00020000);
 
     // Per-slot geometry does not depend on the chunk.  A slot's flat index (pair plane, patch row,
     // column group) is also its LDS position / 4, so only the global side needs a register: the
-    // element offset of its four pixels inside a channel plane, or kOutside.
-    constexpr unsigned kOutside = 0xffffffffu;
+    // byte offset of its four pixels inside a channel plane, or kOutside (past every resource).
+    constexpr unsigned kOutside = 0x80000000u;
     unsigned g_off[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -153,30 +171,32 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
         const int gy = y0 - R + row, gx = x0 - 4 + 4 * q;
         // w % 4 == 0: a group of four columns is inside the image or outside it as a whole
         const bool inside = it < kPatchItems && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-        g_off[k] = inside ? (unsigned)gy * (unsigned)p.w + (unsigned)gx : kOutside;
+        g_off[k] = inside ? ((unsigned)gy * (unsigned)p.w + (unsigned)gx) * kEl : kOutside;
     }
     auto plane_of = [&](int k) { return (tid + k * kThreads) / (PH * (kPW / 4)); };
-    auto load_raw = [&](Raw& r, int ci, size_t off) {
+    auto load_raw = [&](Raw& r, unsigned off) {
         if (XBF)
-            r.h = *reinterpret_cast<const u32x2*>(xb + (size_t)ci * hw + off);
+            r.h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
         else
-            r.f = *reinterpret_cast<const f32x4v*>(xn + (size_t)ci * hw + off);
+            r.f = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
     };
+    const unsigned wchunk_b = (unsigned)(TAPS * p.cout * 32);   // one 16-channel slice of the packed weights
     auto issue = [&](int c) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            if (g_off[k] == kOutside) continue;
-            const int ci0 = c * 16 + 2 * plane_of(k);
-            if (ci0 < p.cin) load_raw(ra[k], ci0, g_off[k]);
-            if (ci0 + 1 < p.cin) load_raw(rb[k], ci0 + 1, g_off[k]);
+            // channel >= cin (padding of the last chunk, or the chunk past the last): past the resource
+            const unsigned o = (unsigned)(c * (16 * KC) + 2 * plane_of(k)) * plane_b + g_off[k];
+            load_raw(ra[k], g_off[k] == kOutside ? kOutside : o);
+            load_raw(rb[k], g_off[k] == kOutside ? kOutside : o + plane_b);
         }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             const int it = tid + k * kThreads;
-            if (it >= kWItems) break;
-            const int tap = it / (NCO * 64), rem = it - tap * (NCO * 64);
-            const size_t src = (((size_t)c * TAPS + tap) * p.cout + co0 + (rem >> 1)) * 16 + 8 * (rem & 1);
-            rw[k] = *reinterpret_cast<const lf::u32x4*>(p.wprep + src);
+            const int kk = it / (TAPS * NCO * 64), r1 = it - kk * (TAPS * NCO * 64);
+            const int tap = r1 / (NCO * 64), rem = r1 - tap * (NCO * 64);
+            const unsigned o = (unsigned)(c * KC + kk) * wchunk_b +
+                               (unsigned)((tap * p.cout + co0 + (rem >> 1)) * 32 + 16 * (rem & 1));
+            rw[k] = __builtin_bit_cast(lf::u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, it < kWItems ? o : kOutside, 0, 0));
         }
     };
     auto widen = [&](const Raw& r, int ci) -> f32x4v {  // fp32 values with the fused prologue applied
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
             v = r.f;
         }
         if (p.in_scale) {
-            const float sc = p.in_scale[ci], sh = p.in_shift[ci];
+            const float sc = lsc[0][ci], sh = lsc[1][ci];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
         }
@@ -205,19 +225,18 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             if (tid + k * kThreads >= kPatchItems) continue;
-            const bool inside = g_off[k] != kOutside;
-            const int ci0 = c * 16 + 2 * plane_of(k);
+            const int ci0 = c * (16 * KC) + 2 * plane_of(k);
             lf::u32x4 o;
             if (passthrough) {
-                // the stored values are the operands: interleave the two channels' bf16 pixels
-                u32x2 a = {0u, 0u}, b = {0u, 0u};  // padding stays exactly zero
-                if (inside && ci0 < p.cin) a = ra[k].h;
-                if (inside && ci0 + 1 < p.cin) b = rb[k].h;
+                // the stored values are the operands (what was not loaded is exactly zero): interleave the
+                // two channels' bf16 pixels
+                const u32x2 a = ra[k].h, b = rb[k].h;
                 o.x = (a.x & 0xffffu) | (b.x << 16);
                 o.y = (a.x >> 16) | (b.x & 0xffff0000u);
                 o.z = (a.y & 0xffffu) | (b.y << 16);
                 o.w = (a.y >> 16) | (b.y & 0xffff0000u);
             } else {
+                const bool inside = g_off[k] != kOutside;   // the prologue must not touch the padding
                 f32x4v a = {0.0f, 0.0f, 0.0f, 0.0f}, b = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (inside && ci0 < p.cin) a = widen(ra[k], ci0);
                 if (inside && ci0 + 1 < p.cin) b = widen(rb[k], ci0 + 1);
@@ -236,6 +255,11 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
         }
     };
 
+    if (p.in_scale)   // read back after the first barrier of the chunk loop
+        for (int c = tid; c < p.cin; c += kThreads) {
+            lsc[0][c] = p.in_scale[c];
+            lsc[1][c] = p.in_shift[c];
+        }
     if (p.out_scale && tid < NCO * 32) {  // read back after the chunk loop's barriers
         eps[0][tid] = p.out_scale[co0 + tid];
         eps[1][tid] = p.out_shift[co0 + tid];
@@ -272,27 +296,29 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_kernel(Bf16ConvArgs p) {
     for (int c = 0; c < p.chunks; ++c) {
         __syncthreads();  // the previous chunk's LDS reads are done
         commit(c);
-        if (c + 1 < p.chunks) issue(c + 1);
+        issue(c + 1);     // past the last chunk: no memory access
         __syncthreads();
         // One B operand (a patch row shifted by dx) serves every (output row, dy) pair that reads
         // it: NB + KS - 1 LDS fetches per dx instead of NB * KS.
 #pragma unroll
-        for (int dx = 0; dx < KS; ++dx) {
+        for (int kd = 0; kd < KC * KS; ++kd) {
+            const int kk = kd / KS, dx = kd - kk * KS;
             bf16x8 A[KS][NCO];
 #pragma unroll
             for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
                 for (int cb = 0; cb < NCO; ++cb)
-                    A[dy][cb] = __builtin_bit_cast(bf16x8, wl[(((dy * KS + dx) * NCO + cb) * 32 + px) * 2 + half]);
+                    A[dy][cb] = __builtin_bit_cast(
+                        bf16x8, wl[((((kk * KS + dy) * KS + dx) * NCO + cb) * 32 + px) * 2 + half]);
             const int col = 4 + px + dx - R;
 #pragma unroll
             for (int prow = 0; prow < NB + KS - 1; ++prow) {
                 const int row = NB * wv + prow;
                 lf::u32x4 bv;
-                bv.x = patch[4 * half + 0][row][col];
-                bv.y = patch[4 * half + 1][row][col];
-                bv.z = patch[4 * half + 2][row][col];
-                bv.w = patch[4 * half + 3][row][col];
+                bv.x = patch[8 * kk + 4 * half + 0][row][col];
+                bv.y = patch[8 * kk + 4 * half + 1][row][col];
+                bv.z = patch[8 * kk + 4 * half + 2][row][col];
+                bv.w = patch[8 * kk + 4 * half + 3][row][col];
                 const bf16x8 B = __builtin_bit_cast(bf16x8, bv);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -646,6 +672,8 @@ int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y
     LF_REQUIRE(w % 4 == 0, "lf_conv2d_bf16: width must be a multiple of 4 (got %d)", w);
     LF_REQUIRE(cout % 32 == 0, "lf_conv2d_bf16: cout must be a multiple of 32 (got %d)", cout);
     LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "lf_conv2d_bf16: scale/shift must both be set");
+    LF_REQUIRE(in_scale == nullptr || cin <= kMaxPrologueCin,
+               "lf_conv2d_bf16: a fused prologue takes at most %d input channels (got %d)", kMaxPrologueCin, cin);
     LF_REQUIRE((out_scale == nullptr) == (out_shift == nullptr),
                "lf_conv2d_bf16: out_scale/out_shift must both be set");
     LF_REQUIRE((size_t)h * w < ((size_t)1 << 32), "lf_conv2d_bf16: plane too large");
@@ -667,7 +695,8 @@ int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y
     }
     Bf16ConvArgs a{};
     a.x = x; a.wprep = wprep; a.y = y; a.n = n; a.cin = cin; a.h = h; a.w = w; a.cout = cout;
-    a.chunks = (cin + 15) / 16;
+    a.chunks16 = (cin + 15) / 16;
+    a.chunks = (a.chunks16 + kKC - 1) / kKC;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
     a.out_scale = out_scale; a.out_shift = out_shift; a.out_relu = out_relu;
     if (x_bf16) {
@@ -695,6 +724,8 @@ int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint1
     LF_REQUIRE(w % 4 == 0, "lf_conv2d_bf16_train: width must be a multiple of 4 (got %d)", w);
     LF_REQUIRE(cout % 32 == 0, "lf_conv2d_bf16_train: cout must be a multiple of 32 (got %d)", cout);
     LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "lf_conv2d_bf16_train: scale/shift must both be set");
+    LF_REQUIRE(in_scale == nullptr || cin <= kMaxPrologueCin,
+               "lf_conv2d_bf16_train: a fused prologue takes at most %d input channels (got %d)", kMaxPrologueCin, cin);
     LF_REQUIRE((size_t)h * w < ((size_t)1 << 32), "lf_conv2d_bf16_train: plane too large");
     LF_REQUIRE(n <= 65535, "lf_conv2d_bf16_train: batch too large for grid.z");
     LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wprep)) & 15) == 0,
@@ -722,7 +753,8 @@ int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint1
     }
     Bf16ConvArgs a{};
     a.x = x; a.wprep = wprep; a.y = y; a.n = n; a.cin = cin; a.h = h; a.w = w; a.cout = cout;
-    a.chunks = (cin + 15) / 16;
+    a.chunks16 = (cin + 15) / 16;
+    a.chunks = (a.chunks16 + kKC - 1) / kKC;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
     a.accumulate = accumulate;
     a.stat_part = tile_part; a.stat_pivot = pivot;
