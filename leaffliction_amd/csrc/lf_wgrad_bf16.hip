@@ -94,6 +94,10 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ float lbn[5 * 32 * COB];
     __shared__ float lsc[2 * 32 * CIB];
+    // per-(image, channel) factors of the gradient (the SE gate and its additive term) of the image being staged:
+    // fetched from global memory where they are used they were a dependent round trip inside every commit
+    __shared__ float lal[2 * 32 * COB];
+    int lal_n = -1;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tr = wv % ROWS, wrest = wv / ROWS;  // filter row of this wave; its (sub-block, K share)
@@ -221,6 +225,17 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
         unsigned char* ld = lx + S::XBYTES;
         int n, tx0, ty0;
         tile_of(item, n, tx0, ty0);
+        if (bn && p.bn_alpha != nullptr && n != lal_n) {   // uniform: a workgroup's items run through the images in order
+            __syncthreads();   // nobody still reads the previous image's factors
+            for (int c = tid; c < 32 * COB; c += kT) {
+                const bool in = co0 + c < p.cout;
+                lal[c] = in ? p.bn_alpha[(size_t)n * p.cout + co0 + c] : 1.f;
+                lal[32 * COB + c] = in && p.bn_add ? p.bn_add[(size_t)n * p.cout + co0 + c] : 0.f;
+            }
+            __syncthreads();
+            lal_n = n;
+        }
+        const bool gated = p.bn_alpha != nullptr;
         // ---- dY (optionally the BatchNorm backward of g), stored transposed; dy_out on the side
 #pragma unroll
         for (int k = 0; k < DPT; ++k) {
@@ -248,8 +263,7 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
                     if (bn) {
                         const float c0 = lbn[c], c1 = lbn[32 * COB + c], c2 = lbn[64 * COB + c],
                                     c3 = lbn[96 * COB + c], c4 = lbn[128 * COB + c];
-                        const float al = p.bn_alpha ? p.bn_alpha[(size_t)n * p.cout + co0 + c] : 1.f;
-                        const float ad = p.bn_add ? p.bn_add[(size_t)n * p.cout + co0 + c] : 0.f;
+                        const float al = gated ? lal[c] : 1.f, ad = gated ? lal[32 * COB + c] : 0.f;
 #pragma unroll
                         for (int e = 0; e < G; ++e) {
                             const unsigned yw = ry[k][i][e / 2];
