@@ -22,7 +22,9 @@ class DeviceDecoder:
     `kept` = positions (into `paths`) that decoded, in order; `x` = uint8 device tensor [len(kept), S, S, 3];
     `natives` = the decoded images at their own size (host arrays, `keep_native=True` only, else None);
     `errors` = [(position, message)] for the files that did not decode.  The worker processes and their
-    slabs live until `close()`: starting them costs as much as decoding a thousand files."""
+    slabs live until `close()`: starting them costs as much as decoding a thousand files.
+    `submit(paths, img_size)` / `collect(handle)` split one batch into its worker half and its device half, so a
+    loader can have the next batch's files decoding while the current one trains."""
 
     CHUNK = 256
 
@@ -30,6 +32,9 @@ class DeviceDecoder:
         from ..utils.system_info import get_optimal_worker_count
         self.workers = int(workers or get_optimal_worker_count())
         self._codec = None   # (CodecPool, slot_bytes, pinned, device staging)
+        self._pending: List[dict] = []   # submitted, not yet collected batches (at most two)
+        self._uploaded = [None, None, None]   # per slab third: event behind its last (asynchronous) upload
+        self._ring = 0                   # next slab third `submit` uses
 
     def _ensure(self, slot: int):
         import torch
@@ -57,72 +62,147 @@ class DeviceDecoder:
                 continue
         return (256 + h0 * w0 * 3 + 4095) // 4096 * 4096
 
-    def chunks(self, paths: Sequence, img_size: int, keep_native: bool = False) -> Iterator[
-            Tuple[int, List[int], "object", Optional[Dict[int, np.ndarray]], List[Tuple[int, str]]]]:
+    def _submit(self, part: Sequence[str], third: int):
+        pool = self._codec[0]
+        ev = self._uploaded[third]   # the last upload out of this slab third must be over before it is rewritten
+        if ev is not None:
+            ev.synchronize()
+            self._uploaded[third] = None
+        tasks = [{"source_img": p, "transform_name": "", "seed": 0} for p in part]
+        return pool.decode(tasks, third * self.CHUNK, True)
+
+    def _finish(self, futures, third: int, n: int, img_size: int, keep_native: bool, pos0: int):
+        """The device half of one chunk whose worker jobs are `futures`: upload, the JPEG back end, the resize.
+        Returns (kept positions, x, natives, errors); the slab third is free again once `_uploaded[third]` has passed."""
         import torch
 
         from .. import ops
-        S, C = int(img_size), self.CHUNK
+        pool, _slot, pinned, dev_in = self._codec
+        S, dev = int(img_size), dev_in.device
+        decoded = [r for f in futures for r in f.result()]
+        host = pool.tensor("in", third * self.CHUNK, n)
+        # Nothing below waits for the GPU (unless `keep_native` fetches pixels back): the device half queues
+        # behind whatever the stream is doing — a training step — and the host goes on to prepare the next one.
+        # The one staging buffer is safe to reuse: uploads and the kernels that read it are ordered on the stream.
+        dev_in = dev_in[:n]
+        dev_in.copy_(host if pinned else host.clone(), non_blocking=pinned)
+        if pinned:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._uploaded[third] = ev
+
+        def index(ks):
+            t = torch.tensor(ks, dtype=torch.int64)
+            return (t.pin_memory() if pinned else t).to(dev, non_blocking=pinned)
+        groups: Dict[tuple, List[int]] = {}
+        big: Dict[int, np.ndarray] = {}
+        errors: List[Tuple[int, str]] = []
+        for k, (status, payload, _prm) in enumerate(decoded):
+            if status == "err":
+                errors.append((pos0 + k, payload))
+            elif status == "big":
+                big[k] = payload
+                groups.setdefault(("big",) + tuple(payload.shape[:2]), []).append(k)
+            else:
+                groups.setdefault((status,) + tuple(payload[:2]), []).append(k)
+        natives: Optional[Dict[int, np.ndarray]] = {} if keep_native else None
+        x = torch.empty((n, S, S, 3), dtype=torch.uint8, device=dev)
+        for (status, h, w), ks in groups.items():
+            whole = len(ks) == n   # one group holds the whole chunk (the usual case): no gather, no scatter
+            idx = None if whole else index(ks)
+            if status == "coef":
+                px = ops.jpeg_idct_rgb_u8(dev_in if whole else dev_in[idx], h, w)
+            elif status == "ok":
+                px = (dev_in if whole else dev_in[idx])[:, :h * w * 3].view(len(ks), h, w, 3)
+            else:
+                px = torch.from_numpy(np.stack([big[k] for k in ks])).to(dev)
+            res = px if (h, w) == (S, S) else ops.resize_lanczos_u8(px.contiguous(), S)
+            if whole:   # (a view of the staging buffer is never contiguous: it gets copied here)
+                x = res if res.is_contiguous() else res.contiguous()
+            else:
+                x[idx] = res
+            if natives is not None:
+                host_px = px.cpu().numpy()
+                for j, k in enumerate(ks):
+                    natives[pos0 + k] = host_px[j]
+        kept = sorted(k for ks in groups.values() for k in ks)
+        if len(kept) < n:
+            x = x[index(kept)] if kept else x[:0]
+        return [pos0 + k for k in kept], x, natives, errors
+
+    def drop_pending(self) -> None:
+        """Wait for (and drop) what `submit` left pending — the synchronous path is about to use every third, or
+        the caller no longer wants those batches; `collect` on a dropped handle returns None."""
+        for h in self._pending:
+            h["dropped"] = True
+            for f in h["futures"]:
+                try:
+                    f.result()
+                except Exception:  # noqa: BLE001
+                    pass
+        self._pending = []
+        self._ring = 0
+
+    def chunks(self, paths: Sequence, img_size: int, keep_native: bool = False) -> Iterator[
+            Tuple[int, List[int], "object", Optional[Dict[int, np.ndarray]], List[Tuple[int, str]]]]:
+        C = self.CHUNK
         paths = [str(p) for p in paths]
-        pool, slot, pinned, dev_in = self._ensure(self._probe_slot(paths, S))
-        dev = dev_in.device
+        self.drop_pending()
+        self._ensure(self._probe_slot(paths, int(img_size)))
         parts = [paths[b:b + C] for b in range(0, len(paths), C)]
-
-        def submit(i):
-            tasks = [{"source_img": p, "transform_name": "", "seed": 0} for p in parts[i]]
-            return pool.decode(tasks, (i % 3) * C, True)
-
         try:
-            ahead = [submit(i) for i in range(min(2, len(parts)))]
+            ahead = [self._submit(parts[i], i % 3) for i in range(min(2, len(parts)))]
             for i, part in enumerate(parts):
-                decoded = [r for f in ahead.pop(0) for r in f.result()]
-                if i + 2 < len(parts):   # into the slab third chunk i-1 used: its upload was waited for below
-                    ahead.append(submit(i + 2))
-                n, base = len(part), (i % 3) * C
-                host = pool.tensor("in", base, n)
-                dev_in[:n].copy_(host if pinned else host.clone(), non_blocking=pinned)
-                groups: Dict[tuple, List[int]] = {}
-                big: Dict[int, np.ndarray] = {}
-                errors: List[Tuple[int, str]] = []
-                for k, (status, payload, _prm) in enumerate(decoded):
-                    if status == "err":
-                        errors.append((i * C + k, payload))
-                    elif status == "big":
-                        big[k] = payload
-                        groups.setdefault(("big",) + tuple(payload.shape[:2]), []).append(k)
-                    else:
-                        groups.setdefault((status,) + tuple(payload[:2]), []).append(k)
-                natives: Optional[Dict[int, np.ndarray]] = {} if keep_native else None
-                x = torch.empty((n, S, S, 3), dtype=torch.uint8, device=dev)
-                for (status, h, w), ks in groups.items():
-                    idx = torch.tensor(ks, dtype=torch.int64, device=dev)
-                    if status == "coef":
-                        px = ops.jpeg_idct_rgb_u8(dev_in[idx], h, w)
-                    elif status == "ok":
-                        px = dev_in[idx, :h * w * 3].view(len(ks), h, w, 3)
-                    else:
-                        px = torch.from_numpy(np.stack([big[k] for k in ks])).to(dev)
-                    x[idx] = px if (h, w) == (S, S) else ops.resize_lanczos_u8(px.contiguous(), S)
-                    if natives is not None:
-                        host_px = px.cpu().numpy()
-                        for j, k in enumerate(ks):
-                            natives[i * C + k] = host_px[j]
-                kept = sorted(k for ks in groups.values() for k in ks)
-                if len(kept) < n:
-                    x = x[torch.tensor(kept, dtype=torch.int64, device=dev)] if kept else x[:0]
-                # this chunk's slab third is handed to the workers again at the next iteration: its
-                # (asynchronous) upload must have finished by then
-                torch.cuda.current_stream().synchronize()
-                yield i * C, [i * C + k for k in kept], x, natives, errors
+                futures = ahead.pop(0)
+                for f in futures:
+                    f.result()
+                if i + 2 < len(parts):   # into the slab third chunk i-1 used: its upload was waited for
+                    ahead.append(self._submit(parts[i + 2], (i + 2) % 3))
+                kept, x, natives, errors = self._finish(futures, i % 3, len(part), img_size, keep_native, i * C)
+                yield i * C, kept, x, natives, errors
         except BaseException:
-            decoded = host = None
             self.close()   # a failed chunk may leave jobs in flight on the slabs: start afresh next time
             raise
+
+    # ---- one batch ahead: the worker half now, the device half when the batch is asked for
+    def submit(self, paths: Sequence, img_size: int):
+        """Start the worker half (file read + Huffman decoding) of one batch of at most CHUNK files and return a
+        handle for `collect`, or None when two batches are already pending (the slab ring has three thirds)."""
+        paths = [str(p) for p in paths]
+        if not paths or len(paths) > self.CHUNK or len(self._pending) >= 2:
+            return None
+        slot = self._probe_slot(paths, int(img_size))
+        if self._codec is None or self._codec[1] < slot:
+            self.drop_pending()
+            self._ensure(slot)
+        third = self._ring % 3
+        self._ring += 1
+        h = {"futures": self._submit(paths, third), "third": third, "n": len(paths), "S": int(img_size)}
+        self._pending.append(h)
+        return h
+
+    def collect(self, h):
+        """The device half of a submitted batch: (kept positions, uint8 device tensor [len(kept), S, S, 3], errors);
+        None when the handle was dropped in the meantime."""
+        if h.get("dropped") or not any(q is h for q in self._pending):
+            return None
+        try:
+            kept, x, _nat, errors = self._finish(h["futures"], h["third"], h["n"], h["S"], False, 0)
+        except BaseException:
+            self.close()
+            raise
+        self._pending = [q for q in self._pending if q is not h]
+        return kept, x, errors
 
     def close(self) -> None:
         """Stop the codec workers and release their slabs (idempotent)."""
         codec, self._codec = self._codec, None
+        self._pending, self._ring = [], 0
         if codec is not None:
+            import torch
+            if any(ev is not None for ev in self._uploaded):
+                torch.cuda.synchronize()   # uploads out of the slabs that are about to be unmapped
+            self._uploaded = [None, None, None]
             codec[0].close()
 
     def __del__(self):

@@ -59,6 +59,7 @@ class ManifestSequence:
         self._cache_u8: Dict[int, np.ndarray] = {}
         self._cache_dev = None  # uint8 device tensor [N,S,S,3] (cache=True, device batches)
         self._decoder = None    # DeviceDecoder (device batches of POOL_MIN files or more)
+        self._ahead: Dict[int, tuple] = {}   # batch index -> (decoder handle, item indexes) started by prefetch()
         if self.shuffle:
             self.rng.shuffle(self.indexes)
         if self.cache:
@@ -70,6 +71,10 @@ class ManifestSequence:
     def on_epoch_end(self) -> None:
         if self.shuffle:
             self.rng.shuffle(self.indexes)
+        if self._ahead:       # started for the old order
+            self._ahead.clear()
+            if self._decoder is not None:
+                self._decoder.drop_pending()
 
     # ------------------------------------------------------------------ loading
     def _decode(self, i: int) -> np.ndarray:
@@ -147,8 +152,31 @@ class ManifestSequence:
             parts.append(x)
         return parts[0] if len(parts) == 1 else torch.cat(parts)
 
+    PREFETCH_MIN = 16   # the worker pool is already up: worth it from a few files on
+
+    def prefetch(self, idx: int) -> None:
+        """Start decoding batch `idx` on the codec workers (file reads + Huffman decoding; nothing on the GPU yet)
+        so that `self[idx]` only has the device half left.  `fit` calls it for the next batch before each step;
+        a no-op for host batches, cached datasets, transforms, and batches too small or too large for one chunk."""
+        if (self.as_numpy or self.cache or self._cache_dev is not None or self.transform is not None
+                or idx < 0 or idx >= len(self) or idx in self._ahead):
+            return
+        import torch
+        if not torch.cuda.is_available():
+            return
+        batch_idx = self.batch_indexes(idx)
+        from .device_decode import DeviceDecoder
+        if not self.PREFETCH_MIN <= len(batch_idx) <= DeviceDecoder.CHUNK:
+            return
+        if self._decoder is None:
+            self._decoder = DeviceDecoder(self.workers if self.workers > 1 else None)
+        h = self._decoder.submit([self.items[i].src for i in batch_idx], self.img_size)
+        if h is not None:
+            self._ahead[idx] = (h, batch_idx)
+
     def close(self) -> None:
         """Stop the decoder's worker processes (idempotent; also done when the sequence is collected)."""
+        self._ahead.clear()
         dec, self._decoder = self._decoder, None
         if dec is not None:
             dec.close()
@@ -216,7 +244,16 @@ class ManifestSequence:
                 import torch
                 x_u8 = torch.from_numpy(x_u8).cuda()
         else:
-            x_u8 = self._load_dev(batch_idx)
+            ahead = self._ahead.pop(idx, None)
+            got = None
+            if ahead is not None and ahead[1] == batch_idx and self._decoder is not None:
+                got = self._decoder.collect(ahead[0])
+            if got is not None:
+                _kept, x_u8, errors = got
+                if errors:
+                    raise OSError(f"Cannot load image {errors[0][1]}")
+            else:
+                x_u8 = self._load_dev(batch_idx)
         if self.as_numpy:
             X = x_u8.astype(np.float32) / 255.0  # normalize_array (image_utils.py:117-130)
         else:

@@ -121,6 +121,12 @@ class LeafCNN:
         self.stop_training = False
         self.gen = torch.Generator(device="cpu").manual_seed(int(seed))
         self.np_rng = np.random.RandomState(int(seed) & 0x7FFFFFFF)
+        # The per-step host draws are a handful of small CPU tensor ops.  torch sizes its intra-op pool by the cores
+        # it can SEE (256 on a box that grants 16): every such op then pays a 256-thread fork/join — 19-27 ms per
+        # step, as long as the whole bf16 step.  Never more threads than the process may use.
+        from ..utils.system_info import get_available_cores
+        if torch.get_num_threads() > get_available_cores():
+            torch.set_num_threads(get_available_cores())
 
         # ---- flat parameter / state storage
         self.specs = _specs(self.num_classes, self.widths, self.use_se)
@@ -863,8 +869,11 @@ class LeafCNN:
             acc_loss = torch.zeros((), device=self.device)
             acc_correct = torch.zeros((), device=self.device)
             seen = 0
-            for bi in order:
+            prefetch = getattr(train_seq, "prefetch", None)
+            for step_no, bi in enumerate(order):
                 bx, by = train_seq[bi]
+                if prefetch is not None and step_no + 1 < len(order):
+                    prefetch(order[step_no + 1])   # its files decode on the codec workers during this step
                 n_local = int(bx.shape[0])
                 dp_on = dp is not None and dp.active
                 if n_local == 0 and not dp_on:

@@ -387,3 +387,56 @@ def test_pooled_loader_batches_and_cache_equal_the_host_loader(cuda, tmp_path, m
     Path(items[20].src).write_bytes(b"\xff\xd8 not a jpeg")
     with pytest.raises(OSError):
         ManifestSequence(items, l2i, 48, 150, False, 5, num_classes=3)[0]
+
+
+def test_prefetched_loader_batches_equal_the_host_loader(cuda, tmp_path, monkeypatch):
+    """`prefetch(i)` starts batch i on the codec workers and `seq[i]` finishes it on the GPU: same batches as the
+    host loader in any access order, also when a prefetched batch is never asked for, when a synchronous batch
+    comes in between (which drops the pending ones) and across `on_epoch_end` reshuffles; `fit` trains through it."""
+    import torch
+    from PIL import Image
+
+    from leaffliction_amd.dataio.manifest import ManifestItem
+    from leaffliction_amd.dataio.sequence import ManifestSequence
+    rng = np.random.RandomState(5)
+    items = []
+    for i in range(200):
+        h, w = [(64, 64), (80, 96), (48, 48)][i % 3]
+        p = tmp_path / f"im_{i:03d}.JPG"
+        Image.fromarray(leaf_like(h, w, i)).save(p, quality=95, **({"subsampling": 0} if i % 9 == 4 else {}))
+        items.append(ManifestItem(f"id{i}", "plant", f"c{i % 2}", f"c{i % 2}", "train", p))
+    l2i = {"c0": 0, "c1": 1}
+    ahead = ManifestSequence(items, l2i, 48, 32, True, 11, num_classes=2, one_hot=True)
+    host = ManifestSequence(items, l2i, 48, 32, True, 11, num_classes=2, one_hot=True)
+    monkeypatch.setattr(host, "prefetch", lambda idx: None)
+    for epoch in range(2):
+        order = list(range(len(host)))
+        random.Random(epoch).shuffle(order)
+        for j, bi in enumerate(order):
+            if j + 1 < len(order):
+                ahead.prefetch(order[j + 1])
+            if j == 2:
+                ahead.prefetch(order[-1])   # a third one: refused (two pending), asked for synchronously later
+            if j == 4:
+                ahead._load_dev(list(range(70)))   # a synchronous pooled load in between drops the pending batch
+            (xa, ya), (xb, yb) = host[bi], ahead[bi]
+            assert xb.is_cuda and torch.equal(xa, xb) and np.array_equal(ya, yb)
+        host.on_epoch_end()
+        ahead.on_epoch_end()
+    assert ahead._decoder is not None and not ahead._ahead
+    ahead.close()
+
+    from leaffliction_amd.model.cnn import build_leafcnn
+    from leaffliction_amd.train.utils import build_loss, build_optimizer
+    calls = []
+    seq = ManifestSequence(items, l2i, 48, 32, True, 11, num_classes=2, one_hot=True)
+    orig = seq.prefetch
+    monkeypatch.setattr(seq, "prefetch", lambda idx: (calls.append(idx), orig(idx))[1])
+    cfg = {"optimizer": "adamw", "lr": 1e-3, "weight_decay": 1e-4, "label_smoothing": 0.02,
+           "cosine_decay": False, "ema_decay": 0.0, "clipnorm": 0.5}
+    model, _norm = build_leafcnn(num_classes=2, img_size=48, widths=[16, 32], drop_block=0.1, drop_top=0.3,
+                                 l2_reg=1e-4, seed=1)
+    model.compile(build_optimizer(cfg, 1e-3), build_loss(cfg), ["accuracy"])
+    model.fit(seq, epochs=1, verbose=0)
+    assert len(calls) == len(seq) - 1
+    seq.close()
