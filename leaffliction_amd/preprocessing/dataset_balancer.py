@@ -33,7 +33,7 @@ from .image_augmenter import ImageAugmenter, apply_batch, draw_params
 from ..utils.common import get_logger
 from ..utils import ranks as _ranks
 from ..utils.ranks import contiguous_share
-from ..utils.system_info import get_optimal_worker_count
+from ..utils.system_info import get_available_cores, get_optimal_worker_count
 
 logger = get_logger(__name__)
 
@@ -64,9 +64,11 @@ class DatasetBalancer:
 
     @staticmethod
     def _host_threads(requested) -> int:
-        """`--workers` keeps the reference's meaning and bounds (default = half the optimal
-        count, capped at it; dataset_balancer.py:41-57); here they are the JPEG codec PROCESSES."""
-        ceiling = get_optimal_worker_count()
+        """`--workers` keeps the reference's meaning (default = half the optimal count;
+        dataset_balancer.py:41-57); here they are the JPEG codec PROCESSES.  An explicit request is honoured up
+        to the cores the process may use (the reference caps it at the optimal count, 3/4 of them: its workers
+        compete with a busy parent, these with one that mostly waits for the GPU)."""
+        ceiling = get_optimal_worker_count() if requested is None else get_available_cores()
         n = max(1, ceiling // 2) if requested is None else max(1, int(requested))
         if n > ceiling:
             logger.warning(f"Requested {n} workers, but only {ceiling} CPUs available; using {ceiling}")
