@@ -8,7 +8,8 @@ import platform
 def get_available_cores() -> int:
     """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
     (a container shows every core of its host but is granted a share of them; sizing a worker
-    pool by the host count oversubscribes the share and pays hundreds of process spawns)."""
+    pool by the host count oversubscribes the share and pays hundreds of process spawns), divided
+    by the ranks of this node when running one process per GPU (LOCAL_WORLD_SIZE)."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -20,6 +21,13 @@ def get_available_cores() -> int:
             n = max(1, min(n, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
+    # one process per GPU under torch.distributed.run: the ranks of a node share its cores
+    try:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        local_world = 1
+    if local_world > 1:
+        n = max(1, n // local_world)
     return n
 
 

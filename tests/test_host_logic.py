@@ -249,3 +249,33 @@ def test_distribution_matches_reference_golden(tmp_path, monkeypatch):
         assert list(csv.reader(f)) == g["fresh"]
     D.main([str(root), "--plants", "Nope", "--no-plots"])       # unknown plant: logs, returns
     D.main([str(tmp_path / "missing"), "--no-plots"])           # missing root: logs, returns
+
+
+def test_worker_counts_follow_the_granted_cores(monkeypatch, tmp_path):
+    """get_available_cores: affinity mask, capped by the cgroup CPU quota, shared among the ranks of a node; the
+    optimal count keeps the reference's heuristic on top of it (system_info.py:9-46)."""
+    import builtins
+    import io
+    import os
+
+    from leaffliction_amd.utils import system_info as si
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if str(path) == "/sys/fs/cgroup/cpu.max":
+            return io.StringIO(quota[0])
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    quota = ["max 100000\n"]
+    assert si.get_available_cores() == 64 and si.get_optimal_worker_count() == 48
+    quota[0] = "1600000 100000\n"
+    assert si.get_available_cores() == 16 and si.get_optimal_worker_count() == 12
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert si.get_available_cores() == 2 and si.get_optimal_worker_count() == 1
+    quota[0] = "garbage"
+    assert si.get_available_cores() == 8
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    quota[0] = "350000 100000\n"
+    assert si.get_available_cores() == 3 and si.get_optimal_worker_count() == 2
