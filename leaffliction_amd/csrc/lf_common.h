@@ -82,6 +82,7 @@ struct ConvBf16TrainArgs {
     const float* mask_shift;
     int mask_relu;
     int tiles_x, tiles_y, items, items_per_wg;  // filled by the streaming launcher
+    int interleave;                             // 1: tile rows dealt out per XCD (see conv_bf16s_kernel)
     // inference: v*out_scale[co]+out_shift[co] (+ReLU) on the fp32 accumulators before rounding — the
     // layer's folded BatchNorm(+ReLU), so that what is stored is the activation itself
     const float* out_scale;

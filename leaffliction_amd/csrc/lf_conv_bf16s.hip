@@ -111,8 +111,16 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     const bool stats = p.stat_part != nullptr, masked = RMW && p.stat_mask_y != nullptr;
     const bool accumulate = RMW && p.accumulate;
     const int tiles = p.tiles_x * p.tiles_y;
-    const int first = blockIdx.x * p.items_per_wg;
-    const int last = min(first + p.items_per_wg, p.items);
+    // Which tiles a workgroup walks.  interleave = 0: a contiguous range of (image, tile row, tile) items.
+    // interleave = 1: XCD k (workgroups k, k+8, ...) owns the k-th eighth of all tile ROWS and deals them out
+    // round-robin to its workgroups, so that at any time the workgroups of an XCD work on neighbouring tile rows
+    // and the halo rows two of them need cross the fabric once and are found in that XCD's L2 the second time.
+    const int rows_total = p.items / p.tiles_x;
+    const int xk = blockIdx.x & 7, xj = blockIdx.x >> 3, xw = gridDim.x >> 3;
+    const int xr0 = (int)((long long)rows_total * xk / 8), xr1 = (int)((long long)rows_total * (xk + 1) / 8);
+    const int my_rows = p.interleave ? (xr1 - xr0 > xj ? (xr1 - xr0 - xj + xw - 1) / xw : 0) : 0;
+    const int first = p.interleave ? 0 : blockIdx.x * p.items_per_wg;
+    const int last = p.interleave ? my_rows * p.tiles_x : min(first + p.items_per_wg, p.items);
 
     // ---- one-time: filter bank -> LDS as [chunk][tap][k half][cout][8 channels] (16 B per entry)
     {
@@ -152,6 +160,13 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     unsigned xmask = 0, hmask = 0;
 
     auto tile_of = [&](int item, int& n, int& tx0, int& ty0) {
+        if (p.interleave) {
+            const int lr = item / p.tiles_x, row = xr0 + xj + lr * xw;
+            n = row / p.tiles_y;
+            tx0 = (item - lr * p.tiles_x) * TW;
+            ty0 = (row - n * p.tiles_y) * TH;
+            return;
+        }
         n = item / tiles;
         const int t = item - n * tiles;
         tx0 = (t % p.tiles_x) * TW;
@@ -451,7 +466,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
 
 struct SPlan {
     bool ok;
-    int ci, nco, tw, th, tiles_x, tiles_y, items, wgs, items_per_wg;
+    int ci, nco, tw, th, tiles_x, tiles_y, items, wgs, items_per_wg, interleave;
 };
 
 SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
@@ -482,6 +497,11 @@ SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
     if (wgs > pl.items) wgs = pl.items;
     pl.items_per_wg = (pl.items + wgs - 1) / wgs;
     pl.wgs = (pl.items + pl.items_per_wg - 1) / pl.items_per_wg;
+    // tile rows dealt out per XCD when every workgroup of the full grid gets at least two of them (A/B in one
+    // process against contiguous ranges, 32->32 @224: forward 662 -> 648 us, input gradient with accumulate
+    // 725 -> 671 us, with accumulate + mask + sums 913 -> 860 us; 64->64 @112 forward 508 -> 487 us)
+    pl.interleave = (wgs == 256 * 2 && n * pl.tiles_y >= 2 * wgs) ? 1 : 0;
+    if (pl.interleave) pl.wgs = wgs;
     pl.ok = true;
     return pl;
 }
@@ -540,6 +560,7 @@ int conv_bf16s_launch(ConvBf16TrainArgs a, int ksize, int x_bf16, hipStream_t s)
         return LF_ERR_INVALID;
     }
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.items = pl.items; a.items_per_wg = pl.items_per_wg;
+    a.interleave = pl.interleave;
     a.stat_tiles = pl.wgs;
     if (pl.tw == 64) return dispatch_s<64, 4>(pl, ksize, a, s);
     return pl.tw == 32 ? dispatch_s<32, 8>(pl, ksize, a, s) : dispatch_s<16, 16>(pl, ksize, a, s);
