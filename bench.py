@@ -372,7 +372,7 @@ def augment_end_to_end(dev):
     from concurrent.futures import ProcessPoolExecutor
 
     from leaffliction_amd.preprocessing.dataset_balancer import DatasetBalancer
-    from leaffliction_amd.utils.system_info import get_available_cores, get_optimal_worker_count
+    from leaffliction_amd.utils.system_info import get_available_cores
     cores = min(get_available_cores(), usable_cores())
     tmp = Path(tempfile.mkdtemp(prefix="lf_e2e_"))
     cwd = os.getcwd()
@@ -380,8 +380,7 @@ def augment_end_to_end(dev):
         src, dst = tmp / "images", tmp / "augmented"
         n_orig = _e2e_make_dataset(src, dev, cores)
         os.chdir(tmp)
-        bal = DatasetBalancer(source_dir=str(src), target_dir=str(dst), seed=42,
-                              workers=min(cores, get_optimal_worker_count()))
+        bal = DatasetBalancer(source_dir=str(src), target_dir=str(dst), seed=42, workers=cores)   # `--workers` = all granted cores
         bal.analyze_distribution()
         bal.calculate_plan()
         torch.cuda.synchronize()

@@ -121,12 +121,8 @@ class LeafCNN:
         self.stop_training = False
         self.gen = torch.Generator(device="cpu").manual_seed(int(seed))
         self.np_rng = np.random.RandomState(int(seed) & 0x7FFFFFFF)
-        # The per-step host draws are a handful of small CPU tensor ops.  torch sizes its intra-op pool by the cores
-        # it can SEE (256 on a box that grants 16): every such op then pays a 256-thread fork/join — 19-27 ms per
-        # step, as long as the whole bf16 step.  Never more threads than the process may use.
-        from ..utils.system_info import get_available_cores
-        if torch.get_num_threads() > get_available_cores():
-            torch.set_num_threads(get_available_cores())
+        from ..utils.system_info import cap_torch_threads
+        cap_torch_threads()   # the per-step host draws are small CPU tensor ops: see there
 
         # ---- flat parameter / state storage
         self.specs = _specs(self.num_classes, self.widths, self.use_se)

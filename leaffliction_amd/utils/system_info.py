@@ -40,3 +40,13 @@ def get_optimal_worker_count() -> int:
     if platform.system() == "Darwin" and platform.machine() == "arm64":
         return min(8, cores)
     return max(1, int(cores * 0.75))
+
+
+def cap_torch_threads() -> None:
+    """torch sizes its intra-op pool by the cores it can SEE (256 on a box that grants 16): every small CPU tensor
+    op of a host loop then pays a 256-thread fork/join (the per-step dropout draws of `fit`: 19-27 ms, as long
+    as the whole bf16 step).  Never more threads than the process may use; called when the library is loaded."""
+    import torch
+    cores = get_available_cores()
+    if torch.get_num_threads() > cores:
+        torch.set_num_threads(cores)
