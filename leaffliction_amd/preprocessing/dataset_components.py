@@ -8,6 +8,7 @@ system); deficits and plans are keyed by class name alone; every item of the aug
 from __future__ import annotations
 
 import json
+import os
 from datetime import datetime, timezone
 from pathlib import Path
 from typing import Dict, Iterator, Tuple
@@ -115,11 +116,14 @@ class ManifestGenerator:
     def _records(self) -> Iterator[dict]:
         for plant_dir, class_dir in _class_dirs(self.target_dir):
             plant, cls = plant_dir.name, class_dir.name
-            for img in class_dir.iterdir():
-                if img.is_file():
-                    yield {"plant": plant, "class": cls, "label": f"{plant}__{cls}", "split": "train",
-                           "src": str(img), "id": str(img.relative_to(self.target_dir)),
-                           "augmented": "_aug_" in img.stem}
+            base, rel, label = str(class_dir) + os.sep, plant + os.sep + cls + os.sep, f"{plant}__{cls}"
+            with os.scandir(class_dir) as entries:   # directory order, as Path.iterdir(); no stat per file
+                for e in entries:
+                    if e.is_file():
+                        name = e.name
+                        yield {"plant": plant, "class": cls, "label": label, "split": "train",
+                               "src": base + name, "id": rel + name,
+                               "augmented": "_aug_" in os.path.splitext(name)[0]}
 
     def generate_augmented_manifest(self):
         items = list(self._records())
@@ -136,6 +140,22 @@ class ManifestGenerator:
                 "augmented_images": n_aug}
         return {"meta": meta, "items": items}
 
+    @staticmethod
+    def _dumps(manifest) -> str:
+        """`json.dumps(manifest, indent=2, ensure_ascii=False)`, byte for byte — which is what the reference
+        writes (dataset_components.py save_manifest) — without the pure-Python encoder an `indent` selects: the
+        flat item records go through the C encoder one call each, with the indentation in the separator."""
+        items = manifest.get("items") if isinstance(manifest, dict) else None
+        flat = (str, int, float, bool, type(None))
+        if (not isinstance(items, list) or not items or list(manifest)[-1] != "items" or len(manifest) < 2
+                or not all(isinstance(r, dict) and r and all(isinstance(k, str) and isinstance(v, flat)
+                                                             for k, v in r.items()) for r in items)):
+            return json.dumps(manifest, indent=2, ensure_ascii=False)
+        head = json.dumps({k: v for k, v in manifest.items() if k != "items"}, indent=2, ensure_ascii=False)
+        sep = (",\n      ", ": ")
+        recs = ["    {\n      " + json.dumps(r, ensure_ascii=False, separators=sep)[1:-1] + "\n    }" for r in items]
+        return head[:-2] + ',\n  "items": [\n' + ",\n".join(recs) + "\n  ]\n}"
+
     def save_manifest(self, manifest, output_path):
-        Path(output_path).write_text(json.dumps(manifest, indent=2, ensure_ascii=False), encoding="utf-8")
+        Path(output_path).write_text(self._dumps(manifest), encoding="utf-8")
         logger.info(f"Augmented manifest saved: {output_path}")

@@ -279,3 +279,20 @@ def test_worker_counts_follow_the_granted_cores(monkeypatch, tmp_path):
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
     quota[0] = "350000 100000\n"
     assert si.get_available_cores() == 3 and si.get_optimal_worker_count() == 2
+
+
+def test_manifest_text_equals_json_dumps_indent2():
+    """The augmented manifest is written as `json.dumps(manifest, indent=2, ensure_ascii=False)` would write it
+    (the reference's save_manifest), through the C encoder."""
+    import json
+
+    from leaffliction_amd.preprocessing.dataset_components import ManifestGenerator as M
+    items = [{"plant": "Apple", "class": "Apple_scab é", "label": "Apple__x", "split": "train",
+              "src": '/a/b "q"/c.JPG', "id": "a\\b\tc", "augmented": i % 2 == 0, "n": i, "f": 0.5, "z": None}
+             for i in range(7)]
+    cases = [{"meta": {"a": 1, "b": None, "c": "x", "d": {"n": [1, 2]}}, "items": items},
+             {"meta": {}, "items": items}, {"meta": {"a": 1}, "items": []}, {"items": items},
+             {"meta": {"a": 1}, "items": [{"x": [1]}]}, {"meta": {"a": 1}, "items": items, "z": 1},
+             {"meta": {"a": 1}, "items": [{}]}, [1, 2], {"meta": {"a": 1}, "items": [{1: "a"}]}]
+    for man in cases:
+        assert M._dumps(man) == json.dumps(man, indent=2, ensure_ascii=False)
