@@ -676,7 +676,11 @@ int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y
                "lf_conv2d_bf16: a fused prologue takes at most %d input channels (got %d)", kMaxPrologueCin, cin);
     LF_REQUIRE((out_scale == nullptr) == (out_shift == nullptr),
                "lf_conv2d_bf16: out_scale/out_shift must both be set");
-    LF_REQUIRE((size_t)h * w < ((size_t)1 << 32), "lf_conv2d_bf16: plane too large");
+    // 32-bit buffer offsets: one image's input (plus the two staged chunks past its end that the pipeline asks
+    // for and gets zeros back) and the packed weights must each stay below 2 GiB
+    LF_REQUIRE((size_t)(cin + 2 * 16 * kKC) * h * w * (x_bf16 ? 2 : 4) < ((size_t)1 << 31) &&
+                   lf_conv2d_bf16_weight_elems(cin, cout, ksize) * 2 < ((size_t)1 << 31),
+               "lf_conv2d_bf16: image or weights too large for 32-bit buffer offsets");
     LF_REQUIRE(n <= 65535, "lf_conv2d_bf16: batch too large for grid.z");
     LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wprep)) & 15) == 0,
                "lf_conv2d_bf16: x and wprep must be 16-byte aligned");
@@ -726,7 +730,9 @@ int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint1
     LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "lf_conv2d_bf16_train: scale/shift must both be set");
     LF_REQUIRE(in_scale == nullptr || cin <= kMaxPrologueCin,
                "lf_conv2d_bf16_train: a fused prologue takes at most %d input channels (got %d)", kMaxPrologueCin, cin);
-    LF_REQUIRE((size_t)h * w < ((size_t)1 << 32), "lf_conv2d_bf16_train: plane too large");
+    LF_REQUIRE((size_t)(cin + 2 * 16 * kKC) * h * w * (x_bf16 ? 2 : 4) < ((size_t)1 << 31) &&
+                   lf_conv2d_bf16_weight_elems(cin, cout, ksize) * 2 < ((size_t)1 << 31),
+               "lf_conv2d_bf16_train: image or weights too large for 32-bit buffer offsets");
     LF_REQUIRE(n <= 65535, "lf_conv2d_bf16_train: batch too large for grid.z");
     LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wprep)) & 15) == 0,
                "lf_conv2d_bf16_train: x and wprep must be 16-byte aligned");

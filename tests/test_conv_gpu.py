@@ -244,6 +244,10 @@ BF16_SHAPES = [  # n, cin, cout, h, w, k
     (2, 32, 64, 112, 112, 1),   # 1x1 projection
     (2, 128, 256, 28, 28, 1),
     (1, 16, 32, 12, 20, 3),     # partial tiles in both directions
+    (2, 48, 64, 20, 24, 3),     # three 16-channel slices: the second staged 32-channel chunk is half empty
+    (1, 40, 32, 9, 12, 3),      # channel count inside a slice: the padding comes back from the buffer bounds
+    (2, 80, 64, 16, 16, 1),     # 1x1, five slices
+    (1, 160, 96, 28, 28, 3),    # cout an odd multiple of 32 (32x16 tiles), five staged chunks
 ]
 
 

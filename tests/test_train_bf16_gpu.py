@@ -50,6 +50,9 @@ def close_bf16(got, ref, max_frac, terms=None):
     (3, 64, 32, 8, 8, 3, True, False, False, "bwd"),
     (2, 32, 64, 12, 20, 1, True, True, False, "fwd"),
     (2, 64, 32, 28, 28, 1, True, False, True, None),
+    (2, 96, 64, 12, 16, 3, True, True, False, "fwd"),    # K-chunked kernel, three 32-channel chunks
+    (2, 160, 128, 8, 24, 3, True, False, True, "bwd"),   # five 16-channel slices: the last chunk half empty
+    (2, 48, 64, 12, 12, 1, True, True, True, "fwd"),
 ])
 def test_conv2d_bf16_train(cuda, n, cin, cout, h, w, k, xbf, pro, acc, stat):
     from leaffliction_amd import nn
