@@ -69,7 +69,9 @@ class DeviceDecoder:
             ev.synchronize()
             self._uploaded[third] = None
         tasks = [{"source_img": p, "transform_name": "", "seed": 0} for p in part]
-        return pool.decode(tasks, third * self.CHUNK, True)
+        # every future costs the parent ~0.1-0.2 ms to send and collect: one job per worker for a small batch (a
+        # 32-file batch as 32 one-file jobs ran at half the rate), two for a full chunk (some slack for a slow core)
+        return pool.decode(tasks, third * self.CHUNK, True, pieces_per_worker=1 if len(part) <= 64 else 2)
 
     def _finish(self, futures, third: int, n: int, img_size: int, keep_native: bool, pos0: int):
         """The device half of one chunk whose worker jobs are `futures`: upload, the JPEG back end, the resize.

@@ -217,16 +217,18 @@ class CodecPool:
         n = int(np.prod(shape))
         return np.frombuffer(self.slabs[slab].buf, np.uint8, n, slot * self.slot_bytes).reshape(shape)
 
-    def _split(self, jobs: List[Any]) -> List[List[Any]]:
+    def _split(self, jobs: List[Any], pieces_per_worker: int = 4) -> List[List[Any]]:
         # four pieces per worker: a piece that happens to hold several distortion tasks (150 k normal deviates
-        # each, 4x the cost of the decode next to it) no longer decides when the chunk is ready
-        per = max(1, -(-len(jobs) // (4 * self.workers)))
+        # each, 4x the cost of the decode next to it) no longer decides when the chunk is ready; one piece per
+        # worker for plain decoding (uniform jobs: every future costs the parent ~0.1 ms to send and collect)
+        per = max(1, -(-len(jobs) // (pieces_per_worker * self.workers)))
         return [jobs[i:i + per] for i in range(0, len(jobs), per)]
 
-    def decode(self, tasks: Sequence[dict], first_slot: int, coefficients: bool = False) -> List[Future]:
+    def decode(self, tasks: Sequence[dict], first_slot: int, coefficients: bool = False,
+               pieces_per_worker: int = 4) -> List[Future]:
         jobs = [(t.get("read_img", t["source_img"]), t["transform_name"], t["seed"], (first_slot + k) * self.slot_bytes,
                  (first_slot + k) * self.slot_bytes, self.slot_bytes, coefficients) for k, t in enumerate(tasks)]
-        return [self.pool.submit(_decode_jobs, self.names, part) for part in self._split(jobs)]
+        return [self.pool.submit(_decode_jobs, self.names, part) for part in self._split(jobs, pieces_per_worker)]
 
     def encode(self, jobs: List[Tuple[str, int, Tuple[int, int, int], Optional[np.ndarray]]]) -> List[Future]:
         return [self.pool.submit(_encode_jobs, self.names, part) for part in self._split(jobs)]

@@ -34,7 +34,7 @@ def epoch(items, l2i, batch, pooled):
         warm.prefetch = lambda idx: None
         warm.POOL_MIN = 10 ** 9
     model.fit(warm, epochs=1, verbose=0)        # graph capture, worker start-up
-    warm.close()
+    seq._decoder, warm._decoder = warm._decoder, None   # the codec workers live across epochs
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     model.fit(seq, epochs=1, verbose=0)
