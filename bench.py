@@ -455,6 +455,50 @@ def inference_throughput(model, dev, batch=1024, iters=5):
     return out
 
 
+def _fit_from_files(files, dev, batch=BATCH):
+    """One epoch of `model.fit` over JPEG files, uncached (the reference's base preset, srcs/cli/train.py:38), on
+    the mixed-precision step: the sequence's next batch decodes on the codec workers during the step
+    (ManifestSequence.prefetch); beside it the plain host loader (one Pillow decode after the other) on a quarter
+    of the files."""
+    from leaffliction_amd.dataio.manifest import ManifestItem
+    from leaffliction_amd.dataio.sequence import ManifestSequence
+    from leaffliction_amd.model.cnn import build_leafcnn
+    from leaffliction_amd.train.utils import build_loss, build_optimizer
+    labels = sorted({Path(f).parent.name for f in files})
+    l2i = {la: i for i, la in enumerate(labels)}
+    items = [ManifestItem(str(i), "p", Path(f).parent.name, Path(f).parent.name, "train", Path(f))
+             for i, f in enumerate(files)]
+    cfg = {"optimizer": "adamw", "lr": 1e-3, "weight_decay": 1e-4, "label_smoothing": 0.02,
+           "cosine_decay": False, "ema_decay": 0.0, "clipnorm": 0.5}
+
+    def epoch(its, pooled):
+        model, _ = build_leafcnn(num_classes=len(l2i), img_size=IMG, widths=list(WIDTHS), drop_block=0.15,
+                                 drop_top=0.40, l2_reg=1e-4, seed=42)
+        model.set_training_dtype("bf16")
+        model.compile(build_optimizer(cfg, 1e-3), build_loss(cfg), ["accuracy"])
+        mk = lambda part, shuffle: ManifestSequence(part, l2i, IMG, batch, shuffle, 42, num_classes=len(l2i),  # noqa: E731
+                                                    one_hot=True)
+        warm, seq = mk(its[:4 * batch], False), mk(its, True)
+        for sq in (warm, seq):
+            if not pooled:
+                sq.prefetch = lambda idx: None
+                sq.POOL_MIN = 10 ** 9
+        model.fit(warm, epochs=1, verbose=0)               # graph capture, worker start-up
+        seq._decoder, warm._decoder = warm._decoder, None   # the codec workers live across epochs
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.fit(seq, epochs=1, verbose=0)
+        torch.cuda.synchronize()
+        sec = time.perf_counter() - t0
+        seq.close()
+        return len(its) / sec
+
+    return {"images_per_sec": round(epoch(items, True), 1), "files": len(items), "batch": batch,
+            "dtype": "bf16 step", "includes": "file reads, JPEG decode, resize, forward, backward, AdamW — one epoch "
+                                              "of model.fit on an uncached ManifestSequence",
+            "host_loader_images_per_sec": round(epoch(items[:max(4 * batch, len(items) // 4)], False), 1)}
+
+
 def predict_end_to_end(dev, n_files=4096):
     """BASELINE configs[4] as a user of `predict -batch` sees it: JPEG files -> labels (Predictor.predict_batch: codec
     worker processes Huffman-decode, the GPU does the rest of the decoding and the bf16 forward pass), next to the
@@ -520,6 +564,8 @@ def predict_end_to_end(dev, n_files=4096):
         finally:
             ManifestSequence.POOL_MIN = keep
         same_cache = bool(torch.equal(seq._cache_dev[:384], seq_host._cache_dev))
+        del seq, seq_host
+        fit_files = _fit_from_files(files, dev)
         return {"images_per_sec": round(len(out) / sec, 1), "files": len(out), "seconds": round(sec, 2),
                 "dtype": "bf16", "includes": "file reads, JPEG decode (Huffman on host cores, the rest on the GPU), "
                                              "forward pass, per-file result records with the decoded pixels",
@@ -530,7 +576,8 @@ def predict_end_to_end(dev, n_files=4096):
                                       "includes": "codec worker start-up, file reads, JPEG decode, upload into the "
                                                   "HBM-resident uint8 dataset (ManifestSequence cache=True)",
                                       "host_loop_images_per_sec": round(384 / sec_fill_host, 1),
-                                      "same_pixels_as_host_loop": same_cache}}
+                                      "same_pixels_as_host_loop": same_cache},
+                "fit_from_files": fit_files}
     finally:
         if pred is not None:
             pred.close()

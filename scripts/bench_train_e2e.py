@@ -55,7 +55,7 @@ def main():
         labels = sorted({f.parent.name for f in files})
         l2i = {la: i for i, la in enumerate(labels)}
         items = [ManifestItem(str(i), "p", f.parent.name, f.parent.name, "train", f) for i, f in enumerate(files)]
-        out = {"files": len(items), "batch": batch, "dtype": "f32 step",
+        out = {"files": len(items), "batch": batch, "dtype": os.environ.get("LEAFFLICTION_TRAIN_DTYPE", "f32") + " step",
                "images_per_sec_prefetching_loader": round(epoch(items, l2i, batch, True), 1),
                "images_per_sec_host_loader": round(epoch(items, l2i, batch, False), 1)}
         print(json.dumps(out))
