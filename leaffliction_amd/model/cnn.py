@@ -942,8 +942,11 @@ class LeafCNN:
         tot_loss = torch.zeros((), device=self.device)
         correct = torch.zeros((), device=self.device)
         count = 0
+        prefetch = getattr(data, "prefetch", None)
         for i in range(len(data)):
             bx, by = data[i]
+            if prefetch is not None and i + 1 < len(data):
+                prefetch(i + 1)   # an uncached sequence decodes its next batch during this one
             if bx.shape[0] == 0:
                 continue
             yt, idx = self._targets(by)
@@ -1111,8 +1114,11 @@ def adapt_normalization(norm_layer, train_seq) -> None:
     if norm_layer is None or not hasattr(norm_layer, "adapt"):
         return
     samples, collected = [], 0
+    prefetch = getattr(train_seq, "prefetch", None)
     for i in range(min(len(train_seq), 64)):
         batch = train_seq[i]
+        if prefetch is not None and i + 1 < min(len(train_seq), 64):
+            prefetch(i + 1)
         X = batch[0] if isinstance(batch, (list, tuple)) else batch
         if isinstance(X, torch.Tensor):
             X = X.cpu().numpy()
