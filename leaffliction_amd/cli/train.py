@@ -135,6 +135,7 @@ def build_and_compile_model(args, cfg: Dict, num_classes: int, train_seq: Any, d
         except ValueError as e:
             LOGGER.info("Mixed precision not available for this shape (%s): training in fp32", e)
     dp.broadcast_(model.flat_p, 0)
+    model._mut += 1   # written by a collective: what inference keeps of the parameters is stale
     if dp.active:
         # same initial weights everywhere; independent dropout / in-model augmentation draws per shard
         model.reseed_step_rng(args.seed + dp.rank)

@@ -119,6 +119,8 @@ class LeafCNN:
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.norm = Normalization() if use_norm else None
         self.stop_training = False
+        self._mut = 0            # passes that wrote parameters / moving statistics from inside the library
+        self._infer_cache: Dict[str, Any] = {}
         self.gen = torch.Generator(device="cpu").manual_seed(int(seed))
         self.np_rng = np.random.RandomState(int(seed) & 0x7FFFFFFF)
         from ..utils.system_info import cap_torch_threads
@@ -362,10 +364,25 @@ class LeafCNN:
         n, _c, _h, _w = x0.shape
         P, bf = self.p, torch.bfloat16
 
+        # Packed bf16 weights and folded BatchNorm coefficients are kept for as long as the parameters stand:
+        # torch's version counters see every in-place write through torch (set_weights, restored best weights, EMA
+        # swaps, a test poking a tensor), `_mut` counts the passes whose kernels write them (training forward,
+        # optimizer step).  96 small launches per forward pass otherwise (~0.5 ms at batch 1,024, most of the
+        # time of a one-image predict).
+        key = (self.flat_p._version, self.flat_s._version, self._mut)
+        if self._infer_cache.get("key") != key:
+            self._infer_cache = {"key": key, "w": {}, "bn": {}}
+        cache = self._infer_cache
+
         def conv(x, wname, k, bn, relu):
             wt = P[wname]
-            st = self._bn(bn, None, False)       # inference: scale / shift from the moving statistics
-            return nn.conv2d_bf16(x, nn.conv2d_bf16_weights(wt, k), wt.shape[2], k,
+            wp = cache["w"].get(wname)
+            if wp is None:
+                wp = cache["w"][wname] = nn.conv2d_bf16_weights(wt, k)
+            st = cache["bn"].get(bn)
+            if st is None:   # inference: scale / shift from the moving statistics (own copy: `stats` is shared)
+                st = cache["bn"][bn] = self._bn(bn, None, False).clone()
+            return nn.conv2d_bf16(x, wp, wt.shape[2], k,
                                   out=self._buf(n, "bf16." + wname, (n, wt.shape[2], x.shape[2], x.shape[3]), bf),
                                   out_scale=st[2], out_shift=st[3], out_relu=relu)
 
@@ -427,6 +444,7 @@ class LeafCNN:
     def _forward_train_bf16(self, x0: torch.Tensor, y_true: torch.Tensor, drops, top_drop):
         """The training forward pass on bf16 storage; everything backward needs goes to self._saved."""
         n, _c, h, w = x0.shape
+        self._mut += 1
         P, bf = self.p, torch.bfloat16
         B = lambda k, shape, dt=bf: self._buf(n, "t16." + k, shape, dt)  # noqa: E731
         F32 = torch.float32
@@ -554,6 +572,8 @@ class LeafCNN:
         """x0: normalised f32 NCHW.  Returns (probs [N,C], per-sample loss or None).
         In training mode every tensor the backward pass needs is kept in self._saved."""
         n, _c, h, w = x0.shape
+        if training:
+            self._mut += 1   # the BatchNorm layers update their moving statistics
         P, B = self.p, lambda k, shape: self._buf(n, k, shape)
         sv: Dict[str, Any] = {"x0": x0, "n": n}
         # Activations a = relu(BN(y)) are never materialised: every consumer (the next conv,
@@ -715,6 +735,7 @@ class LeafCNN:
         all-reduce and advances `opt_step`, Adam moments, weights and EMA exactly like its peers,
         so every rank issues the same collectives and the replicas stay bit-equal.  Returns
         (None, None) in that case."""
+        self._mut += 1   # parameters and moving statistics change (also when the step is a graph replay)
         n = int(x.shape[0])
         self._global_n = global_n
         if n == 0:

@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+import torch.nn.functional as F
+
 from oracle import cnn_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -279,3 +281,36 @@ def test_bf16_inference_224_against_oracle(cuda):
     top2 = np.sort(ref, -1)[:, -2:]
     sure = (top2[:, 1] - top2[:, 0]) > 6e-2
     assert np.array_equal(p16.argmax(-1)[sure], ref.argmax(-1)[sure])
+
+
+def test_bf16_inference_cache_follows_every_kind_of_parameter_write(cuda):
+    """The bf16 forward pass keeps its packed weights and folded BatchNorm coefficients between calls; a
+    write through torch (set_weights, a poked tensor, moving statistics), a training step (eager or a graph
+    replay) and a training-mode forward each make it rebuild them."""
+    from leaffliction_amd.model.cnn import LeafCNN
+    g = torch.Generator().manual_seed(5)
+    model = LeafCNN(num_classes=3, img_size=32, widths=[32, 64], seed=2, device=cuda)
+    model.set_inference_dtype("bf16")
+    x = torch.randint(0, 256, (6, 32, 32, 3), dtype=torch.uint8, generator=g).to(cuda)
+    y = F.one_hot(torch.randint(0, 3, (6,), generator=g), 3).float().to(cuda)
+
+    def fresh():   # the same forward pass with nothing kept
+        model._infer_cache = {}
+        return model.predict_device(x).clone()
+
+    p0 = model.predict_device(x).clone()
+    assert torch.equal(p0, model.predict_device(x)) and torch.equal(p0, fresh())
+    model.p["s0.c1.w"].mul_(1.5)                                   # a write through torch
+    p1 = model.predict_device(x).clone()
+    assert not torch.equal(p0, p1) and torch.equal(p1, fresh())
+    model.s["s1.bn2.var"].add_(0.5)                                # moving statistics
+    p2 = model.predict_device(x).clone()
+    assert not torch.equal(p1, p2) and torch.equal(p2, fresh())
+    for _ in range(5):                                             # steps 3.. replay a HIP graph
+        model.train_step(x, y, 1e-2)
+        pk = model.predict_device(x).clone()
+        assert torch.equal(pk, fresh())
+    w = model.get_weights()
+    model.set_weights([a * 0.5 for a in w])
+    p3 = model.predict_device(x).clone()
+    assert not torch.equal(pk, p3) and torch.equal(p3, fresh())
