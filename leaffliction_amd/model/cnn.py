@@ -85,6 +85,8 @@ class Normalization:
 
 class LeafCNN:
     name = "leaf_cnn"
+    _mut = 0                            # see __init__ (class-level defaults: subclasses that skip it still step)
+    _infer_cache: Dict[str, Any] = {}
 
     def __init__(self, *, num_classes: int, img_size: int = 224, use_norm: bool = True,
                  widths: Optional[List[int]] = None, drop_block: float = 0.15,
