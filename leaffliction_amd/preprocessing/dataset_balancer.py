@@ -94,18 +94,51 @@ class DatasetBalancer:
         logger.info(f"Preparing target directory: {self.target_dir}")
         if self.target_dir.exists():
             shutil.rmtree(self.target_dir)
-        # The tree is laid out first (directories and EMPTY files, in copytree's own order, so that the target's
-        # directory order — the order `random.choice` indexes into — is the one a plain copy gives), the bytes
-        # follow on a thread while the workers already decode from the source tree (`read_img`): the copy of the
-        # originals was a quarter of the whole job.  execute_balancing joins the thread before the manifest.
+        # The tree is laid out first (directories and EMPTY files, in copytree's own order — scandir order, a
+        # directory recursed into where it comes — so that the target's directory order, the order `random.choice`
+        # indexes into, is the one a plain copy gives), the bytes follow on a thread while the workers already
+        # decode from the source tree (`read_img`): the copy of the originals was a quarter of the whole job.
+        # execute_balancing joins the thread before the manifest.  The placeholders of DIFFERENT leaf directories
+        # are created side by side (the syscalls release the GIL): on the GPU box's overlay file system one creation
+        # costs 70-120 us, 8,500 of them a third of the whole job when done one after the other.
+        per_dir: List[List[tuple]] = []   # leaf directories: their files, in order, laid out in parallel
         pending: List[tuple] = []
+        dirs: List[tuple] = []
 
-        def placeholder(src, dst):
-            os.close(os.open(dst, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666))   # (a third of io.open's cost)
-            pending.append((src, dst))
-            return dst
+        def touch(dst: str) -> None:
+            os.close(os.open(dst, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666))
 
-        shutil.copytree(self.source_dir, self.target_dir, copy_function=placeholder)
+        def walk(src: str, dst: str) -> None:
+            os.makedirs(dst)
+            dirs.append((src, dst))
+            with os.scandir(src) as it:
+                entries = list(it)
+            mixed = any(e.is_dir() for e in entries)   # files next to directories: strictly in order, here
+            files: List[tuple] = []
+            for e in entries:
+                d = os.path.join(dst, e.name)
+                if e.is_dir():
+                    walk(e.path, d)
+                elif mixed:
+                    touch(d)
+                    pending.append((e.path, d))
+                else:
+                    files.append((e.path, d))
+            if files:
+                per_dir.append(files)
+
+        walk(str(self.source_dir), str(self.target_dir))
+
+        def lay(files: List[tuple]) -> None:
+            for _src, dst in files:
+                touch(dst)
+
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            list(ex.map(lay, per_dir))
+        for src, dst in reversed(dirs):   # copytree copies a directory's stat once its entries are in place
+            shutil.copystat(src, dst)
+        pending += [pair for files in per_dir for pair in files]
 
         def fill():
             for src, dst in pending:
