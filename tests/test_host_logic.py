@@ -296,3 +296,19 @@ def test_manifest_text_equals_json_dumps_indent2():
              {"meta": {"a": 1}, "items": [{}]}, [1, 2], {"meta": {"a": 1}, "items": [{1: "a"}]}]
     for man in cases:
         assert M._dumps(man) == json.dumps(man, indent=2, ensure_ascii=False)
+
+
+def test_codec_pool_job_splitting():
+    """Decode / encode jobs are cut into `pieces_per_worker` runs per worker: contiguous, in order, nothing lost;
+    a small batch with one piece per worker does not fall apart into one-task jobs."""
+    from leaffliction_amd.preprocessing.codec_pool import CodecPool
+    pool = CodecPool.__new__(CodecPool)
+    pool.workers = 12
+    jobs = list(range(256))
+    for pieces in (1, 2, 4):
+        parts = pool._split(jobs, pieces)
+        assert [j for p in parts for j in p] == jobs
+        assert len(parts) <= pieces * pool.workers and max(map(len, parts)) == -(-256 // (pieces * 12))
+    assert [len(p) for p in pool._split(list(range(32)), 1)] == [3] * 10 + [2]
+    assert len(pool._split(list(range(32)), 4)) == 32
+    assert pool._split([], 2) == []
