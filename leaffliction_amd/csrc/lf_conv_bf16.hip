@@ -687,8 +687,10 @@ int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y
     hipStream_t s = lf::as_stream(stream);
     if (y_bf16 && cout == 32 && lf::conv_bf16s_parts(n, cin, h, w, cout, ksize, x_bf16) > 0) {
         // the 224x224 stage (stem, 32->32): the streaming kernel (resident filter bank, 16-byte accesses).
-        // With no read-modify-write epilogue the K-chunked kernel stays ahead on the 64-channel layers
-        // (1.7 ms against 3.2 ms at 64->64 / 112x112, batch 1,024), the other way round from training.
+        // The 64-channel layers of the 112x112 stage stay on the K-chunked kernel: it was well ahead there
+        // without a read-modify-write epilogue (1.7 ms against 3.2 ms at 64->64, batch 1,024) and is level with
+        // the streaming kernel since that one got 64x4 tiles and per-XCD tile rows (whole forward pass
+        // 52.4 k img/s as routed here, 52.7 k with every covered layer on the streaming kernel).
         lf::ConvBf16TrainArgs t{};
         t.x = x; t.wprep = wprep; t.y = static_cast<uint16_t*>(y); t.n = n; t.cin = cin; t.h = h; t.w = w; t.cout = cout;
         t.in_scale = in_scale; t.in_shift = in_shift; t.in_relu = in_relu;
