@@ -247,3 +247,6 @@ class CodecPool:
                 s.close()
             except BufferError:     # a caller still holds a view: its mapping outlives the pool, harmlessly
                 pass
+        # the workers got their stop while the slabs were being taken down: wait for them and for the executor's
+        # own thread HERE, in a healthy process, rather than leave that to the interpreter's exit handlers
+        self.pool.shutdown(wait=True)
