@@ -618,14 +618,14 @@ def main() -> None:
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    dp = None
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
+        # the training path's own data-parallel glue (what cli.train uses): process group over RCCL, the flat
+        # gradient bucket all-reduced in the dtype LEAFFLICTION_GRAD_BUCKET names
+        from leaffliction_amd.train.parallel import DataParallel
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        dp = DataParallel(backend=backend, device=dev)
+        dist = dp.dist
 
     from leaffliction_amd import _lib
     from leaffliction_amd.model.cnn import LeafCNN
@@ -646,14 +646,12 @@ def main() -> None:
     y = (torch.nn.functional.one_hot(labels, NUM_CLASSES).float() * (1 - 0.02) + 0.02 / NUM_CLASSES).to(dev)
 
     total = args.warmup + args.steps
-    grad_sync = None
-    if world > 1:
-        def grad_sync(flat_g):  # one flat bucket, averaged over ranks (RCCL over xGMI)
-            if backend == "nccl":
-                dist.all_reduce(flat_g, op=dist.ReduceOp.AVG)
-            else:
-                dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
-                flat_g.mul_(1.0 / world)
+    # data-parallel: local gradients are scaled by 1/global_batch inside the step and the bucket is SUMmed over the
+    # ranks by DataParallel.allreduce_grads (fp32 bucket, or bf16 under LEAFFLICTION_GRAD_BUCKET=bf16) — the same
+    # call `fit` makes
+    grad_sync = dp.allreduce_grads if dp is not None else None
+    global_n = world * n if dp is not None else None
+    step_kw = {"grad_sync": grad_sync, "global_n": global_n}
 
     def lr_at(step):
         return 2e-3 * 0.5 * (1.0 + math.cos(math.pi * min(step, total) / total))
@@ -663,7 +661,7 @@ def main() -> None:
         pairs; returns (seconds, max over ranks; final mean loss)."""
         nonlocal step
         for _ in range(warmup):
-            model.train_step(x, y, lr_at(step), grad_sync=grad_sync)
+            model.train_step(x, y, lr_at(step), **step_kw)
             step += 1
         if dist is not None:
             dist.barrier()
@@ -671,7 +669,7 @@ def main() -> None:
         timer.enabled = True
         t0 = time.perf_counter()
         for _ in range(steps):
-            _probs, loss = model.train_step(x, y, lr_at(step), grad_sync=grad_sync)
+            _probs, loss = model.train_step(x, y, lr_at(step), **step_kw)
             step += 1
         torch.cuda.synchronize()
         if dist is not None:
@@ -743,11 +741,11 @@ def main() -> None:
         nonlocal step
         timer.records.clear()
         graphs, model._graphs_on = model._graphs_on, False
-        model.train_step(x, y, lr_at(step), grad_sync=grad_sync)   # eager warm-up
+        model.train_step(x, y, lr_at(step), **step_kw)   # eager warm-up
         torch.cuda.synchronize()
         timer.enabled = True
         for _ in range(steps):
-            model.train_step(x, y, lr_at(step), grad_sync=grad_sync)
+            model.train_step(x, y, lr_at(step), **step_kw)
         torch.cuda.synchronize()
         timer.enabled = False
         model._graphs_on = graphs
@@ -784,7 +782,7 @@ def main() -> None:
                "config": {"workload": "leaf_cnn base train step, mixed precision (configs[3] per-GPU work: img 224, "
                                       "batch 256/GPU, bf16, 8 classes, AdamW+clipnorm+EMA, in-model augmentation)",
                           "per_gpu_batch": n, "global_batch": world * n, "img_size": IMG,
-                          "parallelism": f"dp{world}", "grad_bucket": model.grad_bucket_dtype},
+                          "parallelism": f"dp{world}", "grad_bucket": dp.bucket_dtype if dp is not None else None},
                "roofline": bf16["roofline"], "conv_all": bf16["conv_all"], "step_tflops": bf16["step_tflops"],
                "final_loss": bf16["final_loss"], "per_kernel": bf16["per_kernel"]}
         if not args.no_cpu_baseline and world == 1:
@@ -860,9 +858,9 @@ def main() -> None:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if dp is not None:
+        dp.barrier()
+        dp.shutdown()
 
 
 if __name__ == "__main__":

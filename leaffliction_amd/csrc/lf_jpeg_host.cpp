@@ -341,7 +341,12 @@ struct Reader {
     const uint8_t* end;
     uint64_t buf = 0;
     int n = 0;
+    int pad = 0;           // zero bits fed after the data ran out / a marker came: always the LAST `pad` bits of buf
     bool marker = false;   // ran into a marker: zeros are fed from here on
+    // true once the decoder has CONSUMED bits that were never in the file (the scan ended early: a truncated file,
+    // or a marker in the middle of the entropy-coded segment).  Look-ahead padding that is still in the buffer
+    // does not count: the last MCU of an intact file is decoded with zeros queued behind its bits.
+    bool starved() const { return n < pad; }
     void fill() {
         if (!marker && p + 8 <= end && n <= 56) {   // fast path: no 0xFF among the next eight bytes
             uint64_t v;
@@ -358,19 +363,23 @@ struct Reader {
         }
         while (n <= 56) {
             unsigned b = 0;
+            bool real = false;
             if (!marker && p < end) {
                 b = *p;
+                real = true;
                 if (b == 0xFF) {
                     if (p + 1 < end && p[1] == 0x00) {
                         p += 2;
                     } else {
                         marker = true;
+                        real = false;
                         b = 0;
                     }
                 } else {
                     ++p;
                 }
             }
+            if (!real) pad += 8;
             buf |= (uint64_t)b << (56 - n);
             n += 8;
         }
@@ -383,7 +392,18 @@ struct Reader {
     void reset() {
         buf = 0;
         n = 0;
+        pad = 0;
         marker = false;
+    }
+    // The first marker at or after the reader's position in the FILE (bits still queued in `buf` are bytes the
+    // file pointer has passed): 0 when the data ends without one.  Stuffed 0xFF00 pairs and fill bytes are skipped.
+    unsigned next_marker() const {
+        const uint8_t* q = p;
+        while (q + 1 < end) {
+            if (q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF) return q[1];
+            ++q;
+        }
+        return 0;
     }
 };
 
@@ -527,6 +547,7 @@ extern "C" int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef,
             int until_restart = restart;
             for (long mcu = 0; mcu < mcus; ++mcu) {
                 if (restart && until_restart == 0) {
+                    if (r.starved()) return -1;   // the interval before this marker ended inside an MCU
                     // byte-align, expect RSTn
                     const uint8_t* mp = r.p;
                     while (mp + 1 < r.end && mp < r.p + 8 && !(mp[0] == 0xFF && mp[1] >= 0xD0 && mp[1] <= 0xD7)) ++mp;
@@ -543,6 +564,11 @@ extern "C" int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef,
                 if (!decode_block(r, b + 320, pred[2], dc[td[2]], ac[ta[2]])) return -1;
                 if (restart) --until_restart;
             }
+            // A file cut inside its scan decodes "successfully" on padding zeros; Pillow raises "image file is
+            // truncated" for it (image_utils.py:19-33 then counts the task as failed / skips the file).  Such a
+            // file — bits consumed that were never there, or no EOI behind the scan — is handed back (-1) and the
+            // caller's libjpeg path gives the reference's verdict.
+            if (r.starved() || r.next_marker() != 0xD9) return -1;
             *h_out = h;
             *w_out = w;
             return 0;

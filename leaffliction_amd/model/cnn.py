@@ -117,7 +117,6 @@ class LeafCNN:
         if self.train_dtype not in ("f32", "bf16"):
             raise ValueError("LEAFFLICTION_TRAIN_DTYPE must be f32 or bf16")
         # (the data-parallel gradient bucket's dtype is train.parallel.DataParallel.bucket_dtype)
-        self.grad_bucket_dtype = os.environ.get("LEAFFLICTION_GRAD_BUCKET", "f32")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.norm = Normalization() if use_norm else None
         self.stop_training = False
@@ -412,7 +411,7 @@ class LeafCNN:
     def set_inference_dtype(self, dtype: str) -> None:
         """"f32" (default) or "bf16": the arithmetic of the convolutions in predict / evaluate.
         The reference runs them in half precision under its default mixed_float16 policy
-        (train.py:53-117); training here is fp32 either way."""
+        (train.py:53-117).  The training step's precision is set_training_dtype's."""
         if dtype not in ("f32", "bf16"):
             raise ValueError(f"inference dtype must be 'f32' or 'bf16', got {dtype!r}")
         self.infer_dtype = dtype
@@ -773,6 +772,11 @@ class LeafCNN:
         if st is None:
             st = self._graphs[key] = {"calls": 0, "graph": None}
         st["calls"] += 1
+        if st["graph"] is not None and st["ws_gen"] != nn.workspace_generation():
+            # a launch somewhere in the process (a larger batch, another model) has replaced one of the library's
+            # workspace buffers since this graph was recorded: its nodes hold pointers into the freed buffer.
+            # Drop it and record the step again (this call runs eagerly on the current buffers).
+            st["graph"], st["calls"] = None, 2
         if st["graph"] is None and st["calls"] <= 2:
             return self._forward_backward_eager(x, y_true)
         drops, top, aug4 = self.draw_step_randoms(n, self.augment)  # fixed device views, fresh values
@@ -791,6 +795,7 @@ class LeafCNN:
                 torch.cuda.synchronize()
                 return self._forward_backward_body(x, y_true, drops, top, aug4)
             st["graph"] = g
+            st["ws_gen"] = nn.workspace_generation()
         else:
             st["x"].copy_(x)
             st["y"].copy_(y_true)

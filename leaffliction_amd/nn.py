@@ -11,18 +11,33 @@ from .ops import _chk, _stream
 
 _F32 = torch.float32
 _ws_cache = {}
+_ws_gen = 0
 # A/B knob for measurements: route BatchNorm backward through the standalone apply kernel
 _NO_FUSED_BN_WGRAD = os.environ.get("LEAFFLICTION_NO_FUSED_BN_WGRAD", "0") == "1"
 
 
 def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
-    """Grow-only scratch buffer per device and slot (the C ABI never allocates)."""
+    """Grow-only scratch buffer per device and slot (the C ABI never allocates).
+
+    A buffer that is replaced goes back to torch's allocator, so every pointer taken from it is dead from then on.
+    `workspace_generation()` counts the replacements: whoever keeps such pointers beyond the call — the HIP graph of
+    the training step has them baked into its kernel nodes — compares generations and re-records (model/cnn.py)."""
+    global _ws_gen
     key = (str(device), slot)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("a workspace would have to grow while a HIP graph is being recorded: run the shape "
+                               "eagerly first (the warm-up steps size every workspace)")
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+        _ws_gen += 1
     return buf
+
+
+def workspace_generation() -> int:
+    """Number of times a workspace buffer has been (re)allocated in this process; see _workspace."""
+    return _ws_gen
 
 
 def _ptr(t: Optional[torch.Tensor]):

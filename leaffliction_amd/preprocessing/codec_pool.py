@@ -33,6 +33,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 _SLABS: Dict[str, shared_memory.SharedMemory] = {}
+_DEBUG: list = []
 
 
 def _slabs(names: Dict[str, str]) -> Dict[str, shared_memory.SharedMemory]:
@@ -50,7 +51,13 @@ def _warm(_i: int) -> bool:
     from .image_augmenter import draw_params  # noqa: F401
     from ..utils import jpeg_host
     jpeg_host.load()
+    import os
     import time
+    stacks = os.environ.get("LEAFFLICTION_DEBUG_STACKS")
+    if stacks and not _DEBUG:   # diagnosis of a stuck job: every worker leaves its Python stacks after 100 s
+        import faulthandler
+        _DEBUG.append(open(os.path.join(stacks, f"codec_{os.getppid()}_{os.getpid()}.txt"), "w"))
+        faulthandler.dump_traceback_later(100, exit=False, file=_DEBUG[0])
     time.sleep(0.05)   # long enough that every worker of the pool takes one
     return True
 
@@ -234,7 +241,19 @@ class CodecPool:
         return [self.pool.submit(_encode_jobs, self.names, part) for part in self._split(jobs)]
 
     def close(self) -> None:
-        self.pool.shutdown(wait=False, cancel_futures=True)   # every result has been collected
+        """Stop the workers and WAIT for them, then take the slabs down.
+
+        The wait has to be a real one.  Round 2 called `shutdown(wait=False)` first and `shutdown(wait=True)` at the
+        end, believing the second call joined the executor — it does not: the first call already drops the executor's
+        reference to its manager thread (concurrent/futures/process.py, `self._executor_manager_thread = None`), so
+        the second has nothing to join.  The manager thread was then still on its way to the workers' stop sentinels
+        when a short-lived process (a rank of the two-rank job) reached its exit handlers: multiprocessing's exit
+        finalizers close the call queue — its feeder thread leaves — BEFORE the sentinels are queued, the sentinels
+        are never written to the pipe, the workers wait on it for ever (every worker holds a duplicate of the pipe's
+        write end, so there is no EOF either), and both the manager thread and the exit handler sit in `p.join()`.
+        Those are exactly the stacks a stuck rank and its workers left (tests/test_sharded_paths.py, round 3: ranks in
+        `join_executor_internals -> p.join()` and `_exit_function -> p.join()`, workers in `call_queue.get()`)."""
+        self.pool.shutdown(wait=True, cancel_futures=True)   # every result has been collected; returns once the workers are gone
         self.unpin()
         import gc
         gc.collect()   # numpy views of the slabs that are only kept alive by cycles
@@ -247,6 +266,3 @@ class CodecPool:
                 s.close()
             except BufferError:     # a caller still holds a view: its mapping outlives the pool, harmlessly
                 pass
-        # the workers got their stop while the slabs were being taken down: wait for them and for the executor's
-        # own thread HERE, in a healthy process, rather than leave that to the interpreter's exit handlers
-        self.pool.shutdown(wait=True)

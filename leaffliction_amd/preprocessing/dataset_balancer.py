@@ -140,19 +140,30 @@ class DatasetBalancer:
             shutil.copystat(src, dst)
         pending += [pair for files in per_dir for pair in files]
 
+        self._copy_error = None
+
         def fill():
-            for src, dst in pending:
-                shutil.copy2(src, dst)
+            try:
+                for src, dst in pending:
+                    shutil.copy2(src, dst)
+            except BaseException as e:  # noqa: BLE001 — re-raised on the main thread by _join_copy
+                self._copy_error = e
 
         import threading
         self._copying = threading.Thread(target=fill, name="copy-originals", daemon=True)
         self._copying.start()
 
     def _join_copy(self) -> None:
+        """Wait for the originals' bytes.  A failure of the copy (disk full, a source file gone, permissions) is
+        raised HERE, on the main thread, as the reference's copytree would raise it (dataset_balancer.py:70-81):
+        a tree of zero-byte placeholders must never be reported as a finished job."""
         t = getattr(self, "_copying", None)
         if t is not None:
             t.join()
             self._copying = None
+        err, self._copy_error = getattr(self, "_copy_error", None), None
+        if err is not None:
+            raise err
 
     def _images_by_class(self) -> Dict[str, List[Path]]:
         """class name -> its images in the target tree, `*.JPG` before `*.jpg`, each in glob
@@ -377,12 +388,40 @@ class DatasetBalancer:
         rk = self.ranks
         t0 = time.perf_counter()
         self._codec = CodecPool(self.workers)   # the workers start (and import) while the tree is copied
+        try:
+            self._execute_shares(rk, t0)
+        except BaseException:
+            # the path that never reached _run_share's own clean-up (or left the copy thread behind): stop the codec
+            # workers and take their shared-memory slabs down now rather than leave that to exit handlers, and wait
+            # for the copy thread — its own failure, if any, yields to the exception already on its way up
+            pool, self._codec = getattr(self, "_codec", None), None
+            if pool is not None:
+                pool.close()
+            try:
+                self._join_copy()
+            except BaseException:  # noqa: BLE001
+                pass
+            raise
+
+    def _execute_shares(self, rk, t0: float) -> None:
+        prep_error = None
         if rk.rank == 0:
-            self._fresh_target()
-            t1 = time.perf_counter()
-            self.tasks = self.build_tasks(self._images_by_class())
-            self.timings = {"copy_originals": t1 - t0, "task_list": time.perf_counter() - t1}
-        self.tasks = rk.broadcast_object(self.tasks if rk.rank == 0 else None)
+            # A failure while rank 0 prepares the job (source missing, rmtree / permission errors, a bad plan) must
+            # reach EVERY rank: the others would otherwise wait in the broadcast until the process group times out.
+            try:
+                self._fresh_target()
+                t1 = time.perf_counter()
+                self.tasks = self.build_tasks(self._images_by_class())
+                self.timings = {"copy_originals": t1 - t0, "task_list": time.perf_counter() - t1}
+            except Exception as e:  # noqa: BLE001
+                prep_error = e
+        payload = rk.broadcast_object(({"error": f"{type(prep_error).__name__}: {prep_error}"} if prep_error is not None
+                                       else {"tasks": self.tasks}) if rk.rank == 0 else None)
+        if "error" in payload:
+            if prep_error is not None:
+                raise prep_error
+            raise RuntimeError(f"rank 0 could not prepare the balancing job - {payload['error']}")
+        self.tasks = payload["tasks"]
         total = len(self.tasks)
         begin, end = contiguous_share(total, rk.rank, rk.world)
         logger.info(f"Starting GPU augmentation: {total} images to generate"

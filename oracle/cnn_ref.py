@@ -169,8 +169,10 @@ def input_stage(x_u8: torch.Tensor, aug: Optional[torch.Tensor], mean=None, deno
 
 
 def bf16_round(t: torch.Tensor) -> torch.Tensor:
-    """fp32 -> nearest-even bf16 -> fp32 (what a bf16 store followed by a load yields)."""
-    return t.to(torch.bfloat16).to(torch.float32)
+    """fp32 -> nearest-even bf16 -> fp32 (what a bf16 store followed by a load yields).  A float64 tensor comes back
+    as float64 (the rounding is the same; tests run the restatement in double precision to see how far a change of
+    ACCUMULATION precision alone moves a bf16 step)."""
+    return t.to(torch.bfloat16).to(t.dtype)
 
 
 def _q(t: torch.Tensor, round_grad: bool = True) -> torch.Tensor:

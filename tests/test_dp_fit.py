@@ -176,9 +176,10 @@ def test_early_stopping_restores_best_without_stopping():
 
 
 # ------------------------------------------------------------------ GPU: the real model
-def _gpu_fit_worker(rank, world, port, root, n_items, batch, out_dir, dup):
+def _gpu_fit_worker(rank, world, port, root, n_items, batch, out_dir, dup, dtype="f32", bucket="f32"):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
-                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LEAFFLICTION_DIST_TIMEOUT": "180"})
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LEAFFLICTION_DIST_TIMEOUT": "180",
+                       "LEAFFLICTION_GRAD_BUCKET": bucket})
     torch.cuda.set_device(0)
     from leaffliction_amd.train.parallel import DataParallel
     from leaffliction_amd.train.utils import CosineDecay
@@ -189,8 +190,12 @@ def _gpu_fit_worker(rank, world, port, root, n_items, batch, out_dir, dup):
              for i in range(n_items) for c in (["a", "b"][(i // (2 if dup else 1)) % 2],)]
     seq = ManifestSequence(items, l2i, 32, batch, shuffle=not dup, seed=7, num_classes=2, one_hot=True,
                            rank=rank, world=world)
-    m = LeafCNN(num_classes=2, img_size=32, widths=[16, 32], l2_reg=1e-4, use_norm=False, seed=5,
+    # bf16: widths that take the mixed-precision kernels (multiples of 32), as BASELINE configs[3] runs them
+    m = LeafCNN(num_classes=2, img_size=32, widths=[32, 64] if dtype == "bf16" else [16, 32], l2_reg=1e-4,
+                use_norm=False, seed=5,
                 drop_block=0.0 if dup else 0.15, drop_top=0.0 if dup else 0.4, augment=not dup)
+    m.set_training_dtype(dtype)
+    assert dp.bucket_dtype == bucket
     dp.broadcast_(m.flat_p, 0)
     m.reseed_step_rng(5 + rank)
     if dup:   # gradients of ONE global batch: forward/backward + all-reduce, no optimizer
@@ -201,25 +206,36 @@ def _gpu_fit_worker(rank, world, port, root, n_items, batch, out_dir, dup):
         m._forward_backward(bx, yt)
         dp.allreduce_grads(m.flat_g)
         torch.cuda.synchronize()
-        torch.save({"g": m.flat_g.cpu()}, Path(out_dir) / f"g{world}_{rank}.pt")
+        torch.save({"g": m.flat_g.cpu()}, Path(out_dir) / f"g{world}_{rank}_{dtype}_{bucket}.pt")
     else:
         m.compile(optimizer={"name": "adamw", "schedule": CosineDecay(2e-3, len(seq) * 2),
                              "weight_decay": 1e-4, "clipnorm": 0.5, "ema_decay": 0.999},
                   loss={"label_smoothing": 0.02})
         m.fit(seq, epochs=2, dp=dp, verbose=0)
         torch.cuda.synchronize()
-        torch.save({"p": m.flat_p.cpu(), "ema": m.flat_ema.cpu(), "opt_step": m.opt_step},
+        torch.save({"p": m.flat_p.cpu(), "ema": m.flat_ema.cpu(), "opt_step": m.opt_step,
+                    "graphs": sum(st["graph"] is not None for st in m._graphs.values())},
                    Path(out_dir) / f"r{rank}.pt")
     dp.shutdown()
 
 
+# (training dtype, gradient-bucket dtype): fp32 as configs[1] shards it, and BASELINE configs[3]'s combination —
+# the bf16 step under data parallelism — with the exact fp32 bucket and with the halved bf16 bucket
+DP_MODES = [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16")]
+
+
 @pytest.mark.gpu
-def test_fit_ragged_last_batch_real_model_world2(cuda, tmp_path):
+@pytest.mark.parametrize("dtype,bucket", DP_MODES)
+def test_fit_ragged_last_batch_real_model_world2(cuda, tmp_path, dtype, bucket):
+    """`fit` under world size 2 with the real model: 5 items, global batch 4 (rank 1's slice of the last global
+    batch is empty), 2 epochs.  Both ranks finish, take the same steps and end with BIT-equal parameters and EMA,
+    whatever the step's precision and the bucket's: every rank all-reduces the same bits and applies the same
+    deterministic optimizer kernels."""
     root = tmp_path / "img"
     root.mkdir()
     _write_images(root, 5, 32)
-    mp.spawn(_gpu_fit_worker, args=(2, _free_port(), str(root), 5, 4, str(tmp_path), False), nprocs=2,
-             join=True)
+    mp.spawn(_gpu_fit_worker, args=(2, _free_port(), str(root), 5, 4, str(tmp_path), False, dtype, bucket),
+             nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert r0["opt_step"] == r1["opt_step"] == 4
     assert torch.equal(r0["p"], r1["p"]) and torch.equal(r0["ema"], r1["ema"])
@@ -227,19 +243,53 @@ def test_fit_ragged_last_batch_real_model_world2(cuda, tmp_path):
 
 
 @pytest.mark.gpu
-def test_two_rank_gradients_equal_one_rank(cuda, tmp_path):
+@pytest.mark.parametrize("dtype,bucket", [("bf16", "f32"), ("bf16", "bf16")])
+def test_fit_graph_replay_world2_bf16(cuda, tmp_path, dtype, bucket):
+    """Enough full batches per rank that the bf16 step is REPLAYED from its HIP graph under data parallelism (the
+    third step of a shape is captured): 16 items, global batch 4, 2 epochs = 8 steps of 2 images per rank.
+    Bit-equal replicas, and at least one captured graph on each rank."""
+    root = tmp_path / "img"
+    root.mkdir()
+    _write_images(root, 16, 32)
+    mp.spawn(_gpu_fit_worker, args=(2, _free_port(), str(root), 16, 4, str(tmp_path), False, dtype, bucket),
+             nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert r0["opt_step"] == r1["opt_step"] == 8
+    assert r0["graphs"] >= 1 and r1["graphs"] >= 1
+    assert torch.equal(r0["p"], r1["p"]) and torch.equal(r0["ema"], r1["ema"])
+    assert torch.isfinite(r0["p"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,bucket", DP_MODES)
+def test_two_rank_gradients_equal_one_rank(cuda, tmp_path, dtype, bucket):
     """Global batch {a,a,b,b}: the rank-strided shards are {a,b} and {a,b}, so per-GPU BatchNorm
     statistics equal the global ones and the all-reduced 2-rank gradient must equal the 1-rank
-    gradient of the whole batch (fp32 rounding apart)."""
+    gradient of the whole batch — up to fp32 summation order with the fp32 bucket (also under the bf16 step, whose
+    roundings are per element and therefore the same in both runs), and up to the bucket's own rounding with the
+    bf16 bucket: each rank's contribution is rounded to bf16 (relative 2^-9), the sum of the two once more,
+    i.e. at most 2^-8 + 2^-9 of the larger of |g| and the two contributions — 3 * 2^-9 * |g1| here, since both
+    ranks contribute g1 / 2."""
     root = tmp_path / "img"
     root.mkdir()
     _write_images(root, 8, 32, dup=True)
-    mp.spawn(_gpu_fit_worker, args=(2, _free_port(), str(root), 8, 8, str(tmp_path), True), nprocs=2,
-             join=True)
-    mp.spawn(_gpu_fit_worker, args=(1, _free_port(), str(root), 8, 8, str(tmp_path), True), nprocs=1,
-             join=True)
-    g2a, g2b = torch.load(tmp_path / "g2_0.pt")["g"], torch.load(tmp_path / "g2_1.pt")["g"]
-    g1 = torch.load(tmp_path / "g1_0.pt")["g"]
+    mp.spawn(_gpu_fit_worker, args=(2, _free_port(), str(root), 8, 8, str(tmp_path), True, dtype, bucket),
+             nprocs=2, join=True)
+    mp.spawn(_gpu_fit_worker, args=(1, _free_port(), str(root), 8, 8, str(tmp_path), True, dtype, bucket),
+             nprocs=1, join=True)
+    g2a = torch.load(tmp_path / f"g2_0_{dtype}_{bucket}.pt")["g"]
+    g2b = torch.load(tmp_path / f"g2_1_{dtype}_{bucket}.pt")["g"]
+    g1 = torch.load(tmp_path / f"g1_0_{dtype}_{bucket}.pt")["g"]
     assert torch.equal(g2a, g2b)
     assert g1.abs().max() > 0
-    assert (g2a - g1).abs().max().item() <= 2e-4 * g1.abs().max().item()
+    scale = g1.abs().max().item()
+    if bucket == "f32":
+        # bf16 step: a 2-image shard and the 4-image batch sum their statistics / weight gradients in another
+        # order, and a statistic that moves by one fp32 ulp can flip the bf16 rounding of single activations
+        tol = 2e-4 * scale if dtype == "f32" else 2e-2 * scale
+        assert (g2a - g1).abs().max().item() <= tol, (g2a - g1).abs().max().item() / scale
+    else:
+        exact = (g2a - g1).abs() <= 3 * 2.0 ** -9 * g1.abs() + 2e-2 * scale
+        assert bool(exact.all()), ((g2a - g1).abs().max().item() / scale)
+        # the bucket really was bf16: every summed value is representable in bf16
+        assert torch.equal(g2a, g2a.to(torch.bfloat16).float())

@@ -148,6 +148,29 @@ def test_host_reader_declines_what_it_does_not_cover():
     assert jpeg_host.read_file(_save(a, quality=90)[:400]) is None                     # truncated
 
 
+@pytest.mark.parametrize("kw", [dict(quality=90), dict(quality=95, restart_marker_rows=1)])
+def test_host_reader_hands_back_files_cut_inside_the_scan(kw):
+    """A file truncated INSIDE its entropy-coded scan (or missing its EOI) must not come back as pixels: Pillow raises
+    "image file is truncated" for it, which is what makes the reference count the task as failed / skip the file
+    (image_utils.py:19-33).  The reader used to decode the missing MCUs from padding zeros and report success; it
+    now declines, and the caller's libjpeg path gives the reference's verdict."""
+    import io
+    from PIL import Image
+    from leaffliction_amd.utils import jpeg_host
+    a = scene(224, 224, 5)
+    data = _save(a, **kw)
+    assert jpeg_host.read_file(data) is not None                                       # the intact file is taken
+    for cut in (len(data) // 2, len(data) * 3 // 4, len(data) - 40, len(data) - 3, len(data) - 2, len(data) - 1):
+        assert jpeg_host.read_file(data[:cut]) is None, cut
+        with pytest.raises(OSError):                                                   # ... and Pillow refuses it
+            Image.open(io.BytesIO(data[:cut])).convert("RGB")
+    # a marker planted in the middle of the scan ends it early: declined as well
+    mid = len(data) // 2
+    assert jpeg_host.read_file(data[:mid] + b"\xff\xd9" + data[mid + 2:]) is None
+    # trailing bytes behind EOI are harmless (Pillow reads such files)
+    assert jpeg_host.read_file(data + b"\x00" * 7) is not None
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("h,w,kw", [(224, 224, dict(quality=95)), (64, 96, dict(quality=70, optimize=True)),
                                     (48, 208, dict(quality=85, restart_marker_rows=1)), (16, 16, dict(quality=95)),

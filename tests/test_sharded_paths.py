@@ -98,12 +98,17 @@ def _join(rank, world, port, gpu):
     return R.init_from_env()
 
 
+_KEEP_OPEN = []
+
+
 def _balance_worker(rank, world, port, src, dst, work, gpu):
     import faulthandler
 
     import torch.distributed as dist
     # a rank that is still here after 100 s leaves its stacks behind (see _spawn_bounded)
+    os.environ["LEAFFLICTION_DEBUG_STACKS"] = work     # the codec workers leave theirs as well (codec_pool._warm)
     stacks = open(os.path.join(work, f"stacks_{world}_{rank}.txt"), "w")
+    _KEEP_OPEN.append(stacks)   # the watchdog writes to this descriptor after the function has returned
     faulthandler.dump_traceback_later(100, exit=False, file=stacks)
     rk = _join(rank, world, port, gpu)
     os.chdir(work)
@@ -116,16 +121,18 @@ def _balance_worker(rank, world, port, src, dst, work, gpu):
         {"completed": bal.completed, "failed": bal.failed, "tasks": len(bal.tasks), "share": [b, e]}))
     if rk.active:
         dist.destroy_process_group()
-    faulthandler.cancel_dump_traceback_later()
+    # the watchdog stays armed on purpose: the hang this guards against sits in the interpreter's EXIT path, after
+    # this function has returned (a process that exits in time takes the watchdog thread with it)
+    if world == 1 and not gpu:
+        faulthandler.cancel_dump_traceback_later()   # in-process call (the pytest process itself)
 
 
 def _spawn_bounded(fn, args, nprocs, limit=150.0):
-    """mp.spawn with a deadline: True when every rank finished, False when the ranks had to be killed.  (About one
-    run in twenty of the two-rank CPU job has ended with both ranks asleep on a lock and their idle codec workers
-    beside them — no thread left in a poll, so nothing of gloo and nothing of the executor's plumbing — which the
-    per-test limit then reported after seven minutes.  Since CodecPool.close() joins its executor itself — instead of leaving that to the
-    interpreter's exit handlers — 180 consecutive runs were clean; should it come back, the stacks a stuck rank writes
-    after 100 s name the lock, and the job is run again.)"""
+    """mp.spawn with a deadline: True when every rank finished, False when the ranks had to be killed.  (Round 2 saw
+    about one run in twenty of the two-rank CPU job end with both ranks asleep on a process-shared semaphore on their
+    way OUT; CodecPool.close() now joins its executor itself instead of leaving that to the interpreter's exit handlers.
+    A run that overruns FAILS the test — no second attempt — and the failure message carries the Python stacks each
+    rank wrote after 100 s (`faulthandler`), which is the evidence to work from.)"""
     import time
     ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
     deadline = time.time() + limit
@@ -152,14 +159,11 @@ def _check_balancer(tmp_path, gpu):
             _balance_worker(0, 1, 0, str(src), str(dst), str(work), gpu) if not gpu else \
                 mp.spawn(_balance_worker, args=(1, _free_port(), str(src), str(dst), str(work), gpu), nprocs=1)
         else:
-            for attempt in range(2):
-                if _spawn_bounded(_balance_worker, (2, _free_port(), str(src), str(dst), str(work), gpu), 2):
-                    break
-                stuck = "\n".join(f"--- {f.name}\n{f.read_text()}" for f in sorted(work.glob("stacks_2_*.txt")))
-                print(f"two-rank balancer run {attempt} did not finish; stacks of the stuck ranks:\n{stuck}")
-                assert attempt == 0, "the two-rank balancer run hung twice"
-                shutil.rmtree(work)
-                work.mkdir()
+            if not _spawn_bounded(_balance_worker, (2, _free_port(), str(src), str(dst), str(work), gpu), 2):
+                stuck = "\n".join(f"--- {f.name}\n{f.read_text()}" for f in sorted([*work.glob("stacks_2_*.txt"),
+                                                                                         *work.glob("codec_*.txt")]))
+                pytest.fail(f"the two-rank balancer run did not finish within its deadline; stacks of the stuck "
+                            f"ranks:\n{stuck}")
         man = json.loads((work / "artifacts/datasets/manifest_augmented.json").read_text())
         man["meta"].pop("augmented_at")
         for it in man["items"]:
@@ -256,3 +260,81 @@ def test_balancer_two_ranks_equal_one_rank_gpu(cuda, tmp_path):
     os.environ.pop("WORLD_SIZE", None)
     os.environ.pop("CUDA_VISIBLE_DEVICES", None)
     assert tree_digest(cpu / "augmented") == digest
+
+
+# ------------------------------------------------------------------ failure paths of the job's preparation
+def test_a_failed_copy_of_the_originals_fails_the_job(tmp_path, monkeypatch):
+    """The originals' bytes follow on a thread behind the pipeline; when that copy fails (disk full, a source file
+    gone) the job must raise as the reference's copytree would (dataset_balancer.py:70-81), not report success over
+    a tree of zero-byte placeholders."""
+    import shutil as _sh
+    src = tmp_path / "images"
+    build_tree(src, 16)
+    bal = OracleBalancer(source_dir=str(src), target_dir=str(tmp_path / "aug"), seed=1, workers=1)
+    real = _sh.copy2
+    seen = []
+
+    def flaky(a, b, **kw):
+        seen.append(a)
+        if len(seen) == 3:
+            raise OSError(28, "No space left on device")
+        return real(a, b, **kw)
+
+    monkeypatch.setattr(_sh, "copy2", flaky)
+    os.chdir(tmp_path)
+    os.environ["CUDA_VISIBLE_DEVICES"] = ""
+    try:
+        with pytest.raises(OSError, match="No space left"):
+            bal.run()
+    finally:
+        os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+    assert bal._codec is None
+    assert not (tmp_path / "artifacts/datasets/manifest_augmented.json").exists()   # no manifest of a broken tree
+
+
+def _broken_prep_worker(rank, world, port, src, dst, work):
+    import faulthandler
+    import time
+
+    import torch.distributed as dist
+    stacks = open(os.path.join(work, f"stacks_{world}_{rank}.txt"), "w")
+    _KEEP_OPEN.append(stacks)
+    faulthandler.dump_traceback_later(60, exit=False, file=stacks)
+    rk = _join(rank, world, port, False)
+    os.chdir(work)
+    bal = OracleBalancer(source_dir=src, target_dir=dst, seed=42, workers=1)
+    bal.analyze_distribution()
+    bal.calculate_plan()
+    if rank == 0:   # the tree vanishes between planning and execution: rank 0's preparation raises
+        bal.source_dir = Path(src + "_gone")
+    t0 = time.time()
+    try:
+        bal.execute_balancing()
+        outcome = "finished"
+    except FileNotFoundError as e:
+        outcome = f"FileNotFoundError: {e}"
+    except RuntimeError as e:
+        outcome = f"RuntimeError: {e}"
+    Path(work, f"outcome_{rank}.json").write_text(json.dumps({"outcome": outcome, "seconds": time.time() - t0,
+                                                              "codec": bal._codec is None}))
+    if rk.active:
+        dist.destroy_process_group()
+
+
+def test_rank0_preparation_failure_reaches_every_rank(tmp_path):
+    """Rank 0 prepares the job alone (fresh target tree, task list).  If that raises, the other ranks used to wait
+    in the task-list broadcast until the process group timed out (30 minutes by default) with their codec workers
+    running; now the failure is broadcast in the task list's place and every rank raises at once."""
+    src = tmp_path / "images"
+    build_tree(src, 16)
+    work = tmp_path / "w"
+    work.mkdir()
+    ok = _spawn_bounded(_broken_prep_worker, (2, _free_port(), str(src), str(work / "augmented"), str(work)), 2,
+                        limit=90.0)
+    os.environ.pop("WORLD_SIZE", None)
+    os.environ.pop("RANK", None)
+    assert ok, "\n".join(f.read_text() for f in sorted(work.glob("stacks_2_*.txt")))
+    out = [json.loads((work / f"outcome_{r}.json").read_text()) for r in range(2)]
+    assert out[0]["outcome"].startswith("FileNotFoundError") and "Source directory not found" in out[0]["outcome"]
+    assert out[1]["outcome"].startswith("RuntimeError: rank 0 could not prepare") and "FileNotFoundError" in out[1]["outcome"]
+    assert all(o["codec"] and o["seconds"] < 30 for o in out)
