@@ -81,8 +81,9 @@ struct ConvBf16TrainArgs {
     const float* mask_scale;
     const float* mask_shift;
     int mask_relu;
-    int tiles_x, tiles_y, items, items_per_wg;  // filled by the streaming launcher
-    int interleave;                             // 1: tile rows dealt out per XCD (see conv_bf16s_kernel)
+    int tiles_x, tiles_y;     // filled by the streaming launcher
+    int seg_tiles, segs;      // a column strip is walked in `segs` segments of `seg_tiles` tiles (see conv_bf16s_kernel)
+    int interleave;           // 1: an image's strips on one XCD (see conv_bf16s_kernel)
     // inference: v*out_scale[co]+out_shift[co] (+ReLU) on the fp32 accumulators before rounding — the
     // layer's folded BatchNorm(+ReLU), so that what is stored is the activation itself
     const float* out_scale;
@@ -98,7 +99,9 @@ struct WgradBf16Args {
     const float* in_shift;
     int in_relu;
     int n, cin, cout, h, w;
-    int tiles_x, tiles_y, items, items_per_split;
+    int tiles_x, tiles_y;
+    int seg_tiles, segs;   // a column strip is walked in `segs` segments of `seg_tiles` tiles (wgrad_bf16_kernel)
+    int interleave;        // 1: an image's strips on one XCD
     // optional: dY = BatchNorm backward of g (BN input bn_y), formed while staging:
     //   dz = (g*alpha[n][co] + add[n][co]) * [bn_y*coef0[co] + coef1[co] > 0 or !bn_relu]
     //   dY = bf16(coef2[co]*dz + coef3[co]*bn_y + coef4[co])

@@ -33,13 +33,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-// development-only ablations for timing studies (never set in the shipped build):
-// 1 = no epilogue stores, 2 = every workgroup reads image 0 (cache-resident input),
-// 4 = no LDS staging writes (MFMAs run on stale LDS); wgrad3: 8 = no staging at all after the
-// first item, 16 = no per-item barrier
-#ifndef LF_ABLATE
-#define LF_ABLATE 0
-#endif
 #ifndef LF_KC_SMALL
 #define LF_KC_SMALL 8
 #endif
@@ -159,7 +152,7 @@ void conv_mfma_kernel(ConvArgs p) {
     const int n = bz * p.stack;  // first image of this workgroup's strip
     const size_t hw = (size_t)p.h * p.wd;
     const unsigned uhw = (unsigned)hw;
-    const float* xin = p.x + ((LF_ABLATE & 2) ? (size_t)0 : (size_t)n * p.cin * hw);
+    const float* xin = p.x + (size_t)n * p.cin * hw;
     // strip rows ty0 .. ty0+TH-1: the first `ra` belong to image n + imgA (rows gyA0 ..), the
     // rest (only when the tile straddles a seam, or hangs over the bottom) to the next image
     const int imgA = ty0 / p.h, gyA0 = ty0 - imgA * p.h;
@@ -314,7 +307,7 @@ void conv_mfma_kernel(ConvArgs p) {
                         v.w = pro_apply(v.w, sc, sh, p.in_relu);
                     }
                     float* dst = lp + (pl[i] & 0xffffu);
-                    if (!(LF_ABLATE & 4) || v.x == 123.456f) {
+                    {
                         dst[0] = v.x;
                         dst[1] = v.y;
                         dst[2] = v.z;
@@ -329,13 +322,13 @@ void conv_mfma_kernel(ConvArgs p) {
                     float v = ph[i];
                     if (pro && (okmask >> (16 + i) & 1u))
                         v = pro_apply(v, pro_sc(c0 + kc), pro_sh(c0 + kc), p.in_relu);
-                    if (!(LF_ABLATE & 4) || v == 123.456f) lp[hl[i] & 0xffffu] = v;
+                    lp[hl[i] & 0xffffu] = v;
                 }
             }
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 const int e = tid + i * kThreads;
-                if (e < NWI && (!(LF_ABLATE & 4) || wv[i].x == 123.456f)) reinterpret_cast<float4*>(lw)[e] = wv[i];  // lw[row*CT + col]
+                if (e < NWI) reinterpret_cast<float4*>(lw)[e] = wv[i];  // lw[row*CT + col]
             }
         };
         load_patch(0);
@@ -456,7 +449,7 @@ void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     if (p.accumulate) acc[m][nb][r] += oldv[rr][nb];  // the statistics see the sum
-                    if (co_ok && pix_ok[nb] && (!(LF_ABLATE & 1) || acc[m][nb][r] == 123.456f))
+                    if (co_ok && pix_ok[nb])
                         dst[pixc[nb]] = acc[m][nb][r];
                 }
                 if (!stats) continue;
@@ -1037,7 +1030,7 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             const int n = item / tiles, t = item - n * tiles;
             const int tx0 = (t % p.tiles_x) * TW, ty0 = (t / p.tiles_x) * TH;
             const size_t torg = (size_t)ty0 * p.wd + tx0;
-            const size_t nl = (LF_ABLATE & 2) ? 0 : (size_t)n;
+            const size_t nl = (size_t)n;
             // patch origin = one row up, one column left of the tile (never dereferenced there:
             // rows / columns outside the image get the out-of-range offset)
             const __amdgpu_buffer_rsrc_t rx =
@@ -1105,7 +1098,7 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                         v.w = pro_apply(v.w, sc, sh, p.in_relu);
                     }
                     float* dst = lx + (xl[i] & 0xffffu);
-                    if (!(LF_ABLATE & 32) || v.x == 123.456f) {
+                    {
                         dst[0] = v.x;
                         dst[1] = v.y;
                         dst[2] = v.z;
@@ -1120,7 +1113,7 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                     float v = xh[i];
                     if (pro && (xok >> (16 + i) & 1u))
                         v = pro_apply(v, lsc[c], lsc[kMaxProC / 4 + c], p.in_relu);
-                    if (!(LF_ABLATE & 32) || v == 123.456f) lx[hl[i] & 0xffffu] = v;
+                    lx[hl[i] & 0xffffu] = v;
                 }
             }
             const int sn = item / tiles, st = item - sn * tiles;
@@ -1142,7 +1135,7 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
                             *reinterpret_cast<float4*>(dyo + (dg[i] >> 2)) = v;
                     }
                     float* dst = ld + (dl[i] & 0xffffu);
-                    if (!(LF_ABLATE & 32) || v.x == 123.456f) {
+                    {
                         dst[0] = v.x;
                         dst[1] = v.y;
                         dst[2] = v.z;
@@ -1169,10 +1162,10 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
         // the MFMA pipe busy.
         const int stage_q = (wid >> 2) % 3;
         for (int idx = 0; idx < count; ++idx) {
-            const bool more = !(LF_ABLATE & 8) && idx + 1 < count;
+            const bool more = idx + 1 < count;
             auto stage = [&]() {
                 store_item(nth(idx + 1), cur ^ 1);
-                if (!(LF_ABLATE & 64) && idx + 2 < count) load_item(nth(idx + 2));
+                if (idx + 2 < count) load_item(nth(idx + 2));
             };
             compute_quarter(Q0{}, cur);
             if (more && stage_q == 0) stage();
@@ -1181,7 +1174,7 @@ __global__ __launch_bounds__(64 * 3 * WCI * WCO * KSPL, 3) void wgrad3_kernel(Wg
             compute_quarter(Q2{}, cur);
             if (more && stage_q == 2) stage();
             compute_quarter(Q3{}, cur);
-            if (!(LF_ABLATE & 16)) __syncthreads();
+            __syncthreads();
             cur ^= 1;
         }
     } else {

@@ -5,9 +5,15 @@
 // memory stream, not around the MFMA:
 //
 //   * the whole filter bank (<= 36 KB of bf16) is copied into LDS ONCE per workgroup and stays
-//     there; a workgroup then walks a contiguous range of (image, tile) items, so neighbouring
-//     tiles' halo rows are re-read from the XCD's own L2;
-//   * the input patch of the NEXT tile is in flight in registers while the current tile's MFMAs
+//     there;
+//   * a workgroup walks DOWN a column strip of an image (TW pixels wide), tile after tile, and the
+//     patch in LDS is a RING of TH + 2 pixel rows: a tile brings in only its TH new rows, the two
+//     rows it shares with the tile above are still there (round 3; before, every tile staged its
+//     own TH + 2 rows and the input crossed the fabric 1.5x for the halo rows alone — PMC,
+//     profiles/pmc_latest_bf16.json of round 2: 2.59 GB per forward launch against 1.64 GB).  The
+//     strips of one image go to neighbouring workgroups of one XCD, which walk them at the same
+//     pace: the halo columns and the 128-byte lines two strips share are found in that XCD's L2;
+//   * the NEW rows of the next tile are in flight in registers while the current tile's MFMAs
 //     and epilogue run (all input channels at once: no K-chunk loop, no barrier per chunk);
 //   * the patch sits in LDS as [pixel][channel] rows (64 B per pixel at 32 channels) with the
 //     16-byte channel groups XOR-swizzled by the pixel index: the B operand of a lane (one pixel,
@@ -75,12 +81,12 @@ struct SShape {
     static constexpr int COUT = 32 * NCO, CH = CI / 16;
     static constexpr int WBYTES = CH * TAPS * 2 * COUT * 16;
     static constexpr int PBYTES = (PPIX * ROWB + 15) / 16 * 16;
-    static constexpr int EBYTES = 32 * 256 * 4;             // fp32 accumulators of one 32-channel block
-    // The epilogue's transpose buffer has its own LDS where two workgroups per CU still fit (then a wave may write
-    // its accumulators while slower waves are still reading the patch: no barrier in front of the epilogue);
-    // otherwise it reuses the patch, which is dead once every wave is through the tile's MFMAs.
-    static constexpr bool SEP_LE = WBYTES + PBYTES + EBYTES <= 80 * 1024;
-    static constexpr int LDS = SEP_LE ? WBYTES + PBYTES + EBYTES : WBYTES + (PBYTES > EBYTES ? PBYTES : EBYTES);
+    // The epilogue's transpose buffer: fp32 accumulators of HALF a 32-channel block (16 channels x 256 pixels), a
+    // quarter of it private to each wave.  It has LDS of its own: with the row ring the patch is never dead (the
+    // rows the next tile keeps would be overwritten), and a wave may write its accumulators while slower waves are
+    // still reading the patch — no barrier in front of the epilogue.
+    static constexpr int EBYTES = 16 * 256 * 4;
+    static constexpr int LDS = WBYTES + PBYTES + EBYTES;
 };
 
 // RMW = false: a launch with no read-modify-write operand (no accumulate, no BatchNorm-backward mask): the
@@ -100,7 +106,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* lw = lds;
     unsigned char* lp = lds + S::WBYTES;
-    float* le = reinterpret_cast<float*>(S::SEP_LE ? lp + S::PBYTES : lp);  // [32 channels][256 pixels]
+    float* le = reinterpret_cast<float*>(lp + S::PBYTES);  // [16 channels][256 pixels]
     __shared__ float lsc[2 * CI];
     __shared__ float lst[2 * COUT];
     __shared__ float los[2 * COUT];
@@ -110,17 +116,25 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     const bool pro = p.in_scale != nullptr;
     const bool stats = p.stat_part != nullptr, masked = RMW && p.stat_mask_y != nullptr;
     const bool accumulate = RMW && p.accumulate;
-    const int tiles = p.tiles_x * p.tiles_y;
-    // Which tiles a workgroup walks.  interleave = 0: a contiguous range of (image, tile row, tile) items.
-    // interleave = 1: XCD k (workgroups k, k+8, ...) owns the k-th eighth of all tile ROWS and deals them out
-    // round-robin to its workgroups, so that at any time the workgroups of an XCD work on neighbouring tile rows
-    // and the halo rows two of them need cross the fabric once and are found in that XCD's L2 the second time.
-    const int rows_total = p.items / p.tiles_x;
+    // What a workgroup walks: SEGMENTS of column strips (a strip = TW columns of one image; a segment = seg_tiles
+    // consecutive tiles of it, top to bottom — whole strips when the launch has enough of them to fill the chip).
+    // interleave = 1: image i belongs to XCD i % 8 (workgroups k, k+8, ... run on XCD k), whose workgroups take that
+    // XCD's segments in order — the strips of one image by NEIGHBOURING workgroups, started together —, so what two
+    // strips share (halo columns, 128-byte lines that straddle a strip boundary) crosses the fabric once.
+    // interleave = 0 (small launches): segments dealt round-robin over the grid.
+    const int SG = p.tiles_x, UI = SG * p.segs;   // strips, segments per image
     const int xk = blockIdx.x & 7, xj = blockIdx.x >> 3, xw = gridDim.x >> 3;
-    const int xr0 = (int)((long long)rows_total * xk / 8), xr1 = (int)((long long)rows_total * (xk + 1) / 8);
-    const int my_rows = p.interleave ? (xr1 - xr0 > xj ? (xr1 - xr0 - xj + xw - 1) / xw : 0) : 0;
-    const int first = p.interleave ? 0 : blockIdx.x * p.items_per_wg;
-    const int last = p.interleave ? my_rows * p.tiles_x : min(first + p.items_per_wg, p.items);
+    const int my_total = p.interleave ? (p.n > xk ? (p.n - xk + 7) / 8 : 0) * UI : p.n * UI;
+    const int my_first = p.interleave ? xj : (int)blockIdx.x, my_step = p.interleave ? xw : (int)gridDim.x;
+    const int my_units = my_total > my_first ? (my_total - my_first + my_step - 1) / my_step : 0;
+    auto unit_of = [&](int ui, int& n, int& tx0, int& t_first, int& t_count) {
+        const int q = my_first + ui * my_step;
+        const int im = q / UI, rem = q - im * UI, seg = rem / SG;
+        n = p.interleave ? im * 8 + xk : im;
+        tx0 = (rem - seg * SG) * TW;
+        t_first = seg * p.seg_tiles;
+        t_count = min(p.seg_tiles, p.tiles_y - t_first);
+    };
 
     // ---- one-time: filter bank -> LDS as [chunk][tap][k half][cout][8 channels] (16 B per entry)
     {
@@ -151,40 +165,29 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     };
 
     // ---- staging units: 4 channels x G pixels (interior: one 16-byte load per channel), 4 channels x 1
-    // pixel (halo columns)
+    // pixel (halo columns).  One staging pass covers up to TH image rows gy0 .. gy0 + nrows - 1 of the strip; row gy
+    // lives in ring slot (gy + HALO) mod PH.
     constexpr int QD = XBF ? CI / 4 : 1;  // channel quads that carry data
-    constexpr int NXU = QD * PH * PGS, XPT = (NXU + kT - 1) / kT;
-    constexpr int NHU = QD * PH * 2 * HALO, HPT = (NHU + kT - 1) / kT;
+    constexpr int NXU = QD * TH * PGS, XPT = (NXU + kT - 1) / kT;
+    constexpr int NHU = QD * TH * 2 * HALO, HPT = (NHU + kT - 1) / kT;
+    static_assert(2 * HALO <= TH, "the two rows that prime a strip go through the same staging registers");
     uvec rx[XPT][XBF ? 4 : 3];
     unsigned rh[HPT > 0 ? HPT : 1][XBF ? 4 : 3];   // raw loads: combining them here would wait for them here
     unsigned xmask = 0, hmask = 0;
+    int st_slot = 0, st_rows = 0;   // of the pass in flight: ring slot of its first row, its row count
 
-    auto tile_of = [&](int item, int& n, int& tx0, int& ty0) {
-        if (p.interleave) {
-            const int lr = item / p.tiles_x, row = xr0 + xj + lr * xw;
-            n = row / p.tiles_y;
-            tx0 = (item - lr * p.tiles_x) * TW;
-            ty0 = (row - n * p.tiles_y) * TH;
-            return;
-        }
-        n = item / tiles;
-        const int t = item - n * tiles;
-        tx0 = (t % p.tiles_x) * TW;
-        ty0 = (t / p.tiles_x) * TH;
-    };
-
-    auto issue = [&](int item) {
-        int n, tx0, ty0;
-        tile_of(item, n, tx0, ty0);
+    auto issue = [&](int n, int tx0, int gy0, int nrows) {
         xmask = hmask = 0;
+        st_rows = nrows;
+        st_slot = (gy0 + HALO) % PH;   // gy0 >= -HALO
         const uint16_t* xb = static_cast<const uint16_t*>(p.x) + (XBF ? (size_t)n * p.cin * hw : 0);
         const float* xf = static_cast<const float*>(p.x) + (XBF ? 0 : (size_t)n * p.cin * hw);
 #pragma unroll
         for (int k = 0; k < XPT; ++k) {
             const int u = tid + k * kT;
             const int pg = u % PGS, t1 = u / PGS, quad = t1 % QD, pr = t1 / QD;
-            const int gy = ty0 - HALO + pr, gx = tx0 + G * pg;
-            const bool ok = u < NXU && gy >= 0 && gy < p.h && gx < p.w && 4 * quad < p.cin;
+            const int gy = gy0 + pr, gx = tx0 + G * pg;
+            const bool ok = pr < nrows && gy >= 0 && gy < p.h && gx < p.w && 4 * quad < p.cin;
             xmask |= (ok ? 1u : 0u) << k;
             if (!ok) continue;
             const size_t o = (size_t)(4 * quad) * hw + (size_t)gy * p.w + gx;
@@ -201,8 +204,8 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
         for (int k = 0; k < HPT; ++k) {
             const int u = tid + k * kT;
             const int side = u & 1, t1 = u >> 1, quad = t1 % QD, pr = t1 / QD;
-            const int gy = ty0 - HALO + pr, gx = side ? tx0 + TW : tx0 - 1;
-            const bool ok = u < NHU && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w && 4 * quad < p.cin;
+            const int gy = gy0 + pr, gx = side ? tx0 + TW : tx0 - 1;
+            const bool ok = pr < nrows && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w && 4 * quad < p.cin;
             hmask |= (ok ? 1u : 0u) << k;
             if (!ok) continue;
             const size_t o = (size_t)(4 * quad) * hw + (size_t)gy * p.w + gx;
@@ -220,10 +223,12 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
 #pragma unroll
         for (int k = 0; k < XPT; ++k) {
             const int u = tid + k * kT;
-            if (u >= NXU) continue;
             const int pg = u % PGS, t1 = u / PGS, quad = t1 % QD, pr = t1 / QD;
+            if (pr >= st_rows) continue;
             const bool ok = xmask >> k & 1u;
-            const unsigned pi = (unsigned)(pr * PW + HALO + G * pg);
+            int slot = st_slot + pr;
+            slot = slot >= PH ? slot - PH : slot;
+            const unsigned pi = (unsigned)(slot * PW + HALO + G * pg);
             float prev[G];
             // channel by channel; every second channel the pair goes to LDS, one dword per pixel
 #pragma unroll
@@ -265,8 +270,8 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
 #pragma unroll
         for (int k = 0; k < HPT; ++k) {
             const int u = tid + k * kT;
-            if (u >= NHU) continue;
             const int side = u & 1, t1 = u >> 1, quad = t1 % QD, pr = t1 / QD;
+            if (pr >= st_rows) continue;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (hmask >> k & 1u) {
                 if (XBF) {
@@ -287,7 +292,9 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
             u32x2 o;
             o.x = pack2(v[0], v[1]);
             o.y = pack2(v[2], v[3]);
-            const unsigned pi = (unsigned)(pr * PW + (side ? PW - 1 : 0));
+            int slot = st_slot + pr;
+            slot = slot >= PH ? slot - PH : slot;
+            const unsigned pi = (unsigned)(slot * PW + (side ? PW - 1 : 0));
             *reinterpret_cast<u32x2*>(lp + poff(pi, (unsigned)quad >> 1) + 8 * (quad & 1)) = o;
         }
     };
@@ -296,7 +303,6 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     // (block 0) and 2*px + 1 (block 1): the same row, adjacent columns
     const int f0 = 64 * wv + 2 * px;
     const int prow = f0 / TW, pcol = f0 - prow * TW;
-    const unsigned pp0 = (unsigned)(prow * PW + pcol);
     // epilogue geometry: thread = (pixel group eg of 8 consecutive flat positions, channel ec + 8*j), the groups
     // of a wave being the 64 positions whose accumulators the wave itself holds: what a wave reads back from `le`
     // it has written itself, so the transposition needs no workgroup barrier
@@ -311,14 +317,32 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
         for (int j = 0; j < 4; ++j) s1[cb][j] = s2[cb][j] = 0.f;
     uvec rold[NCO][4], rmask[NCO][4];  // eight pixels of one channel each, as stored
 
-    if (first < last) issue(first);
-    for (int item = first; item < last; ++item) {
+    // A tile's new rows are gy = ty * TH + HALO .. + TH - 1; a segment's first tile also needs the 2 * HALO rows above
+    // them (the "prime" pass: staged when the segment starts, its latency exposed once per segment).
+    int sn = 0, stx0 = 0, stf = 0, stc = 0;
+    if (my_units > 0) {
+        unit_of(0, sn, stx0, stf, stc);
+        issue(sn, stx0, stf * TH + HALO, TH);
+    }
+    for (int ui = 0; ui < my_units; ++ui) {
+    int n, tx0, t_first, t_count;
+    unit_of(ui, n, tx0, t_first, t_count);
+    for (int tt = 0; tt < t_count; ++tt) {
         __syncthreads();  // the previous tile's operand reads are done (first pass: weights / lsc / lst staged)
+        const int ty0 = (t_first + tt) * TH;
         commit();
-        if (item + 1 < last) issue(item + 1);  // in flight during the MFMAs and the epilogue
+        if (HALO > 0 && tt == 0) {
+            issue(n, tx0, ty0 - HALO, 2 * HALO);
+            commit();
+        }
+        // the next tile's new rows: in flight during the MFMAs and the epilogue
+        if (tt + 1 < t_count) {
+            issue(n, tx0, ty0 + TH + HALO, TH);
+        } else if (ui + 1 < my_units) {
+            unit_of(ui + 1, sn, stx0, stf, stc);
+            issue(sn, stx0, stf * TH + HALO, TH);
+        }
         // the epilogue's read-modify-write operands: requested now, consumed after the MFMAs
-        int n, tx0, ty0;
-        tile_of(item, n, tx0, ty0);
         uint16_t* yb = p.y + (size_t)n * p.cout * hw;
         const int gy = ty0 + erow, gx = tx0 + ecol;
         const bool ok = gy < p.h && gx < p.w;  // the 8-pixel group is inside or outside as a whole (w % 8 == 0)
@@ -339,6 +363,16 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
                     rmask[cb][j] = *reinterpret_cast<const uvec*>(my + (size_t)(cb * 32 + 8 * j + ec) * hw + po);
         }
         __syncthreads();
+        // patch row r of this tile (image row ty0 - HALO + r) sits in ring slot (ty0 + r) mod PH
+        unsigned rowpp[TAPS == 9 ? 3 : 1];
+        {
+            int slot = (ty0 + prow) % PH;
+#pragma unroll
+            for (int dy = 0; dy < (TAPS == 9 ? 3 : 1); ++dy) {
+                rowpp[dy] = (unsigned)(slot * PW + pcol);
+                slot = slot + 1 >= PH ? 0 : slot + 1;
+            }
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -358,7 +392,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     B[nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const lf::u32x4*>(
-                        lp + poff(pp0 + (unsigned)(dy * PW + dx + nb), (unsigned)(2 * ch + kh))));
+                        lp + poff(rowpp[dy] + (unsigned)(dx + nb), (unsigned)(2 * ch + kh))));
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -369,20 +403,21 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
         // ---- epilogue, one 32-channel block at a time through LDS: lane (pixel pair, 16 channels)
         // -> thread (8 pixels, 4 channels); then 16-byte stores and the sums of the rounded values
 #pragma unroll
-        for (int cb = 0; cb < NCO; ++cb) {
-            if (!S::SEP_LE && cb == 0) __syncthreads();  // `le` lies over the patch: every wave must be done with it
+        for (int cb = 0; cb < NCO; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cl = 8 * (r >> 2) + 4 * kh + (r & 3);
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int r = 8 * hf; r < 8 * hf + 8; ++r) {
+                const int cl = 8 * ((r >> 2) & 1) + 4 * kh + (r & 3);   // channel within the half block
                 *reinterpret_cast<float2*>(le + cl * 256 + 64 * wv + 2 * px) = make_float2(acc[0][cb][r], acc[1][cb][r]);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own LDS writes (no other wave reads them)
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 2 * hf; j < 2 * hf + 2; ++j) {
                 const int cl = 8 * j + ec, co = cb * 32 + cl;
-                const lf::f32x4 a0 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg);
-                const lf::f32x4 a1 = *reinterpret_cast<const lf::f32x4*>(le + cl * 256 + 8 * eg + 4);
+                const lf::f32x4 a0 = *reinterpret_cast<const lf::f32x4*>(le + (cl & 15) * 256 + 8 * eg);
+                const lf::f32x4 a1 = *reinterpret_cast<const lf::f32x4*>(le + (cl & 15) * 256 + 8 * eg + 4);
                 float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 if (accumulate)
 #pragma unroll
@@ -430,6 +465,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
             __builtin_amdgcn_wave_barrier();   // the reads above stay in front of the next block's writes
         }
     }
+    }
     if (stats) {
         // one partial per workgroup: a channel's pixel groups are 8 lanes (lane & 7) in each of the four waves
         __syncthreads();
@@ -466,7 +502,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
 
 struct SPlan {
     bool ok;
-    int ci, nco, tw, th, tiles_x, tiles_y, items, wgs, items_per_wg, interleave;
+    int ci, nco, tw, th, tiles_x, tiles_y, seg_tiles, segs, wgs, interleave;
 };
 
 SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
@@ -492,16 +528,19 @@ SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
     else { pl.tw = 16; pl.th = 16; }
     pl.tiles_x = (w + pl.tw - 1) / pl.tw;
     pl.tiles_y = (h + pl.th - 1) / pl.th;
-    pl.items = n * pl.tiles_x * pl.tiles_y;
-    int wgs = 256 * 2;
-    if (wgs > pl.items) wgs = pl.items;
-    pl.items_per_wg = (pl.items + wgs - 1) / wgs;
-    pl.wgs = (pl.items + pl.items_per_wg - 1) / pl.items_per_wg;
-    // tile rows dealt out per XCD when every workgroup of the full grid gets at least two of them (A/B in one
-    // process against contiguous ranges, 32->32 @224: forward 662 -> 648 us, input gradient with accumulate
-    // 725 -> 671 us, with accumulate + mask + sums 913 -> 860 us; 64->64 @112 forward 508 -> 487 us)
-    pl.interleave = (wgs == 256 * 2 && n * pl.tiles_y >= 2 * wgs) ? 1 : 0;
-    if (pl.interleave) pl.wgs = wgs;
+    // Column strips are cut into segments only when there are too few of them to fill the chip twice over (small
+    // batches): a segment re-stages the two rows above it, so whole strips are what the full-size step gets
+    // (batch 256 @224: 1,024 strips of 56 tiles; @112: 512 strips in two segments of 14 tiles).
+    const int strips = n * pl.tiles_x;
+    int segs = (4 * 256 + strips - 1) / strips;
+    const int max_segs = (pl.tiles_y + 3) / 4;        // at least four tiles to a segment
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    pl.seg_tiles = (pl.tiles_y + segs - 1) / segs;
+    pl.segs = (pl.tiles_y + pl.seg_tiles - 1) / pl.seg_tiles;
+    const int units = strips * pl.segs;
+    pl.wgs = units < 256 * 2 ? units : 256 * 2;
+    pl.interleave = (pl.wgs % 8 == 0 && n >= 8) ? 1 : 0;
     pl.ok = true;
     return pl;
 }
@@ -559,7 +598,7 @@ int conv_bf16s_launch(ConvBf16TrainArgs a, int ksize, int x_bf16, hipStream_t s)
         set_error("lf_conv2d_bf16_train: shape not covered by the streaming kernel");
         return LF_ERR_INVALID;
     }
-    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.items = pl.items; a.items_per_wg = pl.items_per_wg;
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.seg_tiles = pl.seg_tiles; a.segs = pl.segs;
     a.interleave = pl.interleave;
     a.stat_tiles = pl.wgs;
     if (pl.tw == 64) return dispatch_s<64, 4>(pl, ksize, a, s);

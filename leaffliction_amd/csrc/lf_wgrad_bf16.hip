@@ -20,7 +20,12 @@
 // The step is HBM-bound, not MFMA-bound (bf16 tensors: 72 FLOP per byte moved at 224x224 /
 // 32->32): the kernel reads A, the upstream gradient g and the BatchNorm input y once, writes
 // dY once, and keeps two tiles ahead of the MFMAs: LDS is double-buffered (one barrier per tile)
-// and the loads of the tile after next are in flight in registers.  A 3x3 workgroup is 6 waves,
+// and the loads of the tile after next are in flight in registers.  A workgroup walks DOWN column
+// strips of the images (round 3): the A patch in LDS is a ring of 2 * (TH + 2) pixel rows, a tile
+// stages only its TH new rows next to the two it shares with the tile above (before, every tile
+// staged TH + 2 rows and A crossed the fabric 1.5 times for the halo rows alone), and the strips
+// of one image are walked at the same time by neighbouring workgroups of one XCD, so the 128-byte
+// lines and halo columns two strips share are fetched once.  A 3x3 workgroup is 6 waves,
 // wave (filter row, sub-block / K share): 48-96 accumulator registers per wave instead of 144-576,
 // and at most two waves per SIMD, which is what leaves room for the loads in flight (48 registers
 // of raw bf16 per thread with 16-byte accesses).
@@ -61,11 +66,11 @@ template <int TAPS, int TW, int TH, int CIB, int COB, bool STEM, int WPRQ = 0>
 struct WgShape {
     static constexpr int HALO = (TAPS == 9 && !STEM) ? 1 : 0;
     static constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO;
-    static constexpr int XPIX = PW * PH, DPIX = TW * TH;
+    static constexpr int NSLOT = 2 * PH;               // ring rows of the A patch: this tile's PH and the next one's
+    static constexpr int XPIX = PW * NSLOT, DPIX = TW * TH;
     static constexpr int XBYTES = CIB * XPIX * 64, DBYTES = COB * DPIX * 64;
-    static constexpr int BUF = XBYTES + DBYTES;       // one staging buffer; the kernel double-buffers
     static constexpr int RED = TAPS * 16 * 64 * 4;    // the accumulators of one sub-block's waves
-    static constexpr int LDS = 2 * BUF > RED ? 2 * BUF : RED;
+    static constexpr int LDS = XBYTES + 2 * DBYTES > RED ? XBYTES + 2 * DBYTES : RED;
     static constexpr int ROWS = TAPS == 9 ? 3 : 1;    // filter rows spread over waves
     // waves per filter row (they split the sub-blocks / K): 3x3 with one or two sub-blocks runs 6
     // waves (<= 2 per SIMD: 256 registers each), 2x2 sub-blocks 12 waves (one sub-block each)
@@ -142,20 +147,39 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
     float rs[STEM ? 27 : 1];
     unsigned dmask = 0, xmask = 0, hmask = 0;  // bit k: unit k lies inside the image
 
-    const int first = blockIdx.x * p.items_per_split;
-    const int last = min(first + p.items_per_split, p.items);
-    const int tiles = p.tiles_x * p.tiles_y;
+    // What a workgroup walks: segments of column strips (a strip = TW columns of one image, a segment = seg_tiles
+    // consecutive tiles of it from top to bottom); see plan_wgrad_bf16 for how they are dealt out.
+    const int SG = p.tiles_x, UI = SG * p.segs;
+    const int xk = blockIdx.x & 7, xj = blockIdx.x >> 3, xw = gridDim.x >> 3;
+    const int my_total = p.interleave ? (p.n > xk ? (p.n - xk + 7) / 8 : 0) * UI : p.n * UI;
+    const int my_first = p.interleave ? xj : (int)blockIdx.x, my_step = p.interleave ? xw : (int)gridDim.x;
+    const int my_units = my_total > my_first ? (my_total - my_first + my_step - 1) / my_step : 0;
 
-    auto tile_of = [&](int item, int& n, int& tx0, int& ty0) {
-        n = item / tiles;
-        const int t = item - n * tiles;
-        tx0 = (t % p.tiles_x) * TW;
-        ty0 = (t / p.tiles_x) * TH;
+    // a position in the workgroup's sequence of tiles: unit ui, tile tt of it
+    struct Cursor {
+        int ui, tt, n, tx0, t_first, t_count;
     };
+    auto seek = [&](Cursor& c, int ui) {
+        c.ui = ui;
+        c.tt = 0;
+        if (ui >= my_units) return;
+        const int q = my_first + ui * my_step;
+        const int im = q / UI, rem = q - im * UI, seg = rem / SG;
+        c.n = p.interleave ? im * 8 + xk : im;
+        c.tx0 = (rem - seg * SG) * TW;
+        c.t_first = seg * p.seg_tiles;
+        c.t_count = min(p.seg_tiles, p.tiles_y - c.t_first);
+    };
+    auto advance = [&](Cursor& c) {
+        if (++c.tt >= c.t_count) seek(c, c.ui + 1);
+    };
+    auto valid = [&](const Cursor& c) { return c.ui < my_units; };
 
-    auto issue = [&](int item) {
-        int n, tx0, ty0;
-        tile_of(item, n, tx0, ty0);
+    // A tile's A patch is rows ty0 - HALO .. ty0 + TH + HALO - 1 of the strip.  The first tile of a segment stages
+    // all PH of them, every other tile only the TH new ones (patch rows 2 * HALO .. PH - 1): the rest is in the ring.
+    auto issue = [&](const Cursor& c) {
+        const int n = c.n, tx0 = c.tx0, ty0 = (c.t_first + c.tt) * TH;
+        const int pr0 = c.tt == 0 ? 0 : 2 * HALO;   // first patch row staged
         dmask = xmask = hmask = 0;
         const uint16_t* gn = p.g + (size_t)n * p.cout * hw;
         const uint16_t* yn = bn ? p.bn_y + (size_t)n * p.cout * hw : nullptr;
@@ -191,9 +215,9 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
 #pragma unroll
             for (int k = 0; k < XPT; ++k) {
                 const int u = tid + k * kT;
-                const int pg = u % PGS, t1 = u / PGS, quad = t1 % (8 * CIB), pr = t1 / (8 * CIB);
+                const int pg = u % PGS, t1 = u / PGS, quad = t1 % (8 * CIB), pr = pr0 + t1 / (8 * CIB);
                 const int gy = ty0 - HALO + pr, gx = tx0 + G * pg;
-                const bool ok = u < NXU && gy >= 0 && gy < p.h && gx < p.w && ci0 + 4 * quad < p.cin;
+                const bool ok = pr < PH && gy >= 0 && gy < p.h && gx < p.w && ci0 + 4 * quad < p.cin;
                 xmask |= (ok ? 1u : 0u) << k;
                 if (!ok) continue;
                 const size_t o = (size_t)(ci0 + 4 * quad) * hw + (size_t)gy * p.w + gx;
@@ -203,9 +227,9 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
 #pragma unroll
             for (int k = 0; k < HPT; ++k) {
                 const int u = tid + k * kT;
-                const int side = u & 1, t1 = u >> 1, quad = t1 % (8 * CIB), pr = t1 / (8 * CIB);
+                const int side = u & 1, t1 = u >> 1, quad = t1 % (8 * CIB), pr = pr0 + t1 / (8 * CIB);
                 const int gy = ty0 - HALO + pr, gx = side ? tx0 + TW : tx0 - 1;
-                const bool ok = u < NHU && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w && ci0 + 4 * quad < p.cin;
+                const bool ok = pr < PH && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w && ci0 + 4 * quad < p.cin;
                 hmask |= (ok ? 1u : 0u) << k;
                 if (!ok) continue;
                 const size_t o = (size_t)(ci0 + 4 * quad) * hw + (size_t)gy * p.w + gx;
@@ -220,11 +244,12 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
         }
     };
 
-    auto commit = [&](int item, int buf) {
-        unsigned char* lx = lds + buf * S::BUF;
-        unsigned char* ld = lx + S::XBYTES;
-        int n, tx0, ty0;
-        tile_of(item, n, tx0, ty0);
+    // rb = ring slot of the tile's patch row 0; buf = which dY buffer
+    auto commit = [&](const Cursor& c, int rb, int buf) {
+        unsigned char* lx = lds;
+        unsigned char* ld = lds + S::XBYTES + buf * S::DBYTES;
+        const int n = c.n, tx0 = c.tx0, ty0 = (c.t_first + c.tt) * TH;
+        const int pr0 = c.tt == 0 ? 0 : 2 * HALO;
         if (bn && p.bn_alpha != nullptr && n != lal_n) {   // uniform: a workgroup's items run through the images in order
             __syncthreads();   // nobody still reads the previous image's factors
             for (int c = tid; c < 32 * COB; c += kT) {
@@ -294,7 +319,7 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
         }
         if (STEM) {
             // im2col row of this thread's pixel: "channel" = ci*9 + tap (27 used, 5 zero)
-            const unsigned pd = (unsigned)tid;
+            const unsigned pd = (unsigned)(rb * PW + tid);   // PW = TW: ring slots rb .. rb + TH - 1
 #pragma unroll
             for (int qd = 0; qd < 8; ++qd) {
                 float v[4];
@@ -309,11 +334,13 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
 #pragma unroll
             for (int k = 0; k < XPT; ++k) {
                 const int u = tid + k * kT;
-                if (u >= NXU) continue;
-                const int pg = u % PGS, t1 = u / PGS, quad = t1 % (8 * CIB), pr = t1 / (8 * CIB);
+                const int pg = u % PGS, t1 = u / PGS, quad = t1 % (8 * CIB), pr = pr0 + t1 / (8 * CIB);
+                if (pr >= PH) continue;
                 const bool ok = xmask >> k & 1u;
                 unsigned char* img = lx + (quad >> 3) * (S::XPIX * 64);
-                const unsigned pi = (unsigned)(pr * PW + HALO + G * pg);
+                int slot = rb + pr;
+                slot = slot >= S::NSLOT ? slot - S::NSLOT : slot;
+                const unsigned pi = (unsigned)(slot * PW + HALO + G * pg);
                 float prev[G];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -349,8 +376,8 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
 #pragma unroll
             for (int k = 0; k < HPT; ++k) {
                 const int u = tid + k * kT;
-                if (u >= NHU) continue;
-                const int side = u & 1, t1 = u >> 1, quad = t1 % (8 * CIB), pr = t1 / (8 * CIB);
+                const int side = u & 1, t1 = u >> 1, quad = t1 % (8 * CIB), pr = pr0 + t1 / (8 * CIB);
+                if (pr >= PH) continue;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (hmask >> k & 1u) {
 #pragma unroll
@@ -367,7 +394,9 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
                 o.x = pack2(v[0], v[1]);
                 o.y = pack2(v[2], v[3]);
                 unsigned char* img = lx + (quad >> 3) * (S::XPIX * 64);
-                *reinterpret_cast<u32x2*>(img + img_off((unsigned)(pr * PW + (side ? PW - 1 : 0)), quad & 7)) = o;
+                int slot = rb + pr;
+                slot = slot >= S::NSLOT ? slot - S::NSLOT : slot;
+                *reinterpret_cast<u32x2*>(img + img_off((unsigned)(slot * PW + (side ? PW - 1 : 0)), quad & 7)) = o;
             }
         }
     };
@@ -388,9 +417,9 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
         v.s4 = b.x; v.s5 = b.y; v.s6 = b.z; v.s7 = b.w;
         return __builtin_bit_cast(bf16x8, v);
     };
-    auto compute = [&](int buf) {
-        const unsigned char* xb = lds + buf * S::BUF;
-        const unsigned char* db = xb + S::XBYTES;
+    auto compute = [&](int rb, int buf) {
+        const unsigned char* xb = lds;
+        const unsigned char* db = lds + S::XBYTES + buf * S::DBYTES;
 #pragma unroll 1
         for (int s = ks; s < NS; s += KSPL) {
             const int f0 = 16 * s + 8 * kh, f1 = f0 + 4;  // flat tile positions of the lane's two groups
@@ -410,32 +439,54 @@ __global__ __launch_bounds__((WgShape<TAPS, TW, TH, CIB, COB, STEM, WPRQ>::NT), 
 #pragma unroll
                 for (int b = 0; b < SBW; ++b) {
                     const int cib = (q0 + b) % CIB;
-                    const bf16x8 A = frag(xb + cib * (S::XPIX * 64), (unsigned)((r0 + dy) * PW + c0 + dx),
-                                          (unsigned)((r1 + dy) * PW + c1 + dx));
+                    int s0 = rb + r0 + dy, s1 = rb + r1 + dy;   // ring slots of the two pixel groups' rows
+                    s0 = s0 >= S::NSLOT ? s0 - S::NSLOT : s0;
+                    s1 = s1 >= S::NSLOT ? s1 - S::NSLOT : s1;
+                    const bf16x8 A = frag(xb + cib * (S::XPIX * 64), (unsigned)(s0 * PW + c0 + dx),
+                                          (unsigned)(s1 * PW + c1 + dx));
                     acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[b], acc[b][t], 0, 0, 0);
                 }
             }
         }
     };
 
-    // Two tiles ahead: while tile i's MFMAs run from one LDS buffer, tile i+1 (loaded an iteration
-    // earlier) is transformed into the other and the loads of tile i+2 are issued; one barrier per tile.
-    const int count = last - first;
-    if (count > 0) {
-        issue(first);
+    // Two tiles ahead: while tile i's MFMAs run (A from its ring slots, dY from one buffer), tile i+1 (loaded an
+    // iteration earlier) is transformed into the ring slots behind them / the other dY buffer and the loads of
+    // tile i+2 are issued; one barrier per tile.  A tile that continues its segment moves the ring base by TH rows
+    // (its first 2 * HALO patch rows are the previous tile's last), one that starts a segment by PH rows.
+    Cursor cc, cn, ci;   // computing, committing next, issuing
+    seek(cc, 0);
+    int rb = 0;
+    if (valid(cc)) {
+        issue(cc);
         __syncthreads();  // lbn / lsc are staged
-        commit(first, 0);
-        if (count > 1) issue(first + 1);
+        commit(cc, rb, 0);
+        cn = cc;
+        advance(cn);
+        ci = cn;
+        if (valid(cn)) {
+            issue(cn);
+            advance(ci);
+        }
     }
     __syncthreads();
     int cur = 0;
-    for (int idx = 0; idx < count; ++idx) {
-        compute(cur);
-        if (idx + 1 < count) {
-            commit(first + idx + 1, cur ^ 1);
-            if (idx + 2 < count) issue(first + idx + 2);
+    while (valid(cc)) {
+        compute(rb, cur);
+        int rb_next = rb;
+        if (valid(cn)) {
+            rb_next = rb + (cn.tt == 0 ? PH : TH);
+            rb_next = rb_next >= S::NSLOT ? rb_next - S::NSLOT : rb_next;
+            commit(cn, rb_next, cur ^ 1);
+            if (valid(ci)) {
+                issue(ci);
+                advance(ci);
+            }
         }
         __syncthreads();
+        cc = cn;
+        if (valid(cn)) advance(cn);
+        rb = rb_next;
         cur ^= 1;
     }
 
@@ -508,7 +559,7 @@ __global__ __launch_bounds__(kSumT) void slab_sum_kernel(const float* __restrict
 struct WgBf16Plan {
     int variant;  // index into the launch table
     int tw, th, cib, cob, stem;
-    int tiles_x, tiles_y, items, splits, items_per_split, gy, gz;
+    int tiles_x, tiles_y, seg_tiles, segs, splits, interleave, gy, gz;
 };
 
 // tile shapes: 32x8 (any width, partial tiles masked), 56x4 (112 and 56 wide), 28x4 (28 wide)
@@ -527,15 +578,24 @@ WgBf16Plan plan_wgrad_bf16(int n, int cin, int cout, int h, int w, int ksize) {
     }
     pl.tiles_x = (w + pl.tw - 1) / pl.tw;
     pl.tiles_y = (h + pl.th - 1) / pl.th;
-    pl.items = n * pl.tiles_x * pl.tiles_y;
     pl.gy = pl.stem ? 1 : (cin + 32 * pl.cib - 1) / (32 * pl.cib);
     pl.gz = cout / (32 * pl.cob);
-    // one resident 12-wave workgroup per CU (3x3), a few 4-wave ones (1x1): two rounds' worth of splits
-    int splits = (256 * 2) / (pl.gy * pl.gz);
-    if (splits < 1) splits = 1;
-    if (splits > pl.items) splits = pl.items;
-    pl.items_per_split = (pl.items + splits - 1) / splits;
-    pl.splits = (pl.items + pl.items_per_split - 1) / pl.items_per_split;
+    // one resident 12-wave workgroup per CU (3x3), a few 4-wave ones (1x1): two rounds' worth of workgroups, each
+    // with a slab of partial sums of its own.  They walk column strips; strips are cut into segments (which re-stage
+    // the two rows above them) only when there are too few to go round — small batches.
+    int want = (256 * 2) / (pl.gy * pl.gz);
+    if (want < 1) want = 1;
+    const int strips = n * pl.tiles_x;
+    int segs = (want + strips - 1) / strips;
+    const int max_segs = (pl.tiles_y + 3) / 4;        // at least four tiles to a segment
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    pl.seg_tiles = (pl.tiles_y + segs - 1) / segs;
+    pl.segs = (pl.tiles_y + pl.seg_tiles - 1) / pl.seg_tiles;
+    const int units = strips * pl.segs;
+    pl.splits = want < units ? want : units;
+    // an image's strips side by side on one XCD (see the kernel) when the grid's x extent divides over the XCDs
+    pl.interleave = (pl.splits % 8 == 0 && n >= 8 && pl.gy * pl.gz == 1) ? 1 : 0;
     return pl;
 }
 
@@ -622,7 +682,8 @@ int lf_conv2d_wgrad_bf16(const void* x, const uint16_t* g, const uint16_t* bn_y,
     a.x = static_cast<const uint16_t*>(x); a.g = g; a.part = static_cast<float*>(workspace);
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
     a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.w = w;
-    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.items = pl.items; a.items_per_split = pl.items_per_split;
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.seg_tiles = pl.seg_tiles; a.segs = pl.segs;
+    a.interleave = pl.interleave;
     a.bn_y = bn_y; a.bn_alpha = alpha_nc; a.bn_add = add_nc; a.bn_coef = coef; a.dy_out = dy_out;
     a.bn_relu = bn_relu;
     dim3 grid(pl.splits, pl.gy, pl.gz);

@@ -53,6 +53,14 @@ def close_bf16(got, ref, max_frac, terms=None):
     (2, 96, 64, 12, 16, 3, True, True, False, "fwd"),    # K-chunked kernel, three 32-channel chunks
     (2, 160, 128, 8, 24, 3, True, False, True, "bwd"),   # five 16-channel slices: the last chunk half empty
     (2, 48, 64, 12, 12, 1, True, True, True, "fwd"),
+    # the streaming kernel's row ring (a workgroup walks down a column strip; a tile stages only its new rows):
+    (2, 32, 64, 24, 64, 3, True, True, False, "fwd"),     # 64x4 tiles, six per strip, two output blocks
+    (1, 64, 64, 20, 72, 3, True, False, True, "bwd"),     # two strips, the second 8 of 64 columns wide; 64 channels
+    (2, 64, 32, 32, 32, 3, True, True, True, "fwd"),      # 32x8 tiles, four per strip
+    (8, 32, 32, 12, 64, 3, True, False, True, "bwd"),     # >= 8 images: strips dealt out per XCD
+    (16, 32, 32, 8, 136, 3, True, True, False, "fwd"),    # three strips per image, 48 of them over the XCDs
+    (3, 3, 32, 20, 64, 3, False, False, False, "fwd"),    # the stem (fp32 input) on the ring
+    (9, 32, 64, 16, 64, 1, True, True, False, "fwd"),     # 1x1: no halo, a ring of TH rows
 ])
 def test_conv2d_bf16_train(cuda, n, cin, cout, h, w, k, xbf, pro, acc, stat):
     from leaffliction_amd import nn
@@ -80,12 +88,16 @@ def test_conv2d_bf16_train(cuda, n, cin, cout, h, w, k, xbf, pro, acc, stat):
     torch.cuda.synchronize()
     # float64 restatement on the rounded operands
     a = x.to(torch.float64)
-    if pro:
-        a = torch.relu((x.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))).to(torch.float64)
+    if pro:   # the kernel's prologue is ONE fmaf in fp32: the exact product and sum, rounded once
+        a = torch.relu((x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()).double()
     ref = conv_ref(q(a), q(wt), k)
+    # the kernel sums exact bf16 products in fp32: where the products cancel, |ref| says nothing about the size of
+    # the accumulation error, the sum of their magnitudes does (a few 2^-24 of it over the 18-36 MFMAs of a pixel)
+    terms = conv_ref(q(a).abs(), q(wt).abs(), k)
     if acc:
         ref = ref + old.to(torch.float64)
-    close_bf16(out, ref, 0.02)
+        terms = terms + old.to(torch.float64).abs()
+    close_bf16(out, ref, 0.02, terms)
     if stat is None:
         return
     _, (tp, tiles) = res
@@ -228,14 +240,25 @@ def test_plane_kernels_bf16(cuda):
     assert torch.equal(nn.cast_bf16_f32(b16, torch.empty(1000, device=dev)).cpu(), f.to(BF).float())
 
 
-@pytest.mark.parametrize("size,n,widths,classes", [(32, 8, [32, 64], 4), (64, 4, [32, 64, 128], 3)])
+STEP_CASES = [
+    (32, 8, [32, 64], 4),
+    (64, 4, [32, 64, 128], 3),
+    # BASELINE configs[3]'s geometry: img 224, the base widths, 8 classes.  This is the case that takes the
+    # streaming 64x4 kernels at 224^2 / 112^2, the K-chunked ones at 56^2 / 28^2 and the <9,56,4,...> /
+    # <9,28,4,...> weight-gradient kernels of the benchmark step.
+    (224, 2, [32, 64, 128, 256], 8),
+]
+
+
+@pytest.mark.parametrize("size,n,widths,classes", STEP_CASES)
 def test_train_step_bf16_matches_lowp_oracle(cuda, size, n, widths, classes):
     """One forward/backward of the bf16 step vs the oracle evaluated with bf16 rounding at the same
     points (cnn_ref.train_step(lowp=True)).  What remains between the two is (1) fp32 accumulation
     order and (2) one-step bf16 flips of values next to a rounding boundary, each a 2^-9 relative
-    perturbation of one element that the following layers average out; the bounds below are
-    ~4x what these produce at this size (measured), and 10-30x below the distance between the
-    bf16 step and the fp32 step, which the test also reports as the scale of comparison."""
+    perturbation of one element that the following layers average out.  The bounds are ~3x what was
+    MEASURED on the MI355X for each case (STEP_BOUNDS below; the measured values are in the comment
+    next to each), and the test also reports the distance between the rounded oracle and the fp32
+    oracle as the scale of comparison."""
     from leaffliction_amd import ops
     from leaffliction_amd.model.cnn import LeafCNN
     from oracle import cnn_ref as R
@@ -257,21 +280,102 @@ def test_train_step_bf16_matches_lowp_oracle(cuda, size, n, widths, classes):
     args = (x0.cpu(), onehot, widths, [t.cpu() for t in drops], top.cpu())
     _t, dl_lo, p_lo, g_lo = R.train_step(ref_p, R.init_state(widths), *args, grads_include_l2=False, lowp=True)
     _t, dl_32, p_32, g_32 = R.train_step(ref_p, R.init_state(widths), *args, grads_include_l2=False)
-    assert (probs.cpu() - p_lo).abs().max().item() < 5e-3
-    assert abs(loss.mean().item() - dl_lo) < 5e-3 * max(1.0, abs(dl_lo))
-    worst = 0.0
+    # the same bf16 step with every sum taken in DOUBLE precision: how far the step moves when nothing but the
+    # accumulation arithmetic changes (rounding points, operands and draws are the same).  That distance is the
+    # yardstick for the HIP step, whose sums are fp32 in yet another order.
+    d64 = lambda t: t.double()  # noqa: E731
+    _t, _dl, _p64, g_64 = R.train_step({k: d64(v) for k, v in ref_p.items()},
+                                       {k: d64(v) for k, v in R.init_state(widths).items()}, d64(args[0]),
+                                       d64(args[1]), widths, [d64(t) for t in args[3]], d64(args[4]),
+                                       grads_include_l2=False, lowp=True)
+    gbound, mbound, pbound = STEP_BOUNDS[size]
+    perr = (probs.cpu() - p_lo).abs().max().item()
+    report = {"size": size, "probs": perr, "loss": abs(loss.mean().item() - dl_lo), "tensors": {}}
+    errs, selfs = [], []
     for name, _s, _k in m.specs:
         ref = g_lo[name]
-        err = (m.g[name].cpu() - ref).norm().item() / (ref.norm().item() + 1e-12)
-        gap = (g_32[name] - ref).norm().item() / (ref.norm().item() + 1e-12)
-        worst = max(worst, err)
-        # the HIP step must sit much closer to the rounded oracle than the rounded oracle to fp32
-        assert err < max(0.05, 0.5 * gap), (name, err, gap)
-    assert worst < 0.2
+        nrm = ref.norm().item() + 1e-12
+        err = (m.g[name].cpu() - ref).norm().item() / nrm
+        gap = (g_32[name] - ref).norm().item() / nrm
+        own = (g_64[name].float() - ref).norm().item() / nrm
+        errs.append(err)
+        selfs.append(own)
+        report["tensors"][name] = (round(err, 5), round(own, 5), round(gap, 5))
+    worst, median = max(errs), float(np.median(errs))
+    report.update(worst=worst, median=median, oracle_f64_vs_f32_worst=max(selfs),
+                  oracle_f64_vs_f32_median=float(np.median(selfs)))
+    _leave_report(f"bf16_step_vs_lowp_oracle_{size}", report)
+    assert perr < pbound, report
+    assert abs(loss.mean().item() - dl_lo) < pbound * max(1.0, abs(dl_lo)), report
+    # every gradient tensor within ~3x the distance MEASURED on the MI355X (STEP_BOUNDS), worst and median
+    assert worst < gbound and median < mbound, report
+    # and no tensor further from the restatement than 3x what the restatement itself moves under double-precision sums
+    for name, (err, own, _gap) in report["tensors"].items():
+        assert err < 3.0 * own + 0.01, (name, err, own)
     # and the optimizer step on top of it runs
     m.train_step(x, y, lr=1e-3)
     torch.cuda.synchronize()
     assert torch.isfinite(m.flat_p).all()
+
+
+# size -> (bound on the worst gradient tensor's relative error norm vs the lowp oracle, bound on the median over the
+# tensors, bound on |probs - oracle| and the loss).  Measured on the MI355X (round 3, gpurun_out/parity/*.json):
+#   32:  worst 0.028 (s0.bn1.beta), median 0.006, probs 3.6e-4
+#   64:  worst 0.053 (s0.bn1.gamma), median 0.014, probs 1.9e-4
+#   224: worst 0.089 (stem.w; n = 2, 224 x 224 x base widths), median 0.018, probs 1.9e-4
+# The worst tensors are always stage 0's: the END of the backward chain, where one-step bf16 flips of values next to a
+# rounding boundary have passed through the most layers.  Bounds = 3x measured.
+STEP_BOUNDS = {32: (0.085, 0.02, 1.2e-3), 64: (0.16, 0.045, 6e-4), 224: (0.27, 0.055, 6e-4)}
+
+
+def _leave_report(name, doc):
+    """Measured distances go to gpurun_out/ (merged back from the GPU box) so that the bounds above can be read
+    against what the hardware produced."""
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, name + ".json"), "w") as f:
+            json.dump(doc, f, indent=1)
+    except OSError:
+        pass
+
+
+def test_training_step_bf16_fullsize_reproducible(cuda):
+    """BASELINE configs[3]'s per-GPU work at full size (batch 256, img 224, base widths, bf16 step with in-model
+    augmentation, dropout, SE): three optimisation steps — two eager, the third captured into the HIP graph —
+    twice from the same seeds.  The kernels are deterministic (fixed-order slab sums, no float atomics), so losses,
+    parameters and gradients must be BIT-equal between the two runs, finite, and of the size a random-init
+    8-class net produces."""
+    from leaffliction_amd.model.cnn import LeafCNN
+    n, s = 256, 224
+    g = torch.Generator(device="cpu").manual_seed(6)
+    x = torch.randint(0, 256, (n, s, s, 3), dtype=torch.uint8, generator=g).to(cuda)
+    y = F.one_hot(torch.randint(0, 8, (n,), generator=g), 8).float().to(cuda)
+    outs = []
+    for _ in range(2):
+        m = LeafCNN(num_classes=8, img_size=s, widths=(32, 64, 128, 256), drop_block=0.15, drop_top=0.4,
+                    l2_reg=1e-4, augment=True, use_se=True, seed=9, device=cuda)
+        m.set_training_dtype("bf16")
+        losses = []
+        for step in range(4):
+            _p, loss = m.train_step(x, y, 1e-3)
+            losses.append(loss.mean().item())
+        assert any(st["graph"] is not None for st in m._graphs.values())   # steps 3 and 4 replayed the graph
+        outs.append((losses, m.flat_p.clone(), m.flat_g.clone()))
+        del m
+    (l1, p1, g1), (l2, p2, g2) = outs
+    assert all(np.isfinite(l1)) and l1 == l2
+    assert torch.equal(p1, p2) and torch.equal(g1, g2)
+    assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    assert 0.5 < l1[0] < 8.0
+    # the bf16 step describes the same function as the fp32 step: its first-step loss (same seeds, same draws)
+    # within 2 % of the fp32 step's
+    m32 = LeafCNN(num_classes=8, img_size=s, widths=(32, 64, 128, 256), drop_block=0.15, drop_top=0.4,
+                  l2_reg=1e-4, augment=True, use_se=True, seed=9, device=cuda)
+    _p, l32 = m32.train_step(x, y, 1e-3)
+    assert abs(l32.mean().item() - l1[0]) < 0.02 * l1[0], (l32.mean().item(), l1[0])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -296,4 +400,49 @@ def test_graph_replay_equals_eager_launches(cuda, dtype):
         assert (not graphs) or any(st["graph"] is not None for st in m._graphs.values())
         res.append((m.flat_p.clone(), m.flat_s.clone(), losses))
     assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graph_is_rerecorded_when_a_workspace_buffer_is_replaced(cuda, dtype):
+    """The recorded step holds raw pointers into the library's grow-only workspace buffers (nn._workspace).  A later,
+    larger launch replaces such a buffer and hands the old one back to the allocator; replaying the old graph would
+    then read and write memory it no longer owns.  The model compares workspace generations and records again.
+    Sequence: batch A four times (recorded on the third), a much larger batch B (the buffers grow), batch A three
+    more times — against the same sequence with eager launches: bit-equal parameters and statistics."""
+    from leaffliction_amd import nn
+    from leaffliction_amd.model.cnn import LeafCNN
+    g = torch.Generator().manual_seed(4)
+    xa = torch.randint(0, 256, (6, 32, 32, 3), dtype=torch.uint8, generator=g).to(cuda)
+    ya = F.one_hot(torch.randint(0, 3, (6,), generator=g), 3).float().to(cuda)
+    xb = torch.randint(0, 256, (192, 32, 32, 3), dtype=torch.uint8, generator=g).to(cuda)
+    yb = F.one_hot(torch.randint(0, 3, (192,), generator=g), 3).float().to(cuda)
+    res = []
+    for graphs in (True, False):
+        torch.cuda.synchronize()
+        nn._ws_cache.clear()             # start from small workspaces, whatever ran before in this process
+        m = LeafCNN(num_classes=3, img_size=32, widths=[32, 64], l2_reg=1e-4, use_norm=False, seed=9, device=cuda)
+        m.set_training_dtype(dtype)
+        m._graphs_on = graphs
+        for _ in range(4):
+            m.train_step(xa, ya, lr=1e-3)
+        gen0 = nn.workspace_generation()
+        key_a = next(k for k in m._graphs if k[0] == tuple(xa.shape)) if graphs else None
+        assert (not graphs) or m._graphs[key_a]["graph"] is not None
+        m.train_step(xb, yb, lr=1e-3)
+        torch.cuda.synchronize()
+        assert nn.workspace_generation() > gen0, "batch B did not grow a workspace: the test needs a larger one"
+        # scribble over whatever the allocator hands out next: a stale replay would pick this up
+        junk = [torch.full((1 << 20,), 0xFF, dtype=torch.uint8, device=cuda) for _ in range(8)]
+        m.train_step(xa, ya, lr=1e-3)
+        if graphs:
+            assert m._graphs[key_a]["graph"] is None          # dropped, this step ran eagerly
+        m.train_step(xa, ya, lr=1e-3)
+        m.train_step(xa, ya, lr=1e-3)
+        torch.cuda.synchronize()
+        if graphs:
+            assert m._graphs[key_a]["graph"] is not None      # recorded again on the current buffers
+        del junk
+        res.append((m.flat_p.clone(), m.flat_s.clone()))
+    assert torch.isfinite(res[0][0]).all()
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
