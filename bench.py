@@ -254,8 +254,9 @@ def augment_throughput(dev, n=4096, iters=5, only=None):
         "skew": (lambda: ops.warp_bicubic_u8(x, skew, True, True), 2 * img_b),
         "shear": (lambda: ops.warp_bicubic_u8(x, shear, False), 2 * img_b),
         "crop": (lambda: ops.resample_u8(x, IMG, IMG, ctab[0], ctab[1], ctab[2], ctab[3], True, ctab[4]), 2 * img_b),
-        # distortion = noise add (2 passes) + histogram (1 read) + LUT apply (2): 5 image passes
-        "distortion": (lambda: ops.autocontrast_u8(ops.noise_philox_add_u8(x, 42, 5.0), cut), 5 * img_b),
+        # distortion = noise add (2 passes) + histogram (1 read) + LUT apply (2): 5 image passes by the reference's
+        # count (kept as the algorithmic figure); the kernels make 4 — the histogram is taken while the noise is added
+        "distortion": (lambda: ops.distortion_u8(x, cut, seed=42, sigma=5.0), 5 * img_b),
         "pack": (lambda: ops.pack_hwc_u8_to_nchw_f32(x), img_b + 4 * img_b),
         "hist": (lambda: ops.hist_u8(x), img_b + 3072),
         # the transform-side kernels the north star names: mask-and-composite, separable blur,
@@ -292,8 +293,15 @@ def augment_throughput(dev, n=4096, iters=5, only=None):
 
 
 # ---- end to end: `Augmentation.py` over synthetic 224x224 JPEGs (BASELINE configs[2]) -----------
-_E2E_LAYOUT = {"Apple": {"healthy": 2500, "rust": 500, "scab": 500, "rot": 500},
-               "Grape": {"healthy": 2500, "esca": 1000, "spot": 500, "blight": 500}}   # 11,500 to generate
+# class counts per 1,000 generated images: the balancer tops every class of a plant up to the plant's largest
+# (x 100 = BASELINE configs[2]'s 100,000 generated files from 72,000 originals)
+_E2E_UNIT = {"Apple": {"healthy": 215, "rust": 45, "scab": 45, "rot": 45},
+             "Grape": {"healthy": 215, "esca": 85, "spot": 35, "blight": 35}}
+
+
+def _e2e_layout(generated: int):
+    k = max(1, round(generated / 1000))
+    return {plant: {cls: n * k for cls, n in classes.items()} for plant, classes in _E2E_UNIT.items()}
 
 
 def _e2e_write(job):
@@ -303,13 +311,13 @@ def _e2e_write(job):
     return True
 
 
-def _e2e_make_dataset(root: Path, dev, threads: int) -> int:
-    """8,500 synthetic originals: low-frequency colour fields + noise (JPEG sizes like photographs:
+def _e2e_make_dataset(root: Path, dev, threads: int, layout) -> int:
+    """The synthetic originals: low-frequency colour fields + noise (JPEG sizes like photographs:
     ~25 KB), generated on the GPU in chunks, encoded on host threads.  Not timed."""
     from concurrent.futures import ThreadPoolExecutor
     g = torch.Generator(device=dev).manual_seed(42)
     jobs = []
-    for plant, classes in _E2E_LAYOUT.items():
+    for plant, classes in layout.items():
         for cls, n in classes.items():
             d = root / plant / f"{plant}_{cls}"
             d.mkdir(parents=True)
@@ -361,24 +369,41 @@ def _pil_task(task):
     return True
 
 
-def augment_end_to_end(dev):
-    """The rate a user of `Augmentation.py` sees (BASELINE configs[2]): DatasetBalancer.run() over a
-    synthetic dataset of 8,500 224x224 JPEGs -> 11,500 generated files + manifest (JPEG decode on host
-    threads -> H2D -> kernels -> D2H -> JPEG encode, plus the copy of the originals), and beside it the
-    same task list run the reference's way — one Pillow call chain per task in a process pool — with the
-    reference's default worker count (dataset_balancer.py:41-44) and with every core, on a bounded sample."""
+def _cpu_pool_job(src: Path, dst: Path, tasks, workers: int):
+    """The WHOLE job the reference's way (dataset_balancer.py:70-81,97-168): the balanced tree starts as a copy of
+    the originals (shutil.copytree), then one Pillow call chain per task in a pool of `workers` processes writes the
+    generated files into it.  Returns (seconds for everything, seconds of the copy)."""
+    import shutil
+    from concurrent.futures import ProcessPoolExecutor
+    t0 = time.perf_counter()
+    shutil.copytree(src, dst)
+    t_copy = time.perf_counter() - t0
+    jobs = [(t["read_img"], str(dst / Path(t["output_path"]).relative_to(Path(t["output_path"]).parents[2])),
+             t["transform_name"], t["seed"]) for t in tasks]
+    with ProcessPoolExecutor(max_workers=workers) as ex:
+        list(ex.map(_pil_task, jobs, chunksize=16))
+    return time.perf_counter() - t0, t_copy
+
+
+def augment_end_to_end(dev, generated: int = None):
+    """The rate a user of `Augmentation.py` sees at BASELINE configs[2]'s size: DatasetBalancer.run() over a
+    synthetic dataset of 72,000 224x224 JPEGs -> 100,000 generated files + manifest (LF_E2E_IMAGES sets the number
+    of generated files; the copy of the originals, JPEG decode, H2D, kernels, D2H, JPEG encode, manifest all inside
+    the timed region), and beside it THE SAME JOB run the reference's way — copytree, then one Pillow call chain
+    per task in a process pool — with every granted core and with the reference's default worker count
+    (dataset_balancer.py:41-44); the default-count run is bounded to a quarter of the tasks and scaled."""
     import shutil
     import tempfile
-    from concurrent.futures import ProcessPoolExecutor
 
     from leaffliction_amd.preprocessing.dataset_balancer import DatasetBalancer
     from leaffliction_amd.utils.system_info import get_available_cores
+    generated = int(os.environ.get("LF_E2E_IMAGES", "100000")) if generated is None else generated
     cores = min(get_available_cores(), usable_cores())
     tmp = Path(tempfile.mkdtemp(prefix="lf_e2e_"))
     cwd = os.getcwd()
     try:
         src, dst = tmp / "images", tmp / "augmented"
-        n_orig = _e2e_make_dataset(src, dev, cores)
+        n_orig = _e2e_make_dataset(src, dev, cores, _e2e_layout(generated))
         os.chdir(tmp)
         bal = DatasetBalancer(source_dir=str(src), target_dir=str(dst), seed=42, workers=cores)   # `--workers` = all granted cores
         bal.analyze_distribution()
@@ -393,22 +418,25 @@ def augment_end_to_end(dev):
                "pipeline_images_per_sec": round(bal.completed / max(
                    bal.timings.get("decode_kernels_encode", sec) - bal.timings.get("codec_pool_start", 0.0), 1e-6), 1),
                "includes": "copy of the originals, JPEG decode, H2D, kernels, D2H, JPEG encode (q=95), manifest"}
-        # CPU pools on a sample of the same task list (fresh output names in a scratch tree)
-        sample = bal.tasks[:: max(1, len(bal.tasks) // 1500)][:1500]
-        scratch = tmp / "cpu_out"
-        scratch.mkdir()
-        jobs = [(t["source_img"], str(scratch / f"{i}.jpg"), t["transform_name"], t["seed"]) for i, t in enumerate(sample)]
-        pools = {}
+        tasks = bal.tasks
+        shutil.rmtree(dst, ignore_errors=True)   # disk space for the CPU runs
+        # the same job on host cores only: every task, all granted cores
+        sec_all, copy_all = _cpu_pool_job(src, tmp / "cpu_all", tasks, cores)
+        shutil.rmtree(tmp / "cpu_all", ignore_errors=True)
+        pools = {"all_cores": {"images_per_sec": round(len(tasks) / sec_all, 1), "workers": cores, "tasks": len(tasks),
+                               "seconds": round(sec_all, 2), "copy_seconds": round(copy_all, 2)}}
+        # the reference's default worker count: the copy + every fourth task, the pool part scaled by four
         ref_default = max(1, int(cores * 0.75) // 2)   # dataset_balancer.py:41-44 with system_info.py:37-46
-        for label, workers in (("reference_default_workers", ref_default), ("all_cores", cores)):
-            with ProcessPoolExecutor(max_workers=workers) as ex:
-                list(ex.map(_pil_task, jobs[:workers * 2], chunksize=1))   # start the workers
-                t0 = time.perf_counter()
-                list(ex.map(_pil_task, jobs, chunksize=8))
-                dt = time.perf_counter() - t0
-            pools[label] = {"images_per_sec": round(len(jobs) / dt, 1), "workers": workers, "tasks": len(jobs)}
-        out["cpu_pool_baseline"] = {"kind": "the reference's libraries (Pillow/numpy call chain of image_augmenter.py, one "
-                                            "process per worker, file -> file)", "cores": cores, **pools}
+        part = tasks[::4]
+        sec_def, copy_def = _cpu_pool_job(src, tmp / "cpu_def", part, ref_default)
+        est = copy_def + (sec_def - copy_def) * (len(tasks) / max(1, len(part)))
+        pools["reference_default_workers"] = {"images_per_sec": round(len(tasks) / est, 1), "workers": ref_default,
+                                              "tasks": len(part), "seconds_scaled_to_all_tasks": round(est, 2),
+                                              "copy_seconds": round(copy_def, 2)}
+        out["cpu_pool_baseline"] = {"kind": "the reference's libraries on the same job (copytree, then the Pillow/numpy call "
+                                            "chain of image_augmenter.py per task, one process per worker, file -> file)",
+                                    "cores": cores, **pools}
+        out["vs_cpu_all_cores"] = round(out["images_per_sec"] / pools["all_cores"]["images_per_sec"], 3)
         return out
     finally:
         os.chdir(cwd)
@@ -651,7 +679,9 @@ def main() -> None:
     # call `fit` makes
     grad_sync = dp.allreduce_grads if dp is not None else None
     global_n = world * n if dp is not None else None
-    step_kw = {"grad_sync": grad_sync, "global_n": global_n}
+    step_kw = {"grad_sync": grad_sync, "global_n": global_n,
+               # the bucket goes out in two pieces, the first beside the 224 x 224 layers' backward (train_step)
+               "grad_overlap": dp if dp is not None and dp.overlap else None}
 
     def lr_at(step):
         return 2e-3 * 0.5 * (1.0 + math.cos(math.pi * min(step, total) / total))
@@ -782,7 +812,8 @@ def main() -> None:
                "config": {"workload": "leaf_cnn base train step, mixed precision (configs[3] per-GPU work: img 224, "
                                       "batch 256/GPU, bf16, 8 classes, AdamW+clipnorm+EMA, in-model augmentation)",
                           "per_gpu_batch": n, "global_batch": world * n, "img_size": IMG,
-                          "parallelism": f"dp{world}", "grad_bucket": dp.bucket_dtype if dp is not None else None},
+                          "parallelism": f"dp{world}", "grad_bucket": dp.bucket_dtype if dp is not None else None,
+                          "grad_overlap": bool(dp is not None and dp.overlap)},
                "roofline": bf16["roofline"], "conv_all": bf16["conv_all"], "step_tflops": bf16["step_tflops"],
                "final_loss": bf16["final_loss"], "per_kernel": bf16["per_kernel"]}
         if not args.no_cpu_baseline and world == 1:

@@ -100,6 +100,15 @@ int lf_add_wrap_u8(const uint8_t* in, const uint8_t* add, uint8_t* out, size_t n
 int lf_noise_philox_add_u8(const uint8_t* in, uint8_t* out, size_t nbytes, uint64_t seed,
                            float sigma, lf_stream_t stream);
 
+/* ImageAugmenter.distortion (image_augmenter.py:121-131), first half in one pass: out = in + noise
+ * (mod 256) TOGETHER WITH the per-image, per-channel histogram of `out` that ImageOps.autocontrast
+ * takes next (hist [N][3][256] int32, as lf_hist_u8 gives it) — the noisy image is not read back
+ * just to be counted.  add != NULL: the uint8 noise plane of lf_add_wrap_u8; add == NULL: the
+ * Philox noise of lf_noise_philox_add_u8 (same seed -> same bytes).  h*w*3 % 16 == 0, 16-byte
+ * aligned buffers. */
+int lf_noise_hist_u8(const uint8_t* in, const uint8_t* add, uint8_t* out, int32_t* hist, int n, int h,
+                     int w, uint64_t seed, float sigma, lf_stream_t stream);
+
 /* apply_mask (srcs/utils/mask_utils.py:67-79) and blur.py:74-75:
  * out = mask > 127 ? img : color (color 0 or 255), mask is [N][H][W] u8. */
 int lf_mask_composite_u8(const uint8_t* img, const uint8_t* mask, uint8_t* out, int n, int h,

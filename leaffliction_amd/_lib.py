@@ -32,6 +32,7 @@ SIGNATURES = {
     "lf_noise_wrap_add_u8": [P, P, P, c_size_t, P],
     "lf_add_wrap_u8": [P, P, P, c_size_t, P],
     "lf_noise_philox_add_u8": [P, P, c_size_t, c_u64, c_float, P],
+    "lf_noise_hist_u8": [P, P, P, P, c_int, c_int, c_int, c_u64, c_float, P],
     "lf_mask_composite_u8": [P, P, P, c_int, c_int, c_int, c_int, P],
     "lf_rgb2hsv_u8": [P, P, c_size_t, P],
     "lf_rgb2gray_u8": [P, P, c_size_t, P],

@@ -478,6 +478,84 @@ __global__ __launch_bounds__(kBlock) void noise_philox_kernel(const uint8_t* __r
     }
 }
 
+// The distortion's first two passes in one (round 3): out = in + noise (mod 256) AND the per-image, per-channel
+// histogram of `out`, which autocontrast needs next — one workgroup per image with the slotted table of
+// hist_slot_kernel, so the noisy image is not read back from memory just to be counted (5 image passes -> 4).
+// ADD: the noise is a uint8 plane (cast on the host by numpy, lf_add_wrap_u8); otherwise Philox4x32-10 + Box-Muller
+// keyed by (seed, dword index in the BATCH), the very values lf_noise_philox_add_u8 draws.  nbytes % 16 == 0.
+template <bool ADD>
+__global__ __launch_bounds__(kBlock) void noise_hist_kernel(const uint8_t* __restrict__ in,
+                                                            const uint8_t* __restrict__ add,
+                                                            uint8_t* __restrict__ out, int32_t* __restrict__ hist,
+                                                            size_t nbytes, int n, uint64_t seed, float sigma) {
+    __shared__ __attribute__((aligned(16))) unsigned tab[768 * kHistSlots];
+    const unsigned slot = threadIdx.x & (kHistSlots - 1);
+    const size_t nchunks = nbytes / 16;
+    for (int img = blockIdx.x; img < n; img += gridDim.x) {
+        for (int i = threadIdx.x; i < 768 * kHistSlots / 4; i += kBlock)
+            reinterpret_cast<lf::u32x4*>(tab)[i] = lf::u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        const lf::u32x4* src = reinterpret_cast<const lf::u32x4*>(in + (size_t)img * nbytes);
+        const lf::u32x4* nz = ADD ? reinterpret_cast<const lf::u32x4*>(add + (size_t)img * nbytes) : nullptr;
+        lf::u32x4* dst = reinterpret_cast<lf::u32x4*>(out + (size_t)img * nbytes);
+        const size_t word0 = (size_t)img * (nbytes / 4);
+        for (size_t q = threadIdx.x; q < nchunks; q += kBlock) {
+            const lf::u32x4 v = src[q];
+            const unsigned x[4] = {v.x, v.y, v.z, v.w};
+            unsigned y[4];
+            if (ADD) {
+                const lf::u32x4 a = nz[q];
+                const unsigned b[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)   // per-byte add without carries across bytes
+                    y[k] = ((x[k] & 0x7f7f7f7fu) + (b[k] & 0x7f7f7f7fu)) ^ ((x[k] ^ b[k]) & 0x80808080u);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const size_t wq = word0 + 4 * q + k;
+                    uint32_t r[4];
+                    philox4x32_10((uint32_t)wq, (uint32_t)(wq >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+                    float z[4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float u1 = ((float)(r[2 * j] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                        const float u2 = ((float)(r[2 * j + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                        const float rad = sigma * __fsqrt_rn(-2.0f * __logf(u1));
+                        float sn, cs;
+                        __sincosf(6.283185307179586f * u2, &sn, &cs);
+                        z[2 * j] = rad * cs;
+                        z[2 * j + 1] = rad * sn;
+                    }
+                    unsigned o = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o |= ((byte_of(x[k], j) + (unsigned)(int)z[j]) & 0xffu) << (8 * j);
+                    y[k] = o;
+                }
+            }
+            dst[q] = lf::u32x4{y[0], y[1], y[2], y[3]};
+            const unsigned r0 = (unsigned)((q * 16) % 3);   // channel of byte 0 of this chunk (images start on a pixel)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                unsigned c = r0 + (j % 3);
+                c = c >= 3 ? c - 3 : c;
+                atomicAdd(&tab[(c * 256 + byte_of(y[j >> 2], j & 3)) * kHistSlots + slot], 1u);
+            }
+        }
+        __syncthreads();
+        int32_t* gh = hist + (size_t)img * 768;
+        for (int b = threadIdx.x; b < 768; b += kBlock) {
+            unsigned sum = 0;
+#pragma unroll
+            for (int k = 0; k < kHistSlots / 4; ++k) {
+                const lf::u32x4 v = reinterpret_cast<const lf::u32x4*>(tab)[b * (kHistSlots / 4) + k];
+                sum += (v.x + v.y) + (v.z + v.w);
+            }
+            gh[b] = (int32_t)sum;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // mask-and-composite
 // ---------------------------------------------------------------------------
@@ -1133,6 +1211,22 @@ int lf_noise_philox_add_u8(const uint8_t* in, uint8_t* out, size_t nbytes, uint6
         noise_philox_kernel<false><<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, nwords,
                                                                               nbytes, seed, sigma);
     return lf::check_launch("lf_noise_philox_add");
+}
+
+int lf_noise_hist_u8(const uint8_t* in, const uint8_t* add, uint8_t* out, int32_t* hist, int n, int h, int w,
+                     uint64_t seed, float sigma, lf_stream_t stream) {
+    LF_REQUIRE(in && out && hist, "lf_noise_hist_u8: null buffer");
+    LF_REQUIRE(n > 0 && h > 0 && w > 0, "lf_noise_hist_u8: bad dims n=%d h=%d w=%d", n, h, w);
+    const size_t nbytes = (size_t)h * w * 3;
+    LF_REQUIRE(nbytes % 16 == 0, "lf_noise_hist_u8: an image must be a multiple of 16 bytes (got %zu)", nbytes);
+    LF_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(add) | reinterpret_cast<size_t>(out)) & 15) == 0,
+               "lf_noise_hist_u8: buffers must be 16-byte aligned");
+    const unsigned grid = (unsigned)std::min<size_t>((size_t)n, (size_t)256 * 8);
+    if (add != nullptr)
+        noise_hist_kernel<true><<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, add, out, hist, nbytes, n, seed, sigma);
+    else
+        noise_hist_kernel<false><<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, add, out, hist, nbytes, n, seed, sigma);
+    return lf::check_launch("lf_noise_hist_u8");
 }
 
 int lf_mask_composite_u8(const uint8_t* img, const uint8_t* mask, uint8_t* out, int n, int h,

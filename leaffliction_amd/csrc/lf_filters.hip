@@ -664,6 +664,398 @@ __global__ __launch_bounds__(kBlock) void inclusive_morph_kernel(const uint32_t*
 constexpr size_t kAlign = 256;
 inline size_t up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
+// ===========================================================================
+// Round 3: the per-image middle of both filters in ONE workgroup per image, planes resident in LDS.
+//
+// Both chains above spend their time in launches and in round trips of small planes through L2 / HBM (13 launches
+// and 20 bytes of intermediates per pixel for the saliency filter).  A 224 x 224 gray plane is 50 KB: the gray
+// plane, the Canny map and the bit planes of the brown regions of one image fit the 160 KB of a CU together, and
+// everything the old kernels kept in 4-byte planes (squared gradient, (dx, dy), gradient magnitude, colour
+// difference, saliency) is cheaper to RECOMPUTE from the gray plane in LDS / the two RGB images in L2 than to store.
+// What stays outside: the two Gaussian blurs (the i8-MFMA kernel of lf_blur_mfma.hip) and the final masking pass.
+// The arithmetic is the old kernels', expression for expression (the bit-exact tests are unchanged).
+// ===========================================================================
+constexpr int kFuseT = 1024;
+
+__device__ __forceinline__ unsigned gray_px_f(int r, int g, int b) {   // cv2 RGB2GRAY, 14-bit fixed point (lf_augment.hip)
+    return (unsigned)(r * 4899 + g * 9617 + b * 1868 + 8192) >> 14;
+}
+
+// Canny's non-maximum suppression + double threshold on a gray plane in LDS: map = 1 (no edge), 0 (weak),
+// 2 (strong).  L1: |dx| + |dy| (cv2.Canny default), else dx^2 + dy^2 against squared thresholds.  The gradient of a
+// neighbour is recomputed from the plane (8 LDS bytes) instead of being read from a 4-byte plane in memory.
+template <bool L1>
+__device__ __forceinline__ void canny_nms_lds(const uint8_t* gray, uint8_t* emap, int h, int w, int low, int high) {
+    const int hw = h * w;
+    auto sob = [&](int y, int x) -> Sob {
+        return sobel_at(gray, w, clampi(y - 1, 0, h - 1), y, clampi(y + 1, 0, h - 1), clampi(x - 1, 0, w - 1), x,
+                        clampi(x + 1, 0, w - 1));
+    };
+    auto mag = [&](const Sob s) -> int {
+        return L1 ? (s.dx < 0 ? -s.dx : s.dx) + (s.dy < 0 ? -s.dy : s.dy) : __mul24(s.dx, s.dx) + __mul24(s.dy, s.dy);
+    };
+    auto at = [&](int yy, int xx) -> int {  // the magnitude buffer has a zero frame
+        return (yy < 0 || yy >= h || xx < 0 || xx >= w) ? 0 : mag(sob(yy, xx));
+    };
+    const float inv_w = 1.0f / (float)w;
+    for (int p = threadIdx.x; p < hw; p += kFuseT) {
+        int y = (int)((float)p * inv_w);
+        int x = p - __mul24(y, w);
+        if (x < 0) { --y; x += w; } else if (x >= w) { ++y; x -= w; }
+        const Sob s = sob(y, x);
+        const int m = mag(s);
+        uint8_t out = 1;
+        if (m > low) {
+            const int xs = s.dx, ys = s.dy;
+            const int ax = xs < 0 ? -xs : xs;
+            const int ay = (ys < 0 ? -ys : ys) << 15;
+            const int tg22x = __mul24(ax, 13573);  // tan(22.5 deg) in 15-bit fixed point
+            bool keep;
+            if (ay < tg22x) {
+                keep = m > at(y, x - 1) && m >= at(y, x + 1);
+            } else {
+                const int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) {
+                    keep = m > at(y - 1, x) && m >= at(y + 1, x);
+                } else {
+                    const int sg = (xs ^ ys) < 0 ? 1 : -1;
+                    keep = m > at(y - 1, x - sg) && m > at(y + 1, x + sg);
+                }
+            }
+            if (keep) out = m > high ? 2 : 0;
+        }
+        emap[p] = out;
+    }
+    __syncthreads();
+}
+
+// Hysteresis on the map in LDS (1 = no edge, 0 = weak, 2 = strong; 2 = edge afterwards): a weak pixel with a strong
+// 8-neighbour becomes strong, until nothing changes.  On bit planes — strong bits S, weak bits W, one 32-pixel word
+// per thread and sweep: S |= W & dilate3x3(S) — instead of one pixel per thread with nine byte reads: a sweep over a
+// 224 x 224 map is 1,792 words, and noisy images need dozens of sweeps (the byte sweeps were most of the fused
+// kernels' time: 0.4 ms per image).  Rows are `wpr` words wide (two per 64-pixel segment, as the ballots deliver them).
+__device__ __forceinline__ void canny_hysteresis_lds(uint8_t* m, unsigned* sb, unsigned* wb, int h, int w, int wpr,
+                                                     int* changed) {
+    const int spr = wpr / 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int seg = wv; seg < h * spr; seg += kFuseT / 64) {
+        const int y = seg / spr, sx = seg - y * spr, x = sx * 64 + lane;
+        const uint8_t v = x < w ? m[y * w + x] : 1;
+        const unsigned long long s = __ballot(v == 2), wk = __ballot(v == 0);
+        if (lane == 0) {
+            sb[y * wpr + 2 * sx] = (unsigned)s;
+            sb[y * wpr + 2 * sx + 1] = (unsigned)(s >> 32);
+            wb[y * wpr + 2 * sx] = (unsigned)wk;
+            wb[y * wpr + 2 * sx + 1] = (unsigned)(wk >> 32);
+        }
+    }
+    do {
+        __syncthreads();
+        if (threadIdx.x == 0) *changed = 0;
+        __syncthreads();
+        bool any = false;
+        for (int i = threadIdx.x; i < h * wpr; i += kFuseT) {
+            const unsigned weak = wb[i] & ~sb[i];
+            if (weak == 0u) continue;
+            const int y = i / wpr, xw = i - y * wpr;
+            unsigned nb = 0;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= h) continue;
+                const unsigned* row = sb + yy * wpr;
+                const unsigned c = row[xw], pv = xw > 0 ? row[xw - 1] : 0u, nx = xw < wpr - 1 ? row[xw + 1] : 0u;
+                nb |= c | (c << 1) | (pv >> 31) | (c >> 1) | (nx << 31);
+            }
+            const unsigned grow = weak & nb;   // (bits past column w are never weak)
+            if (grow) {
+                sb[i] |= grow;                 // in place: growth is monotone, the fixed point is the same
+                any = true;
+            }
+        }
+        if (any) *changed = 1;
+        __syncthreads();
+    } while (*changed);
+    for (int seg = wv; seg < h * spr; seg += kFuseT / 64) {
+        const int y = seg / spr, sx = seg - y * spr, x = sx * 64 + lane;
+        if (x < w) m[y * w + x] = (sb[y * wpr + (x >> 5)] >> (x & 31) & 1u) ? 2 : 1;
+    }
+    __syncthreads();
+}
+
+// min / max of non-negative floats over the workgroup (bit patterns, as MinMax does), result in lohi[0..1]
+__device__ __forceinline__ void minmax_block(MinMax r, unsigned* wscratch, unsigned* lohi) {
+    unsigned lo = r.lo, hi = r.hi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64));
+    }
+    __syncthreads();   // wscratch may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) {
+        wscratch[2 * (threadIdx.x >> 6)] = lo;
+        wscratch[2 * (threadIdx.x >> 6) + 1] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kFuseT / 64; ++k) {
+            lo = min(lo, wscratch[2 * k]);
+            hi = max(hi, wscratch[2 * k + 1]);
+        }
+        lohi[0] = lo;
+        lohi[1] = hi;
+    }
+    __syncthreads();
+}
+
+// One workgroup per image: gray plane, Canny (L2 gradient, 50 / 150), brown regions (closed, dilated twice), the
+// three normalisations and the weighted sum of blur.py:30-66 -> the normalised saliency plane (uint8) in `nsal`.
+// rgb / blurred: [n][h][w][3]; leaf: [n][h][w]; w % 4 == 0.
+__global__ __launch_bounds__(kFuseT) void saliency_fused_kernel(const uint8_t* __restrict__ rgb,
+                                                                const uint8_t* __restrict__ blurred,
+                                                                const uint8_t* __restrict__ leaf,
+                                                                uint8_t* __restrict__ nsal, int h, int w, int use_brown,
+                                                                int hue_lo, int hue_hi, int s_min, int v_max) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
+    __shared__ int sdiv[256], hdiv[256];
+    __shared__ unsigned wscratch[2 * (kFuseT / 64)];
+    __shared__ unsigned mm[6];
+    __shared__ float coef[6];
+    __shared__ int changed;
+    const int hw = h * w, plane = (hw + 15) & ~15;
+    const int spr = (w + 63) / 64, wpr = 2 * spr;      // 64-pixel segments / 32-bit words per bit row
+    uint8_t* gray = fl;
+    uint8_t* emap = fl + plane;
+    unsigned* ba = reinterpret_cast<unsigned*>(fl + 2 * plane);
+    unsigned* bb = ba + h * wpr;
+    unsigned* hs = bb + h * wpr;   // hysteresis: strong / weak bit planes (bb is free until the brown morphology)
+    const size_t n = blockIdx.x;
+    const uint8_t* src = rgb + n * (size_t)hw * 3;
+    const uint8_t* blr = blurred + n * (size_t)hw * 3;
+    const uint8_t* lf_ = leaf + n * (size_t)hw;
+    for (int i = threadIdx.x; i < 256; i += kFuseT) {
+        sdiv[i] = i ? __double2int_rn(__ddiv_rn(1044480.0, (double)i)) : 0;
+        hdiv[i] = i ? __double2int_rn(__ddiv_rn(737280.0, __dmul_rn(6.0, (double)i))) : 0;
+    }
+    __syncthreads();
+    // ---- pass 1: gray plane; brown_regions of blur.py:47-53 as one bit per pixel (a wave = 64 pixels of a row)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int seg = wv; seg < h * spr; seg += kFuseT / 64) {
+            const int y = seg / spr, sx = seg - y * spr, x = sx * 64 + lane;
+            bool brown = false;
+            if (x < w) {
+                const int p = y * w + x;
+                const int r = src[3 * p], g = src[3 * p + 1], b = src[3 * p + 2];
+                gray[p] = (uint8_t)gray_px_f(r, g, b);
+                if (use_brown) {
+                    const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
+                    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+                    const int s = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
+                    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+                    hh = (__mul24(hh, hdiv[diff]) + (1 << 11)) >> 12;
+                    hh += hh < 0 ? 180 : 0;
+                    brown = hh >= hue_lo && hh <= hue_hi && s >= s_min && v <= v_max && lf_[p] > 0;
+                }
+            }
+            const unsigned long long m = __ballot(brown);
+            if (lane == 0) {
+                ba[y * wpr + 2 * sx] = (unsigned)m;
+                ba[y * wpr + 2 * sx + 1] = (unsigned)(m >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- Canny(gray, 50, 150, L2gradient=True): thresholds compared squared; edges = (emap == 2)
+    canny_nms_lds<false>(gray, emap, h, w, 50 * 50, 150 * 150);
+    canny_hysteresis_lds(emap, hs, bb, h, w, wpr, &changed);
+    // ---- brown: MORPH_CLOSE with the 3x3 ellipse (a plus), then dilate twice
+    if (use_brown) {
+        morph_bits<3, false>(ba, bb, h, w, wpr);
+        morph_bits<3, true>(bb, ba, h, w, wpr);
+        morph_bits<3, false>(ba, bb, h, w, wpr);
+        morph_bits<3, false>(bb, ba, h, w, wpr);
+    }
+    const float inv_w = 1.0f / (float)w;
+    auto rowcol = [&](int p, int& y, int& x) {
+        y = (int)((float)p * inv_w);
+        x = p - __mul24(y, w);
+        if (x < 0) { --y; x += w; } else if (x >= w) { ++y; x -= w; }
+    };
+    // cv2.Sobel + cv2.magnitude (BORDER_REFLECT_101), float32 sqrt of an exact integer
+    auto gmag_at = [&](int y, int x) -> float {
+        const Sob r = sobel_at(gray, w, reflect101i(y - 1, h), y, reflect101i(y + 1, h), reflect101i(x - 1, w), x,
+                               reflect101i(x + 1, w));
+        return __fsqrt_rn((float)(__mul24(r.dx, r.dx) + __mul24(r.dy, r.dy)));
+    };
+    // ---- pass 2: min / max of the gradient magnitude
+    {
+        MinMax r;
+        for (int p = threadIdx.x; p < hw; p += kFuseT) {
+            int y, x;
+            rowcol(p, y, x);
+            r.take(gmag_at(y, x));
+        }
+        minmax_block(r, wscratch, mm + 0);
+    }
+    // mean over channels of |rgb - blurred| as numpy float32 computes it: four pixels (three dwords of each image)
+    auto cdiff4 = [&](int q, float* out) {
+        const uint32_t* a = reinterpret_cast<const uint32_t*>(src) + 3 * q;
+        const uint32_t* b = reinterpret_cast<const uint32_t*>(blr) + 3 * q;
+        const unsigned av[3] = {a[0], a[1], a[2]}, bv[3] = {b[0], b[1], b[2]};
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int d = (int)((av[j >> 2] >> (8 * (j & 3))) & 0xffu) - (int)((bv[j >> 2] >> (8 * (j & 3))) & 0xffu);
+            acc[j / 3] += d < 0 ? -d : d;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = __fdiv_rn((float)acc[k], 3.0f);
+    };
+    // ---- pass 3: min / max of the colour difference
+    {
+        MinMax r;
+        for (int q = threadIdx.x; q < hw / 4; q += kFuseT) {
+            float v[4];
+            cdiff4(q, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.take(v[k]);
+        }
+        minmax_block(r, wscratch, mm + 2);
+    }
+    if (threadIdx.x == 0) {
+        norm_coeffs(mm[0], mm[1], coef[0], coef[1]);
+        norm_coeffs(mm[2], mm[3], coef[2], coef[3]);
+    }
+    __syncthreads();
+    // saliency = 0.4 dilate(edges) + 0.3 uint8(norm(gradient)) + 0.6 brown + 0.2 norm(colour diff): each product and
+    // sum rounded to float32 in blur.py's order (saliency_kernel above)
+    const float ga = coef[0], gb = coef[1], ca = coef[2], cb = coef[3];
+    auto sal4 = [&](int q, float* out) {
+        float cd[4];
+        cdiff4(q, cd);
+        int y, x;
+        rowcol(4 * q, y, x);   // w % 4 == 0: the four pixels share a row
+#pragma unroll
+        for (int k = 0; k < 4; ++k, ++x) {
+            const int p = 4 * q + k;
+            const bool e = emap[p] == 2 || (x > 0 && emap[p - 1] == 2) || (x < w - 1 && emap[p + 1] == 2) ||
+                           (y > 0 && emap[p - w] == 2) || (y < h - 1 && emap[p + w] == 2);
+            float sv = (e ? 255.0f : 0.0f) * 0.4f;
+            sv = sv + (float)trunc_u8(__fmaf_rn(gmag_at(y, x), ga, gb)) * 0.3f;
+            if (use_brown) sv = sv + ((ba[y * wpr + (x >> 5)] >> (x & 31) & 1u) ? 255.0f : 0.0f) * 0.6f;
+            sv = sv + __fmaf_rn(cd[k], ca, cb) * 0.2f;
+            out[k] = sv;
+        }
+    };
+    // ---- pass 4: min / max of the saliency
+    {
+        MinMax r;
+        for (int q = threadIdx.x; q < hw / 4; q += kFuseT) {
+            float v[4];
+            sal4(q, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.take(v[k]);
+        }
+        minmax_block(r, wscratch, mm + 4);
+    }
+    if (threadIdx.x == 0) norm_coeffs(mm[4], mm[5], coef[4], coef[5]);
+    __syncthreads();
+    // ---- pass 5: the normalised saliency plane
+    const float na = coef[4], nb = coef[5];
+    uint32_t* dst = reinterpret_cast<uint32_t*>(nsal + n * (size_t)hw);
+    for (int q = threadIdx.x; q < hw / 4; q += kFuseT) {
+        float v[4];
+        sal4(q, v);
+        unsigned o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o |= (unsigned)trunc_u8(__fmaf_rn(v[k], na, nb)) << (8 * k);
+        dst[q] = o;
+    }
+}
+
+// gray plane (from memory) -> Canny (L1 gradient, 30 / 100) in LDS -> the per-pixel predicates of
+// _create_inclusive_mask (inclusive_pred_kernel above, expression for expression) -> one bit per pixel.
+__global__ __launch_bounds__(kFuseT) void inclusive_fused_kernel(
+    const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ gray_g, const uint8_t* __restrict__ blur,
+    const uint16_t* __restrict__ lab_tabs, uint32_t* __restrict__ bits, int h, int w, int hue_lo, int hue_hi) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
+    __shared__ int sdiv[256], hdiv[256];
+    __shared__ uint16_t gam[256], cbr[kLabCbrtSize];
+    __shared__ int changed;
+    const int hw = h * w, plane = (hw + 15) & ~15;
+    uint8_t* gray = fl;
+    uint8_t* emap = fl + plane;
+    const size_t n = blockIdx.x;
+    for (int i = threadIdx.x; i < 256; i += kFuseT) {
+        sdiv[i] = i ? __double2int_rn(__ddiv_rn(1044480.0, (double)i)) : 0;
+        hdiv[i] = i ? __double2int_rn(__ddiv_rn(737280.0, __dmul_rn(6.0, (double)i))) : 0;
+        gam[i] = lab_tabs[i];
+    }
+    for (int i = threadIdx.x; i < kLabCbrtSize; i += kFuseT) cbr[i] = lab_tabs[256 + i];
+    {
+        const uint32_t* g4 = reinterpret_cast<const uint32_t*>(gray_g + n * (size_t)hw);   // hw % 4 == 0
+        for (int q = threadIdx.x; q < hw / 4; q += kFuseT) reinterpret_cast<uint32_t*>(gray)[q] = g4[q];
+    }
+    __syncthreads();
+    const int spr = (w + 63) / 64, wpr = 2 * spr;
+    canny_nms_lds<true>(gray, emap, h, w, 30, 100);   // cv2.Canny(gray, 30, 100)
+    {
+        unsigned* hs = reinterpret_cast<unsigned*>(fl + 2 * plane);
+        canny_hysteresis_lds(emap, hs, hs + h * wpr, h, w, wpr, &changed);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint8_t* src = rgb + n * (size_t)hw * 3;
+    const uint8_t* bl = blur + n * (size_t)hw;
+    for (int seg = wv; seg < h * spr; seg += kFuseT / 64) {
+        const int y = seg / spr, sx = seg - y * spr, x = sx * 64 + lane;
+        bool plant = false;
+        if (x < w) {
+            const int q = y * w + x;
+            const int r = src[3 * q], g = src[3 * q + 1], b = src[3 * q + 2];
+            const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
+            const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+            const int s = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
+            int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+            hh = (__mul24(hh, hdiv[diff]) + (1 << 11)) >> 12;
+            hh += hh < 0 ? 180 : 0;
+            const int R = gam[r], G = gam[g], B = gam[b];
+            const int fx = cbr[(R * 1777 + G * 1541 + B * 778 + 2048) >> 12];
+            const int fy = cbr[(R * 871 + G * 2929 + B * 296 + 2048) >> 12];
+            const int fz = cbr[(R * 73 + G * 448 + B * 3575 + 2048) >> 12];
+            const int L = clampi((296 * fy - 1336934 + 16384) >> 15, 0, 255);
+            const int la = clampi((500 * (fx - fy) + 4194304 + 16384) >> 15, 0, 255);
+            const int lb = clampi((200 * (fy - fz) + 4194304 + 16384) >> 15, 0, 255);
+            const bool strong_green = hh >= hue_lo && hh <= hue_hi && s >= 30 && v >= 30;
+            const bool dominant = g > ((r + 15) & 255) || g > ((b + 15) & 255) ||
+                                  (g > ((r + 5) & 255) && g > ((b + 5) & 255) && s >= 20);
+            const bool lab_green = la <= 125 && lb >= 120 && L >= 20 && L <= 240;
+            const bool edge = emap[q] == 2 || (x > 0 && emap[q - 1] == 2) || (x < w - 1 && emap[q + 1] == 2) ||
+                              (y > 0 && emap[q - w] == 2) || (y < h - 1 && emap[q + w] == 2);
+            const int tex = (int)gray[q] - (int)bl[q];
+            const bool background = (s <= 25 && v >= 50 && v <= 220) ||
+                                    (hh >= 120 && hh <= 160 && s >= 20 && r > g && b > g) ||
+                                    (s <= 15 && (tex < 0 ? -tex : tex) < 10);
+            plant = (strong_green || dominant || lab_green || edge) && !background;
+        }
+        const unsigned long long m = __ballot(plant);
+        if (lane == 0) {
+            uint32_t* o = bits + ((n * h + y) * (size_t)wpr + 2 * sx);
+            o[0] = (unsigned)m;
+            o[1] = (unsigned)(m >> 32);
+        }
+    }
+}
+
+// dynamic LDS of the two kernels above, or 0 when an image does not fit a CU (the multi-launch chains then run)
+static size_t fused_lds_bytes(int h, int w, bool with_bits) {
+    if (w % 4 != 0 || h < 1) return 0;
+    const size_t plane = ((size_t)h * w + 15) & ~(size_t)15;
+    const size_t wpr = 2 * (size_t)((w + 63) / 64);
+    const size_t need = 2 * plane + (with_bits ? 3 : 2) * (size_t)h * wpr * 4;   // + strong / weak (/ brown) bit planes
+    return need <= (size_t)140 * 1024 ? need : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -705,8 +1097,26 @@ int lf_blur_saliency_u8(const uint8_t* rgb, const uint8_t* leaf_mask, uint8_t* o
 
     const dim3 grid_px((hw + kBlock - 1) / kBlock, n);
     const dim3 grid_fat((hw + kBlock * kPxPerThread - 1) / (kBlock * kPxPerThread), n);
+    int rc;
+    // images that fit a CU (two byte planes + the brown bit planes in LDS; 224 x 224 does): the 15 x 15 blur, ONE
+    // workgroup per image for everything up to the normalised saliency plane, the 5 x 5 blur, the masking pass
+    if (const size_t fl = fused_lds_bytes(h, w, true)) {
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(saliency_fused_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) == hipSuccess;
+        if (ok) {
+            rc = lf_gauss_blur_u8(rgb, blurred, n, h, w, 3, kq15, 15, stream);
+            if (rc != LF_OK) return rc;
+            saliency_fused_kernel<<<n, kFuseT, fl, s>>>(rgb, blurred, leaf_mask, pa, h, w, use_brown, hue_lo, hue_hi,
+                                                        s_min, v_max);
+            rc = lf_gauss_blur_u8(pa, pb, n, h, w, 1, kq5, 5, stream);
+            if (rc != LF_OK) return rc;
+            saliency_out_kernel<<<lf::stream_grid(px / 4 + 1, kBlock, lf::kFullGrid), kBlock, 0, s>>>(pb, leaf_mask,
+                                                                                                   out, px);
+            return lf::check_launch("lf_blur_saliency");
+        }
+    }
     minmax_init_kernel<<<(n * 6 + 255) / 256, 256, 0, s>>>(mm, n);
-    int rc = lf_rgb2gray_u8(rgb, pa, px, stream);
+    rc = lf_rgb2gray_u8(rgb, pa, px, stream);
     if (rc != LF_OK) return rc;
     sal_sobel_kernel<<<grid_fat, kBlock, 0, s>>>(pa, mag2, dxdy, gmag, mm, h, w);
     // cv2.Canny(gray, 50, 150, L2gradient=True): thresholds are compared squared
@@ -846,6 +1256,18 @@ int lf_inclusive_mask_u8(const uint8_t* rgb, uint8_t* mask, int n, int h, int w,
     if (rc != LF_OK) return rc;
     rc = lf_gauss_blur_u8(gray, blur, n, h, w, 1, kq15, 15, stream);
     if (rc != LF_OK) return rc;
+    if (const size_t fl = fused_lds_bytes(h, w, false)) {
+        // the image fits a CU: Canny and the predicates in one workgroup per image, gray plane and map in LDS
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(inclusive_fused_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) == hipSuccess;
+        if (ok) {
+            inclusive_fused_kernel<<<n, kFuseT, fl, s>>>(rgb, gray, blur, tabs, bits, h, w, std::max(0, green_lo - 10),
+                                                         std::min(179, green_hi + 15));
+            inclusive_morph_kernel<<<n, kBlock, lds, s>>>(bits, mask, rn, parent, area, h, w, wpr,
+                                                          (int)mask_runs_per_image(h, w));
+            return lf::check_launch("lf_inclusive_mask");
+        }
+    }
     const dim3 grid_px((hw + kBlock - 1) / kBlock, n);
     canny_sobel_l1_kernel<<<grid_px, kBlock, 0, s>>>(gray, mag, dxdy, h, w);
     canny_nms_kernel<<<grid_px, kBlock, 0, s>>>(mag, dxdy, map, h, w, 30, 100);   // cv2.Canny(gray, 30, 100)

@@ -4,6 +4,8 @@
 // operation order as libImaging/Geometry.c; this file is compiled with
 // -ffp-contract=off so that no multiply-add is fused (a fused FMA rounds once where C
 // rounds twice and would break bit-exactness).  The resampler is pure integer.
+#include <algorithm>
+
 #include "lf_common.h"
 
 namespace {
@@ -337,6 +339,83 @@ __global__ __launch_bounds__(kBlock) void affine_nearest_kernel(const uint8_t* _
     }
 }
 
+// The same transform for source images that fit a CU's LDS (224 x 224 x 3 = 147 KB does): one workgroup per image
+// copies the whole source into LDS with aligned 16-byte loads — every source byte crosses the memory pipe ONCE, as
+// part of a full line — and the per-pixel gathers go to LDS.  The global-memory version above issues one unaligned
+// 4-byte gather per output pixel and is bound by the texture addresser (TA_BUSY 80 %, 2.25x the algorithmic bytes
+// before the XCD-aware block order); here the vector memory pipe only sees the streaming copy in and the coalesced
+// dword stores out.  Same arithmetic, same bytes (tests compare both with the oracle).
+constexpr int kRotT = 1024;
+
+__global__ __launch_bounds__(kRotT) void affine_nearest_lds_kernel(const uint8_t* __restrict__ in,
+                                                                   uint8_t* __restrict__ out,
+                                                                   const int32_t* __restrict__ fix6,
+                                                                   const int32_t* __restrict__ ohw,
+                                                                   const int64_t* __restrict__ out_off, int n_images,
+                                                                   int h, int w, unsigned fill) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t simg[];
+    const int nbytes = h * w * 3;   // a multiple of 16 (checked on the host)
+    for (int n = blockIdx.x; n < n_images; n += gridDim.x) {
+        const lf::u32x4* s16 = reinterpret_cast<const lf::u32x4*>(in + (size_t)n * nbytes);
+        __syncthreads();   // the previous image's gathers are done
+        for (int i = threadIdx.x; i < nbytes / 16; i += kRotT) reinterpret_cast<lf::u32x4*>(simg)[i] = s16[i];
+        const int32_t* a = fix6 + (size_t)n * 6;
+        const unsigned a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
+        const int oh = ohw[2 * n], ow = ohw[2 * n + 1];
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out + out_off[n]);
+        const int total = oh * ow;            // pixels
+        const int nd = (total * 3 + 3) / 4;   // dwords that hold at least one pixel byte
+        const int ng = (total + 3) / 4;       // groups of four pixels
+        const bool small = total < (1 << 22);
+        const float inv_ow = 1.0f / (float)ow;
+        __syncthreads();
+        for (int g = threadIdx.x; g < ng; g += kRotT) {
+            const int p0 = 4 * g;
+            unsigned oy, ox;
+            if (small) {
+                oy = (unsigned)((float)p0 * inv_ow);
+                int rem = p0 - __mul24((int)oy, ow);
+                if (rem < 0) {
+                    --oy;
+                    rem += ow;
+                } else if (rem >= ow) {
+                    ++oy;
+                    rem -= ow;
+                }
+                ox = (unsigned)rem;
+            } else {
+                oy = (unsigned)p0 / (unsigned)ow;
+                ox = (unsigned)p0 - oy * (unsigned)ow;
+            }
+            unsigned xx = a2 + a1 * oy + a0 * ox, yy = a5 + a4 * oy + a3 * ox;
+            unsigned px[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned v = fill * 0x010101u;
+                const int xin = (int)xx >> 16, yin = (int)yy >> 16;
+                if (p0 + k < total && xin >= 0 && xin < w && yin >= 0 && yin < h) {
+                    const uint8_t* sp = simg + (unsigned)(__mul24(yin, w) + xin) * 3u;
+                    v = sp[0] | sp[1] << 8 | sp[2] << 16;
+                }
+                px[k] = v;
+                if (++ox == (unsigned)ow) {
+                    ox = 0;
+                    ++oy;
+                    xx = a2 + a1 * oy;
+                    yy = a5 + a4 * oy;
+                } else {
+                    xx += a0;
+                    yy += a3;
+                }
+            }
+            const int d0 = 3 * g;
+            if (d0 < nd) dst[d0] = px[0] | px[1] << 24;
+            if (d0 + 1 < nd) dst[d0 + 1] = px[1] >> 8 | px[2] << 16;
+            if (d0 + 2 < nd) dst[d0 + 2] = px[2] >> 16 | px[3] << 8;
+        }
+    }
+}
+
 // Resample.c ImagingResampleHorizontal_8bpc / Vertical_8bpc: ss = 1<<21 + sum px*k; clip8(ss>>22).
 constexpr int kPrec = 22;
 
@@ -654,6 +733,18 @@ int lf_affine_nearest_fixed_u8(const uint8_t* in, uint8_t* out, const int32_t* f
                max_out_pixels);
     LF_REQUIRE(h < 32768 && w < 32768, "lf_affine_nearest_fixed: 16.16 fixed point needs sizes < 32768");
     LF_REQUIRE(fill >= 0 && fill <= 255, "lf_affine_nearest_fixed: fill must be 0..255");
+    const size_t nbytes = (size_t)h * w * 3;
+    if (nbytes <= (size_t)152 * 1024 && nbytes % 16 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0) {
+        // the source image fits a CU's LDS: one workgroup per image, source staged once (see the kernel)
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(affine_nearest_lds_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) == hipSuccess;
+        if (ok) {
+            const unsigned wgs = (unsigned)std::min<size_t>((size_t)n, (size_t)256 * 4);
+            affine_nearest_lds_kernel<<<wgs, kRotT, nbytes, lf::as_stream(stream)>>>(in, out, fix6, ohw, out_off, n, h, w,
+                                                                                   (unsigned)fill);
+            return lf::check_launch("lf_affine_nearest_fixed");
+        }
+    }
     dim3 grid(lf::stream_grid(((size_t)max_out_pixels + 3) / 4, kBlock, 1024), n);
     affine_nearest_kernel<<<grid, kBlock, 0, lf::as_stream(stream)>>>(in, out, fix6, ohw, out_off, h,
                                                                       w, (unsigned)fill);

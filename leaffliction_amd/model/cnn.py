@@ -499,23 +499,26 @@ class LeafCNN:
         self._saved = sv
         return probs, loss
 
-    def _backward_bf16(self) -> None:
-        """Fills flat_g (fp32) from the tensors of the last _forward_train_bf16."""
+    def _backward_bf16(self, part: Optional[int] = None) -> None:
+        """Fills flat_g (fp32) from the tensors of the last _forward_train_bf16.  part: see backward()."""
         sv, P, G = self._saved, self.p, self.g
         n = sv["n"]
         bf, F32 = torch.bfloat16, torch.float32
         B = lambda k, shape, dt=bf: self._buf(n, "t16." + k, shape, dt)  # noqa: E731
         f_last = self.widths[-1]
-        dlogits = B("dlogits", (n, self.num_classes), F32)
-        dfeat = B("dfeat", (n, f_last), F32)
-        nn.head_bwd(sv["feat"], P["dense.w"], sv["probs"], sv["y_true"], dlogits, dfeat,
-                    G["dense.w"], G["dense.b"], 1.0 / (self._global_n or n))
-        dg = dfeat
-        if sv["top_drop"] is not None:
-            dg = nn.mul(dfeat, sv["top_drop"], B("dg", dfeat.shape, F32))
-        h, w = sv["last_hw"]
-        dp = nn.bcast_planes_bf16(dg, h, w, 1.0 / (h * w), B("dp_last", (n, f_last, h, w)))
-        for i in reversed(range(len(self.widths))):
+        if part in (None, 0):
+            dlogits = B("dlogits", (n, self.num_classes), F32)
+            dfeat = B("dfeat", (n, f_last), F32)
+            nn.head_bwd(sv["feat"], P["dense.w"], sv["probs"], sv["y_true"], dlogits, dfeat,
+                        G["dense.w"], G["dense.b"], 1.0 / (self._global_n or n))
+            dg = dfeat
+            if sv["top_drop"] is not None:
+                dg = nn.mul(dfeat, sv["top_drop"], B("dg", dfeat.shape, F32))
+            h, w = sv["last_hw"]
+            dp = nn.bcast_planes_bf16(dg, h, w, 1.0 / (h * w), B("dp_last", (n, f_last, h, w)))
+        else:
+            dp = sv["bwd_dp"]
+        for i in self._backward_stages(part):
             f = self.widths[i]
             cin = self.widths[i - 1] if i > 0 else self.widths[0]
             p = f"s{i}."
@@ -562,6 +565,9 @@ class LeafCNN:
             else:
                 nn.conv2d_bf16_train(gB, self._wt["d:" + p + "c1.w"], cin, 3, dx, accumulate=True)
             dp = dx
+        if part == 0:
+            sv["bwd_dp"] = dp   # the gradient that enters stage 0: where part 1 picks up
+            return
         # the stem has no input gradient: its BN backward exists only inside the wgrad kernel
         nn.bn_bwd_wgrad_bf16(sv["x0"], dp, sv["stem.y"], self.stats["stem.bn"], P["stem.bn.gamma"],
                              G["stem.bn.gamma"], G["stem.bn.beta"], True, 3, G["stem.w"], None,
@@ -631,22 +637,46 @@ class LeafCNN:
         return probs, loss
 
     # ------------------------------------------------------------ backward
-    def backward(self) -> None:
-        """Fills flat_g with d(mean data loss)/d(param) for the last training forward."""
+    def _backward_stages(self, part: Optional[int]):
+        """Stage indices a backward pass walks, last stage first.  part None: all of them.  The data-parallel step
+        runs the pass in two parts so that the gradients of the first part cross xGMI while the second computes:
+        part 0 = head and stages >= 1 (98 % of the parameters: everything from `grad_split()` on in the flat
+        bucket), part 1 = stage 0 and the stem (the 224 x 224 layers: a large share of the time, 2 % of the
+        parameters)."""
+        last = len(self.widths) - 1
+        if part is None:
+            return range(last, -1, -1)
+        return range(last, 0, -1) if part == 0 else range(0, -1, -1)
+
+    def grad_split(self) -> int:
+        """Offset in the flat parameter / gradient buffers of the first tensor that does NOT belong to the stem or
+        stage 0: [0, split) is written by backward part 1, [split, n_params) by part 0 (train_step rounds it UP to
+        whole cache lines for the exchange: the few part-0 elements below the rounded offset go with the second
+        piece, by which time they are long complete)."""
+        for (name, _s, _k), off in zip(self.specs, self.offsets.tolist()):
+            if not (name.startswith("stem.") or name.startswith("s0.")):
+                return int(off)
+        return self.n_params
+
+    def backward(self, part: Optional[int] = None) -> None:
+        """Fills flat_g with d(mean data loss)/d(param) for the last training forward (part: _backward_stages)."""
         sv, P, G = self._saved, self.p, self.g
         n = sv["n"]
         B = lambda k, shape: self._buf(n, k, shape)  # noqa: E731
         f_last = self.widths[-1]
-        dlogits = B("dlogits", (n, self.num_classes))
-        dfeat = B("dfeat", (n, f_last))
-        nn.head_bwd(sv["feat"], P["dense.w"], sv["probs"], sv["y_true"], dlogits, dfeat,
-                    G["dense.w"], G["dense.b"], 1.0 / (self._global_n or n))
-        dg = dfeat
-        if sv["top_drop"] is not None:
-            dg = nn.mul(dfeat, sv["top_drop"], B("dg", dfeat.shape))
-        h, w = sv["last_hw"]
-        dp = nn.bcast_planes(dg, h, w, 1.0 / (h * w), out=B("dp_last", (n, f_last, h, w)))
-        for i in reversed(range(len(self.widths))):
+        if part in (None, 0):
+            dlogits = B("dlogits", (n, self.num_classes))
+            dfeat = B("dfeat", (n, f_last))
+            nn.head_bwd(sv["feat"], P["dense.w"], sv["probs"], sv["y_true"], dlogits, dfeat,
+                        G["dense.w"], G["dense.b"], 1.0 / (self._global_n or n))
+            dg = dfeat
+            if sv["top_drop"] is not None:
+                dg = nn.mul(dfeat, sv["top_drop"], B("dg", dfeat.shape))
+            h, w = sv["last_hw"]
+            dp = nn.bcast_planes(dg, h, w, 1.0 / (h * w), out=B("dp_last", (n, f_last, h, w)))
+        else:
+            dp = sv["bwd_dp"]
+        for i in self._backward_stages(part):
             f = self.widths[i]
             cin = self.widths[i - 1] if i > 0 else self.widths[0]
             p = f"s{i}."
@@ -700,6 +730,9 @@ class LeafCNN:
             else:
                 nn.conv2d(gB, self._dgrad_w(p + "c1.w", 3), 3, out=dx, accumulate=True)
             dp = dx
+        if part == 0:
+            sv["bwd_dp"] = dp   # the gradient that enters stage 0: where part 1 picks up
+            return
         # stem: dp is the gradient wrt relu(BN(stem.y))
         # the stem has no input gradient: its BN backward exists only inside the wgrad kernel
         nn.bn_bwd_wgrad(sv["x0"], dp, sv["stem.y"], self.stats["stem.bn"], P["stem.bn.gamma"],
@@ -724,7 +757,7 @@ class LeafCNN:
 
     def train_step(self, x, y_true: Optional[torch.Tensor], lr: float, *, weight_decay: float = 1e-4,
                    clipnorm: float = 0.5, ema_decay: float = 0.999, adamw: bool = True,
-                   grad_sync=None, global_n: Optional[int] = None):
+                   grad_sync=None, global_n: Optional[int] = None, grad_overlap=None):
         """One optimisation step on a batch.  y_true: f32 [N,C] (already label-smoothed).
         grad_sync(flat_g) is called between backward and the optimizer (data-parallel
         all-reduce); with global_n the local gradient is scaled by 1/global_n so that a SUM
@@ -735,11 +768,31 @@ class LeafCNN:
         global batch holds nothing) still takes the step: it contributes a zero gradient to the
         all-reduce and advances `opt_step`, Adam moments, weights and EMA exactly like its peers,
         so every rank issues the same collectives and the replicas stay bit-equal.  Returns
-        (None, None) in that case."""
+        (None, None) in that case.
+
+        grad_overlap (a train.parallel.DataParallel with `overlap` on) replaces grad_sync: the backward pass is run
+        in two parts and the all-reduce of the first part's gradients — head and stages >= 1, 98 % of the bucket —
+        is in flight over xGMI while the second part (stage 0 and the stem, the 224 x 224 layers) computes; the
+        small remainder follows.  Same kernels in the same order on the compute stream, same reductions: the
+        parameters come out bit-equal to the non-overlapped step."""
         self._mut += 1   # parameters and moving statistics change (also when the step is a graph replay)
         n = int(x.shape[0])
         self._global_n = global_n
-        if n == 0:
+        if grad_overlap is not None:
+            # two exchanges, the same two on every rank (a rank with an empty batch sends zeros in both)
+            split = min(self.n_params, -(-self.grad_split() // 64) * 64)   # whole 256-byte lines per piece
+            handles = []
+            if n == 0:
+                self.flat_g.zero_()
+                probs = loss = None
+                handles.append(grad_overlap.allreduce_begin(self.flat_g, split, self.n_params))
+            else:
+                probs, loss = self._forward_backward(x, y_true, between=lambda: handles.append(
+                    grad_overlap.allreduce_begin(self.flat_g, split, self.n_params)))
+            handles.append(grad_overlap.allreduce_begin(self.flat_g, 0, split))
+            grad_overlap.allreduce_finish(self.flat_g, handles)
+            grad_sync = None
+        elif n == 0:
             self.flat_g.zero_()
             probs = loss = None
         else:
@@ -751,8 +804,10 @@ class LeafCNN:
                                ema_decay=ema_decay)
         return probs, loss
 
-    def _forward_backward(self, x, y_true: torch.Tensor):
-        """Forward + backward of one local batch: fills flat_g, returns (probs, loss).
+    def _forward_backward(self, x, y_true: torch.Tensor, between=None):
+        """Forward + backward of one local batch: fills flat_g, returns (probs, loss).  `between`, when given, is
+        called on the host between the two parts of the backward pass (backward()'s `part`): everything of part 0
+        has been issued to the stream by then, nothing of part 1.
 
         The ~250 launches of a step are recorded once per (batch shape, precision) into a HIP graph
         and replayed (the host would otherwise spend 3-6 ms per step issuing them, a fifth of the
@@ -762,12 +817,13 @@ class LeafCNN:
         changes every step) and the gradient all-reduce stay outside.  LEAFFLICTION_GRAPH=0 turns
         this off."""
         if self._graphs_on and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.uint8:
-            return self._forward_backward_graph(x, y_true)
-        return self._forward_backward_eager(x, y_true)
+            return self._forward_backward_graph(x, y_true, between)
+        return self._forward_backward_eager(x, y_true, between)
 
-    def _forward_backward_graph(self, x: torch.Tensor, y_true: torch.Tensor):
+    def _forward_backward_graph(self, x: torch.Tensor, y_true: torch.Tensor, between=None):
         n = int(x.shape[0])
-        key = (tuple(x.shape), self.train_dtype, self.augment, self._global_n, tuple(y_true.shape))
+        key = (tuple(x.shape), self.train_dtype, self.augment, self._global_n, tuple(y_true.shape),
+               between is not None)
         st = self._graphs.get(key)
         if st is None:
             st = self._graphs[key] = {"calls": 0, "graph": None}
@@ -778,7 +834,7 @@ class LeafCNN:
             # Drop it and record the step again (this call runs eagerly on the current buffers).
             st["graph"], st["calls"] = None, 2
         if st["graph"] is None and st["calls"] <= 2:
-            return self._forward_backward_eager(x, y_true)
+            return self._forward_backward_eager(x, y_true, between)
         drops, top, aug4 = self.draw_step_randoms(n, self.augment)  # fixed device views, fresh values
         if st["graph"] is None:
             st["x"] = torch.empty_like(x)
@@ -787,36 +843,58 @@ class LeafCNN:
             st["y"].copy_(y_true)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            g2 = torch.cuda.CUDAGraph() if between is not None else None
             try:
+                # with `between`: two graphs out of one memory pool, cut where the host may start the first exchange
                 with torch.cuda.graph(g):
-                    st["out"] = self._forward_backward_body(st["x"], st["y"], drops, top, aug4)
+                    st["out"] = self._forward_backward_body(st["x"], st["y"], drops, top, aug4,
+                                                            part=None if between is None else 0)
+                if g2 is not None:
+                    with torch.cuda.graph(g2, pool=g.pool()):
+                        self._forward_backward_body(st["x"], st["y"], drops, top, aug4, part=1)
             except Exception:
                 self._graphs_on = False   # capture is an optimisation: fall back to eager launches
                 torch.cuda.synchronize()
-                return self._forward_backward_body(x, y_true, drops, top, aug4)
-            st["graph"] = g
+                return self._forward_backward_split(x, y_true, drops, top, aug4, between)
+            st["graph"], st["graph2"] = g, g2
             st["ws_gen"] = nn.workspace_generation()
         else:
             st["x"].copy_(x)
             st["y"].copy_(y_true)
         st["graph"].replay()
+        if between is not None:
+            between()
+            st["graph2"].replay()
         return st["out"]
 
-    def _forward_backward_eager(self, x, y_true: torch.Tensor):
+    def _forward_backward_eager(self, x, y_true: torch.Tensor, between=None):
         n = int(x.shape[0])
         drops, top, aug4 = self.draw_step_randoms(n, self.augment)
-        return self._forward_backward_body(x, y_true, drops, top, aug4)
+        return self._forward_backward_split(x, y_true, drops, top, aug4, between)
 
-    def _forward_backward_body(self, x, y_true, drops, top, aug4):
+    def _forward_backward_split(self, x, y_true, drops, top, aug4, between):
+        if between is None:
+            return self._forward_backward_body(x, y_true, drops, top, aug4)
+        out = self._forward_backward_body(x, y_true, drops, top, aug4, part=0)
+        between()
+        self._forward_backward_body(x, y_true, drops, top, aug4, part=1)
+        return out
+
+    def _forward_backward_body(self, x, y_true, drops, top, aug4, part: Optional[int] = None):
+        """part None: forward + the whole backward pass; 0: forward + backward part 0; 1: backward part 1."""
+        bf16 = self.train_dtype == "bf16"
+        if part == 1:
+            self._backward_bf16(1) if bf16 else self.backward(1)
+            return None
         x0 = self._input(x, True, aug4)
-        if self.train_dtype == "bf16":
+        if bf16:
             if not (self.use_se and self._bf16_storage_ok(x0.shape[2], x0.shape[3])):
                 raise ValueError("bf16 training: unsupported shape (see set_training_dtype)")
             probs, loss = self._forward_train_bf16(x0, y_true, drops, top)
-            self._backward_bf16()
+            self._backward_bf16(part)
         else:
             probs, loss = self.forward(x0, True, y_true, drops, top)
-            self.backward()
+            self.backward(part)
         return probs, loss
 
     def _optimizer_update(self, lr: float, *, weight_decay: float, clipnorm: float,
@@ -911,7 +989,8 @@ class LeafCNN:
                     bx, yt, lr, weight_decay=opt.get("weight_decay", 0.0),
                     clipnorm=opt.get("clipnorm", 0.0), ema_decay=opt.get("ema_decay", 0.0),
                     adamw=opt.get("name", "adamw") == "adamw",
-                    grad_sync=dp.allreduce_grads if dp_on else None, global_n=gn)
+                    grad_sync=dp.allreduce_grads if dp_on else None, global_n=gn,
+                    grad_overlap=dp if dp_on and getattr(dp, "overlap", False) else None)
                 if n_local:
                     acc_loss += loss.sum()
                     acc_correct += (probs.argmax(-1) == idx).sum()

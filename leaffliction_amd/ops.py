@@ -151,6 +151,33 @@ def noise_philox_add_u8(x: torch.Tensor, seed: int, sigma: float = 5.0) -> torch
     return out
 
 
+def noise_hist_u8(x: torch.Tensor, add: Optional[torch.Tensor] = None, seed: int = 0, sigma: float = 5.0):
+    """(x + noise mod 256, its per-channel histograms [N,3,256]) in one pass over the batch: `add` is the uint8 noise
+    plane (add_wrap_u8's), or None for the device-drawn Philox noise of noise_philox_add_u8 (same seed, same bytes).
+    Falls back to the two separate kernels when an image is not a multiple of 16 bytes."""
+    n, h, w = _hwc(x, "noise_hist.x")
+    if add is not None:
+        _chk(add, _U8, "noise_hist.add")
+        if add.shape != x.shape:
+            raise ValueError("noise_hist.add: same shape as the batch")
+    if (h * w * 3) % 16 or x.data_ptr() % 16 or (add is not None and add.data_ptr() % 16):
+        y = add_wrap_u8(x, add) if add is not None else noise_philox_add_u8(x, seed, sigma)
+        return y, hist_u8(y)
+    out = torch.empty_like(x)
+    hist = torch.empty((n, 3, 256), dtype=_I32, device=x.device)
+    _lib.call("lf_noise_hist_u8", x.data_ptr(), None if add is None else add.data_ptr(), out.data_ptr(),
+              hist.data_ptr(), n, h, w, int(seed) & (2**64 - 1), float(sigma), _stream())
+    return out, hist
+
+
+def distortion_u8(x: torch.Tensor, cutoff: torch.Tensor, add: Optional[torch.Tensor] = None, seed: int = 0,
+                  sigma: float = 5.0) -> torch.Tensor:
+    """ImageAugmenter.distortion on a batch (image_augmenter.py:121-131): noise add (+ histogram in the same pass),
+    autocontrast LUT, LUT apply — four image passes."""
+    y, hist = noise_hist_u8(x, add, seed, sigma)
+    return lut_apply_u8(y, autocontrast_lut(hist, cutoff))
+
+
 def mask_composite_u8(img: torch.Tensor, mask: torch.Tensor, mask_color: str = "white"):
     """apply_mask: out = mask > 127 ? img : (255 if white else 0)."""
     if mask_color.upper() == "WHITE":
@@ -342,14 +369,23 @@ def warp_bicubic_u8(x: torch.Tensor, coeffs: torch.Tensor, perspective: bool,
     return out
 
 
-def rotate_expand_plan(w: int, h: int, angles: Sequence[float], device):
+def rotate_expand_plan(w: int, h: int, angles: Sequence[float], device, offsets: Optional[Sequence[int]] = None,
+                       limit: Optional[int] = None):
     """Host-side part of Image.rotate(expand=True): fixed-point coefficients, canvas sizes and
-    packed output offsets for a batch (device tensors) — reusable across launches."""
+    output offsets for a batch (device tensors) — reusable across launches.  Offsets are packed (16-byte
+    aligned) unless the caller names them (`offsets`, 16-byte aligned, e.g. the slots of an output slab; with
+    `limit` the plan is None when a canvas does not fit its `limit` bytes)."""
     fix, ohw, offs, off = [], [], [], 0
-    for a in angles:
+    for i, a in enumerate(angles):
         m, nw, nh = _geo.rotate_expand_matrix(w, h, float(a))
         fix.append(_geo.affine_fixed_coeffs(m))
         ohw.append((nh, nw))
+        if offsets is not None:
+            if int(offsets[i]) % 16 or (limit is not None and nh * nw * 3 > limit):
+                return None
+            offs.append(int(offsets[i]))
+            off = max(off, int(offsets[i]) + ((nh * nw * 3 + 15) // 16) * 16)
+            continue
         offs.append(off)
         off += ((nh * nw * 3 + 15) // 16) * 16
     return {"fix": torch.tensor(fix, dtype=_I32, device=device),

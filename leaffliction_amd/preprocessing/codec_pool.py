@@ -191,13 +191,14 @@ class CodecPool:
         self.names = {k: s.name for k, s in self.slabs.items()}
 
     def pin(self) -> bool:
-        """Page-lock the input and output slabs (hipHostRegister) so that a whole chunk crosses PCIe as
-        ONE asynchronous copy each way, straight from / into the memory the codec workers use.
+        """Page-lock the slabs (hipHostRegister) so that a whole chunk crosses PCIe as ONE asynchronous copy each
+        way, straight from / into the memory the codec workers use (the noise slab too: a distortion task's noise
+        plane goes up from its slot with an asynchronous copy of its own instead of being stacked on the host first).
         Returns False when the runtime refuses (the pageable path still works, at a third of the rate)."""
         import torch
         rt = torch.cuda.cudart()
         self._pinned = []
-        for key in ("in", "out"):
+        for key in ("in", "out", "noise"):
             t = torch.frombuffer(self.slabs[key].buf, dtype=torch.uint8)
             if int(rt.cudaHostRegister(t.data_ptr(), t.numel(), 0)) != 0:
                 return False

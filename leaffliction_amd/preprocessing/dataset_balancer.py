@@ -248,7 +248,9 @@ class DatasetBalancer:
             if prm is None:
                 prm = draw_params(task["transform_name"], w, h)
             elif "noise8" in prm and prm["noise8"] is None:
-                prm["noise8"] = pool.view("noise", base + k, (h, w, 3))
+                # in the (page-locked) noise slab: goes up from there with an asynchronous copy of its own
+                prm["noise8"] = pool.tensor("noise", base + k, 1)[0, :h * w * 3].view(h, w, 3) if device_path \
+                    else pool.view("noise", base + k, (h, w, 3))
             images[k], params[k] = img, prm
             groups.setdefault((task["transform_name"], h, w, status), []).append(k)
         jobs: List[tuple] = []
@@ -261,6 +263,15 @@ class DatasetBalancer:
                         x = ops.jpeg_idct_rgb_u8(dev_in[idx], h, w)
                     else:
                         x = dev_in[idx, :h * w * 3].view(len(ks), h, w, 3)
+                    if op == "rotate":
+                        # the rotated canvases are written by the kernel straight into their slots of the output mirror
+                        plan = ops.rotate_expand_plan(w, h, [q["angle"] for q in prm], dev_in.device,
+                                                      offsets=[k * pool.slot_bytes for k in ks], limit=pool.slot_bytes)
+                        if plan is not None:
+                            ops.rotate_expand_apply(x, plan, 255, out=dev_out.view(-1))
+                            jobs += [(chunk[k]["output_path"], (base + k) * pool.slot_bytes, (oh, ow, 3), None)
+                                     for k, (oh, ow) in zip(ks, plan["sizes"])]
+                            continue
                     res = apply_batch(op, x, prm)
                     if op != "rotate":
                         y = torch.stack(res)

@@ -65,7 +65,9 @@ def _lanczos(x: float) -> float:
     return 0.0
 
 
-@lru_cache(maxsize=512)
+# (a crop of a W-pixel axis has ~W/8 widths x ~W/5 offsets: a balancing job asks for a few thousand distinct tables,
+# ~1 ms of Python each; 512 entries thrashed)
+@lru_cache(maxsize=8192)
 def lanczos_coeffs(in_size: int, in0: float, in1: float, out_size: int):
     """(bounds int32 [out,2], coeffs int32 [out,ksize], ksize) for one axis."""
     scale = (in1 - in0) / out_size

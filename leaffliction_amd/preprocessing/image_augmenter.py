@@ -73,8 +73,14 @@ def apply_batch(op: str, x, params: Sequence[Dict[str, Any]]) -> List:
     if op == "distortion":
         cutoff = torch.tensor([p["cutoff"] for p in params], dtype=torch.float64, device=dev)
         if "noise8" in params[0]:   # the codec workers cast the noise to uint8 (numpy's own astype)
-            n8 = torch.from_numpy(np.stack([p["noise8"] for p in params])).to(dev)
-            return list(ops.autocontrast_u8(ops.add_wrap_u8(x, n8), cutoff))
+            if all(isinstance(p["noise8"], torch.Tensor) for p in params):
+                # views of the page-locked noise slab: one asynchronous copy per task, no stacking on the host
+                n8 = torch.empty_like(x)
+                for j, p in enumerate(params):
+                    n8[j].copy_(p["noise8"], non_blocking=True)
+            else:
+                n8 = torch.from_numpy(np.stack([np.asarray(p["noise8"]) for p in params])).to(dev)
+            return list(ops.distortion_u8(x, cutoff, add=n8))   # histogram taken while the noise is added
         noise = torch.from_numpy(np.stack([p["noise"] for p in params])).to(dev)
         return list(ops.autocontrast_u8(ops.noise_wrap_add_u8(x, noise), cutoff))
     raise AttributeError(op)

@@ -24,6 +24,10 @@ class DataParallel:
         # "bf16": rounded to bf16 for the all-reduce (2.5 MB) and widened again — BASELINE.md section 4
         self.bucket_dtype = os.environ.get("LEAFFLICTION_GRAD_BUCKET", "f32")
         self._bucket16: Optional[torch.Tensor] = None
+        # overlap the exchange with the backward pass (LeafCNN.train_step, `grad_overlap`): the bucket goes out in two
+        # pieces, the first while the 224 x 224 layers' backward still computes.  LEAFFLICTION_GRAD_OVERLAP=0: one
+        # all-reduce after the whole backward pass (round 1 / 2 behaviour; same bits).
+        self.overlap = self.world > 1 and os.environ.get("LEAFFLICTION_GRAD_OVERLAP", "1") != "0"
         if self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -52,6 +56,35 @@ class DataParallel:
             nn.cast_bf16_f32(self._bucket16, flat_g)
         else:
             self.dist.all_reduce(flat_g, op=self.dist.ReduceOp.SUM)
+        return flat_g
+
+    def allreduce_begin(self, flat_g: torch.Tensor, lo: int, hi: int):
+        """Start the sum of flat_g[lo:hi] over the ranks without waiting for it: the collective runs on the
+        backend's own stream behind everything issued to the current stream so far, and beside what is issued
+        next (RCCL over xGMI while the rest of the backward pass computes).  Returns a handle for allreduce_finish."""
+        if not self.active or hi <= lo:
+            return None
+        part = flat_g[lo:hi]
+        if self.bucket_dtype == "bf16" and flat_g.is_cuda:
+            from .. import nn
+            if self._bucket16 is None or self._bucket16.numel() != flat_g.numel():
+                self._bucket16 = torch.empty(flat_g.numel(), dtype=torch.bfloat16, device=flat_g.device)
+            b16 = self._bucket16[lo:hi]
+            nn.cast_f32_bf16(part, b16)
+            return (self.dist.all_reduce(b16, op=self.dist.ReduceOp.SUM, async_op=True), b16, part)
+        return (self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM, async_op=True), None, part)
+
+    def allreduce_finish(self, flat_g: torch.Tensor, handles) -> torch.Tensor:
+        """The current stream waits for the exchanges started by allreduce_begin (no host wait with RCCL); the bf16
+        bucket's pieces are widened back into the fp32 gradient."""
+        for hd in handles:
+            if hd is None:
+                continue
+            work, b16, part = hd
+            work.wait()
+            if b16 is not None:
+                from .. import nn
+                nn.cast_bf16_f32(b16, part)
         return flat_g
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:

@@ -18,7 +18,7 @@ if __name__ == "__main__":
     tmp = Path(tempfile.mkdtemp(prefix="lf_prof_"))
     try:
         src, dst = tmp / "images", tmp / "augmented"
-        bench._e2e_make_dataset(src, dev, 16)
+        bench._e2e_make_dataset(src, dev, 16, bench._e2e_layout(int(os.environ.get('LF_E2E_IMAGES', '25000'))))
         os.chdir(tmp)
         bal = DatasetBalancer(source_dir=str(src), target_dir=str(dst), seed=42, workers=16)
         bal.analyze_distribution()

@@ -82,6 +82,30 @@ def test_flip_noise_mask_bit_exact(cuda, h, w):
         ops.mask_composite_u8(xd, dev(mask, cuda), "red")
 
 
+@pytest.mark.parametrize("h,w", [(224, 224), (64, 48), (33, 17), (16, 16)])
+def test_distortion_fused_pass_equals_the_separate_kernels(cuda, h, w):
+    """ImageAugmenter.distortion (image_augmenter.py:121-131): the kernel that adds the noise AND counts the noisy
+    image in the same pass gives the bytes of the add kernel and the bins of the histogram kernel — for the host's
+    uint8 noise plane (bit-exact against the oracle's autocontrast of the wrapped sum) and for the device-drawn
+    Philox noise (same seed, same bytes); 33 x 17 is not a multiple of 16 bytes and takes the separate kernels."""
+    from leaffliction_amd import ops
+    n = 4   # 4 x 33 x 17 x 3 bytes is still a multiple of 4: the separate add kernel takes it
+    x = batch_inputs(n, h, w, 13)
+    xd = dev(x, cuda)
+    n8 = np.random.RandomState(2).normal(0, 5, x.shape).astype(np.uint8)   # numpy's own cast, as the reference does
+    cut = np.array([0.0, 0.4, 1.3, 1.99])
+    y, hist = ops.noise_hist_u8(xd, dev(n8, cuda))
+    assert np.array_equal(y.cpu().numpy(), (x + n8).astype(np.uint8))
+    assert np.array_equal(hist.cpu().numpy(), ops.hist_u8(y).cpu().numpy())
+    got = ops.distortion_u8(xd, dev(cut, cuda), add=dev(n8, cuda)).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], P.autocontrast((x[i] + n8[i]).astype(np.uint8), float(cut[i]))), i
+    yp, hp = ops.noise_hist_u8(xd, None, seed=42, sigma=5.0)
+    ref = ops.noise_philox_add_u8(xd, 42, 5.0)
+    assert np.array_equal(yp.cpu().numpy(), ref.cpu().numpy())
+    assert np.array_equal(hp.cpu().numpy(), ops.hist_u8(ref).cpu().numpy())
+
+
 def test_apply_mask_docstring_example(cuda):
     """srcs/utils/mask_utils.py:29-41."""
     from leaffliction_amd import ops

@@ -36,8 +36,12 @@ class _TorchStandIn(LeafCNN):
         self._compiled = {}
         self._global_n = None
         self.steps_with_data = 0
+        self.n_params = int(self.flat_p.numel())
 
-    def _forward_backward(self, x, y_true):
+    def grad_split(self):   # "late" gradients = the bias: the stand-in's backward has nothing to overlap, the
+        return 3 * self.num_classes   # exchange still goes out in the two pieces train_step cuts
+
+    def _forward_backward(self, x, y_true, between=None):
         c = self.num_classes
         x = torch.as_tensor(x, dtype=torch.float32)
         feat = x.mean((1, 2))                                   # [n,3]
@@ -48,6 +52,8 @@ class _TorchStandIn(LeafCNN):
         self.flat_g[:3 * c] = (feat.t() @ d).reshape(-1)
         self.flat_g[3 * c:] = d.sum(0)
         self.steps_with_data += 1
+        if between is not None:
+            between()
         return probs, loss
 
     def _optimizer_update(self, lr, *, weight_decay, clipnorm, ema_decay):
@@ -176,10 +182,10 @@ def test_early_stopping_restores_best_without_stopping():
 
 
 # ------------------------------------------------------------------ GPU: the real model
-def _gpu_fit_worker(rank, world, port, root, n_items, batch, out_dir, dup, dtype="f32", bucket="f32"):
+def _gpu_fit_worker(rank, world, port, root, n_items, batch, out_dir, dup, dtype="f32", bucket="f32", overlap="1"):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LEAFFLICTION_DIST_TIMEOUT": "180",
-                       "LEAFFLICTION_GRAD_BUCKET": bucket})
+                       "LEAFFLICTION_GRAD_BUCKET": bucket, "LEAFFLICTION_GRAD_OVERLAP": overlap})
     torch.cuda.set_device(0)
     from leaffliction_amd.train.parallel import DataParallel
     from leaffliction_amd.train.utils import CosineDecay
@@ -195,7 +201,7 @@ def _gpu_fit_worker(rank, world, port, root, n_items, batch, out_dir, dup, dtype
                 use_norm=False, seed=5,
                 drop_block=0.0 if dup else 0.15, drop_top=0.0 if dup else 0.4, augment=not dup)
     m.set_training_dtype(dtype)
-    assert dp.bucket_dtype == bucket
+    assert dp.bucket_dtype == bucket and dp.overlap == (world > 1 and overlap == "1")
     dp.broadcast_(m.flat_p, 0)
     m.reseed_step_rng(5 + rank)
     if dup:   # gradients of ONE global batch: forward/backward + all-reduce, no optimizer
@@ -258,6 +264,30 @@ def test_fit_graph_replay_world2_bf16(cuda, tmp_path, dtype, bucket):
     assert r0["graphs"] >= 1 and r1["graphs"] >= 1
     assert torch.equal(r0["p"], r1["p"]) and torch.equal(r0["ema"], r1["ema"])
     assert torch.isfinite(r0["p"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,bucket", DP_MODES)
+def test_overlapped_exchange_leaves_the_same_bits(cuda, tmp_path, dtype, bucket):
+    """The data-parallel step sends the gradient bucket in two pieces, the first while stage 0's backward still
+    computes (train_step's `grad_overlap`).  Same kernels in the same order on the compute
+    stream, the same two element-wise sums: after 2 epochs (graph replays included) the parameters and the EMA must
+    equal those of the plain step (one all-reduce after the whole backward pass, LEAFFLICTION_GRAD_OVERLAP=0)
+    bit for bit, on both ranks."""
+    root = tmp_path / "img"
+    root.mkdir()
+    _write_images(root, 16, 32)
+    res = {}
+    for ov in ("1", "0"):
+        out = tmp_path / f"ov{ov}"
+        out.mkdir()
+        mp.spawn(_gpu_fit_worker, args=(2, _free_port(), str(root), 16, 4, str(out), False, dtype, bucket, ov),
+                 nprocs=2, join=True)
+        res[ov] = [torch.load(out / f"r{r}.pt") for r in range(2)]
+        assert torch.equal(res[ov][0]["p"], res[ov][1]["p"])
+    assert res["1"][0]["opt_step"] == res["0"][0]["opt_step"] == 8
+    assert torch.equal(res["1"][0]["p"], res["0"][0]["p"]) and torch.equal(res["1"][0]["ema"], res["0"][0]["ema"])
+    assert torch.isfinite(res["1"][0]["p"]).all()
 
 
 @pytest.mark.gpu
