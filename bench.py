@@ -542,7 +542,7 @@ def predict_end_to_end(dev, n_files=4096):
     pred = None
     try:
         src = tmp / "images"
-        _e2e_make_dataset(src, dev, usable_cores())
+        _e2e_make_dataset(src, dev, usable_cores(), _e2e_layout(11000))   # 7,920 originals
         files = sorted(str(p) for p in src.rglob("*.JPG"))[:n_files]
         os.chdir(tmp)
         model = LeafCNN(num_classes=NUM_CLASSES, img_size=IMG, widths=WIDTHS, drop_block=0.15, drop_top=0.40, l2_reg=1e-4,
@@ -732,8 +732,13 @@ def main() -> None:
             try:
                 doc = json.loads(pmc.read_text())
                 tmpl = dname.split(">")[0].replace("<", "<").strip()
-                hit = [v for kk, v in doc.items() if kk != "_source" and kk.replace(" ", "").startswith(tmpl.replace(" ", ""))]
-                traffic = hit[0] if hit else None
+                # every instantiation of the dominant kernel's template with these leading arguments (its forward and
+                # input-gradient variants), weighted by how often each was launched in the profiled command
+                pre = tmpl.replace(" ", "").rstrip(">")
+                hit = {kk: v for kk, v in doc.items() if not kk.startswith("_") and kk.replace(" ", "").startswith(pre)}
+                cnt = doc.get("_launches", {})
+                wsum = sum(cnt.get(kk, 1) for kk in hit)
+                traffic = round(sum(v * cnt.get(kk, 1) for kk, v in hit.items()) / wsum) if hit else None
                 traffic_source = {"file": "profiles/pmc_latest_bf16.json", **doc.get("_source", {})}
             except Exception:
                 traffic = None

@@ -50,7 +50,7 @@ def main():
     dev = torch.device("cuda:0")
     tmp = Path(tempfile.mkdtemp(prefix="lf_train_"))
     try:
-        bench._e2e_make_dataset(tmp / "images", dev, bench.usable_cores())
+        bench._e2e_make_dataset(tmp / "images", dev, bench.usable_cores(), bench._e2e_layout(11000))
         files = sorted((tmp / "images").rglob("*.JPG"))[:n_files]
         labels = sorted({f.parent.name for f in files})
         l2i = {la: i for i, la in enumerate(labels)}

@@ -67,11 +67,16 @@ def main() -> None:
                        [round(agg[k][c][0] / max(agg[k][c][1], 1), 1) if c in agg[k] else "" for c in counters])
     if js is not None:
         traffic = {}
+        launches = {}
         for k in rows:
             if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
                 f = agg[k]["FETCH_SIZE"][0] / agg[k]["FETCH_SIZE"][1]
                 wv = agg[k]["WRITE_SIZE"][0] / agg[k]["WRITE_SIZE"][1]
                 traffic[k] = round((2.0 * f + wv) * 1024.0)
+                launches[k] = agg[k]["FETCH_SIZE"][1]
+        # launches per kernel variant in the profiled command: bench.py weights the variants of its dominant kernel
+        # (forward / input-gradient instantiations of one template) by them
+        traffic["_launches"] = launches
         if source is not None:
             import subprocess
             try:
