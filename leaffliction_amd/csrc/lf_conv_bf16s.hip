@@ -36,6 +36,8 @@
 // requested BEFORE the MFMAs), and the statistics of a channel live in one half-wave.
 // Replaces Conv2D forward and its input-gradient (srcs/model/cnn.py:27-29 under the mixed_float16
 // policy of train.py:179-190).
+#include <cstdlib>
+
 #include "lf_common.h"
 
 namespace {
@@ -124,13 +126,13 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     // interleave = 0 (small launches): segments dealt round-robin over the grid.
     const int SG = p.tiles_x, UI = SG * p.segs;   // strips, segments per image
     const int xk = blockIdx.x & 7, xj = blockIdx.x >> 3, xw = gridDim.x >> 3;
-    const int my_total = p.interleave ? (p.n > xk ? (p.n - xk + 7) / 8 : 0) * UI : p.n * UI;
-    const int my_first = p.interleave ? xj : (int)blockIdx.x, my_step = p.interleave ? xw : (int)gridDim.x;
+    const int my_total = (p.interleave & 1) ? (p.n > xk ? (p.n - xk + 7) / 8 : 0) * UI : p.n * UI;
+    const int my_first = (p.interleave & 1) ? xj : (int)blockIdx.x, my_step = (p.interleave & 1) ? xw : (int)gridDim.x;
     const int my_units = my_total > my_first ? (my_total - my_first + my_step - 1) / my_step : 0;
     auto unit_of = [&](int ui, int& n, int& tx0, int& t_first, int& t_count) {
         const int q = my_first + ui * my_step;
         const int im = q / UI, rem = q - im * UI, seg = rem / SG;
-        n = p.interleave ? im * 8 + xk : im;
+        n = (p.interleave & 1) ? im * 8 + xk : im;
         tx0 = (rem - seg * SG) * TW;
         t_first = seg * p.seg_tiles;
         t_count = min(p.seg_tiles, p.tiles_y - t_first);
@@ -159,6 +161,12 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
             for (int e = tid; e < S::PBYTES / 16; e += kT)
                 *reinterpret_cast<lf::u32x4*>(lp + 16 * e) = lf::u32x4{0u, 0u, 0u, 0u};
     }
+
+    // Two workgroups share a CU and run the same program: started together they reach their staging, their LDS read
+    // bursts and their matrix work together and contend instead of complementing each other
+    // (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  The second half of the grid — the workgroups that land
+    // beside the first half's — starts about half a tile late.
+    if ((p.interleave & 2) && blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_sleep(80);
 
     auto poff = [&](unsigned pp, unsigned c16) -> unsigned {  // byte offset of 16-byte group c16 of patch pixel pp
         return pp * ROWB + ((c16 ^ ((pp / S::R) % S::C)) << 4);
@@ -541,6 +549,8 @@ SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
     const int units = strips * pl.segs;
     pl.wgs = units < 256 * 2 ? units : 256 * 2;
     pl.interleave = (pl.wgs % 8 == 0 && n >= 8) ? 1 : 0;
+    static const bool stagger = []() { const char* e = getenv("LF_CONV_STAGGER"); return e != nullptr && e[0] == '1'; }();
+    if (stagger && pl.wgs == 256 * 2) pl.interleave |= 2;
     pl.ok = true;
     return pl;
 }
