@@ -36,8 +36,6 @@
 // requested BEFORE the MFMAs), and the statistics of a channel live in one half-wave.
 // Replaces Conv2D forward and its input-gradient (srcs/model/cnn.py:27-29 under the mixed_float16
 // policy of train.py:179-190).
-#include <cstdlib>
-
 #include "lf_common.h"
 
 namespace {
@@ -161,12 +159,6 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
             for (int e = tid; e < S::PBYTES / 16; e += kT)
                 *reinterpret_cast<lf::u32x4*>(lp + 16 * e) = lf::u32x4{0u, 0u, 0u, 0u};
     }
-
-    // Two workgroups share a CU and run the same program: started together they reach their staging, their LDS read
-    // bursts and their matrix work together and contend instead of complementing each other
-    // (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  The second half of the grid — the workgroups that land
-    // beside the first half's — starts about half a tile late.
-    if ((p.interleave & 2) && blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_sleep(80);
 
     auto poff = [&](unsigned pp, unsigned c16) -> unsigned {  // byte offset of 16-byte group c16 of patch pixel pp
         return pp * ROWB + ((c16 ^ ((pp / S::R) % S::C)) << 4);
@@ -387,26 +379,52 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
             for (int cb = 0; cb < NCO; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nb][cb][r] = 0.f;
+        // One GROUP = one 16-channel chunk of one filter row: its three taps read four neighbouring patch pixels between
+        // them (dx + nb = 0 .. 3), so a group is 4 B reads + 3 A reads (per output block) for 6 MFMAs (per output
+        // block) — and all of a group's reads are issued before its first MFMA, so that they are in flight beside the
+        // PREVIOUS group's MFMAs (the compiler kept two or three reads in flight, every MFMA behind an operand
+        // requested one MFMA earlier).  Measured: 32->32 @224 forward 593-606 -> 582 us, input gradient with accumulate
+        // 622-630 -> 606 us (-3 %); the same software pipelining of the weight-gradient kernel's k-steps changed
+        // nothing and was not kept.  The order of the contributions to each accumulator — (chunk, filter row, tap) —
+        // is unchanged: same bits.
+        constexpr int ROWS = TAPS == 9 ? 3 : 1, TPR = TAPS / ROWS, NBP = TPR + NB - 1, NG = CH * ROWS;
+        // With one output block per workgroup the registers allow TWO groups' operands: group g + 1 is requested,
+        // whole, before group g's MFMAs are issued (scheduling barriers keep the compiler from sinking the reads back
+        // to their uses).  Two output blocks (NCO = 2) are at their register budget and keep the compiler's order.
+        constexpr bool DEEP = NCO == 1 && CI >= 32;   // (the stem variant runs three workgroups per CU at 168 registers)
+        bf16x8 A[DEEP ? 2 : 1][TPR][NCO], B[DEEP ? 2 : 1][NBP];
+        auto fetch = [&](int g, int buf) {
+            const int ch = g / ROWS, dy = g - ch * ROWS;
 #pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
+            for (int j = 0; j < NBP; ++j)
+                B[buf][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const lf::u32x4*>(
+                    lp + poff(rowpp[dy] + (unsigned)j, (unsigned)(2 * ch + kh))));
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int dy = TAPS == 9 ? t / 3 : 0, dx = TAPS == 9 ? t % 3 : 0;
-                bf16x8 A[NCO], B[NB];
+            for (int dx = 0; dx < TPR; ++dx)
 #pragma unroll
                 for (int cb = 0; cb < NCO; ++cb)
-                    A[cb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const lf::u32x4*>(
-                        lw + ((((ch * TAPS + t) * 2 + kh) * COUT) + cb * 32 + px) * 16));
+                    A[buf][dx][cb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const lf::u32x4*>(
+                        lw + ((((ch * TAPS + dy * TPR + dx) * 2 + kh) * COUT) + cb * 32 + px) * 16));
+        };
+        if (DEEP) fetch(0, 0);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    B[nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const lf::u32x4*>(
-                        lp + poff(rowpp[dy] + (unsigned)(dx + nb), (unsigned)(2 * ch + kh))));
+        for (int g = 0; g < NG; ++g) {
+            const int buf = DEEP ? (g & 1) : 0;
+            if (DEEP) {
+                if (g + 1 < NG) fetch(g + 1, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                fetch(g, 0);
+            }
+#pragma unroll
+            for (int dx = 0; dx < TPR; ++dx)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int cb = 0; cb < NCO; ++cb)
-                        acc[nb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cb], B[nb], acc[nb][cb], 0, 0, 0);
-            }
+                        acc[nb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[buf][dx][cb], B[buf][dx + nb],
+                                                                              acc[nb][cb], 0, 0, 0);
+            if (DEEP) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue, one 32-channel block at a time through LDS: lane (pixel pair, 16 channels)
         // -> thread (8 pixels, 4 channels); then 16-byte stores and the sums of the rounded values
@@ -549,8 +567,6 @@ SPlan plan_s(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
     const int units = strips * pl.segs;
     pl.wgs = units < 256 * 2 ? units : 256 * 2;
     pl.interleave = (pl.wgs % 8 == 0 && n >= 8) ? 1 : 0;
-    static const bool stagger = []() { const char* e = getenv("LF_CONV_STAGGER"); return e != nullptr && e[0] == '1'; }();
-    if (stagger && pl.wgs == 256 * 2) pl.interleave |= 2;
     pl.ok = true;
     return pl;
 }
