@@ -313,6 +313,17 @@ int lf_conv2d_bf16_act(const void* x, int x_bf16, const uint16_t* wprep, void* y
                        int cin, int h, int wd, int cout, int ksize, const float* in_scale,
                        const float* in_shift, int in_relu, const float* out_scale,
                        const float* out_shift, int out_relu, lf_stream_t stream);
+/* The block's second convolution at inference TOGETHER WITH the squeeze of its SE gate (cnn.py:33-41:
+ * GlobalAveragePooling2D over relu(BN(conv2))): stores the bf16 activation like lf_conv2d_bf16_act and
+ * leaves means[n][co] = mean over the plane of the STORED (rounded) values — summed in the
+ * convolution's epilogue, per image, so the activation is not read back from memory for the pool
+ * (lf_gap_bf16 remains for everything else).  Workspace: lf_conv2d_bf16_act_mean_workspace bytes. */
+size_t lf_conv2d_bf16_act_mean_workspace(int n, int cin, int h, int wd, int cout, int ksize, int x_bf16);
+int lf_conv2d_bf16_act_mean(const void* x, int x_bf16, const uint16_t* wprep, uint16_t* y, int n, int cin,
+                            int h, int wd, int cout, int ksize, const float* in_scale,
+                            const float* in_shift, int in_relu, const float* out_scale,
+                            const float* out_shift, int out_relu, float* means, void* workspace,
+                            size_t ws_bytes, lf_stream_t stream);
 int lf_gap_bf16(const uint16_t* x, float* out, int n, int c, int hw, const float* scale,
                 const float* shift, int relu, lf_stream_t stream);
 int lf_block_tail_fwd_bf16(const uint16_t* y, const float* a_scale, const float* a_shift,

@@ -65,6 +65,9 @@ SIGNATURES = {
     "lf_conv2d_bf16_f32": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P],
     "lf_conv2d_bf16_act": [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int,
                            P, P, c_int, P],
+    "lf_conv2d_bf16_act_mean_workspace": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "lf_conv2d_bf16_act_mean": [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int, P, P,
+                                c_size_t, P],
     "lf_gap_bf16": [P, P, c_int, c_int, c_int, P, P, c_int, P],
     "lf_block_tail_fwd_bf16": [P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
     "lf_conv2d_bf16_stats_tiles": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
@@ -125,6 +128,7 @@ _RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t,
              "lf_bn_workspace": c_size_t, "lf_se_bwd_workspace": c_size_t,
              "lf_adamw_workspace": c_size_t, "lf_conv2d_stats_tiles": C.c_longlong,
              "lf_blur_saliency_workspace": c_size_t, "lf_inclusive_mask_workspace": c_size_t, "lf_conv2d_bf16_weight_elems": c_size_t,
+             "lf_conv2d_bf16_act_mean_workspace": c_size_t,
              "lf_conv2d_bf16_stats_tiles": C.c_longlong, "lf_conv2d_wgrad_bf16_workspace": c_size_t,
              "lf_jpeg_file_bound": c_size_t, "lf_jpeg_entropy_workspace": c_size_t, "lf_jpeg_wrap_scan": C.c_long, "lf_jpeg_decode_workspace": c_size_t, "lf_jpeg_write_file": C.c_long, "lf_jpeg_quant_tables": None}
 

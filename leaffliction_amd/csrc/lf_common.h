@@ -89,6 +89,9 @@ struct ConvBf16TrainArgs {
     const float* out_scale;
     const float* out_shift;
     int out_relu;
+    // inference, optional: per (image, segment) channel sums of the STORED values (what a global-average pool of the
+    // stored activation adds up): unit_sums[(n * segments_per_image + segment) * cout + co]
+    float* unit_sums;
 };
 // arguments of the bf16 weight-gradient kernel (lf_wgrad_bf16.hip)
 struct WgradBf16Args {
@@ -115,6 +118,7 @@ struct WgradBf16Args {
 };
 
 long long conv_bf16s_parts(int n, int cin, int h, int w, int cout, int ksize, int x_bf16);  // 0 = shape not covered
+int conv_bf16s_units_per_image(int n, int cin, int h, int w, int cout, int ksize, int x_bf16);   // segments per image
 int conv_bf16s_launch(ConvBf16TrainArgs a, int ksize, int x_bf16, hipStream_t s);
 
 // Tile kernels whose neighbouring tiles share input halos: workgroups are dealt to the eight XCDs

@@ -470,6 +470,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int nb = 0; nb < NB; ++nb) {
                 float v = acc[nb][cb][r];
                 if (p.accumulate) v += oldv[nb];
+                if (p.out_scale) v = fmaf(v, eps[0][col], eps[1][col]);   // inference with sums: the folded BatchNorm
+                if (p.out_relu) v = fmaxf(v, 0.0f);
                 const uint16_t vb = bf16_down(v);
                 if (ok[nb]) yb[cbase + po[nb]] = vb;
                 if (!stats) continue;
@@ -642,6 +644,20 @@ void launch_conv_bf16(const Bf16ConvArgs& a, int ksize, hipStream_t s) {
     }
 }
 
+// means[n][c] = scale * sum over the image's partial sums: `unit` layout part[(n * units + u) * c_total + c] (the
+// streaming kernel's segments) or `tile` layout part[((c * n_total + n) * units + u) * 2] (the K-chunked kernel's
+// per-tile statistics, sum in element 0).  Fixed order: deterministic.
+__global__ void partial_sums_mean_kernel(const float* __restrict__ part, float* __restrict__ means, int n, int c,
+                                         int units, int tile_layout, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const int im = i / c, ch = i - im * c;
+    float acc = 0.f;
+    for (int u = 0; u < units; ++u)
+        acc += tile_layout ? part[(((size_t)ch * n + im) * units + u) * 2] : part[((size_t)im * units + u) * c + ch];
+    means[i] = acc * scale;
+}
+
 }  // namespace
 
 extern "C" {
@@ -770,6 +786,67 @@ int lf_conv2d_bf16_train(const void* x, int x_bf16, const uint16_t* wprep, uint1
     a.stat_mask_y = mask_y; a.mask_scale = mask_scale; a.mask_shift = mask_shift; a.mask_relu = mask_relu;
     if (x_bf16) launch_conv_bf16<true, true, true>(a, ksize, s); else launch_conv_bf16<false, true, true>(a, ksize, s);
     return lf::check_launch("lf_conv2d_bf16_train");
+}
+
+size_t lf_conv2d_bf16_act_mean_workspace(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
+    if (n <= 0 || cin <= 0 || h <= 0 || w <= 0 || cout <= 0) return 0;
+    // (the same routing as lf_conv2d_bf16_act: the streaming kernel for the 32-channel layers only, so that the
+    // stored activation is bit-equal with and without the means)
+    const int units = cout == 32 ? lf::conv_bf16s_units_per_image(n, cin, h, w, cout, ksize, x_bf16) : 0;
+    if (units > 0) return (size_t)n * units * cout * sizeof(float);
+    return (size_t)n * bf16_tiles(h, w, cout) * cout * 2 * sizeof(float);
+}
+
+int lf_conv2d_bf16_act_mean(const void* x, int x_bf16, const uint16_t* wprep, uint16_t* y, int n, int cin, int h, int w,
+                            int cout, int ksize, const float* in_scale, const float* in_shift, int in_relu,
+                            const float* out_scale, const float* out_shift, int out_relu, float* means,
+                            void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(x && wprep && y && means && workspace, "lf_conv2d_bf16_act_mean: null buffer");
+    LF_REQUIRE(n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0, "lf_conv2d_bf16_act_mean: bad dims");
+    LF_REQUIRE(ksize == 1 || ksize == 3, "lf_conv2d_bf16_act_mean: ksize must be 1 or 3");
+    LF_REQUIRE(w % 4 == 0, "lf_conv2d_bf16_act_mean: width must be a multiple of 4 (got %d)", w);
+    LF_REQUIRE(cout % 32 == 0, "lf_conv2d_bf16_act_mean: cout must be a multiple of 32 (got %d)", cout);
+    LF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (out_scale == nullptr) == (out_shift == nullptr),
+               "lf_conv2d_bf16_act_mean: scale/shift must both be set");
+    LF_REQUIRE(in_scale == nullptr || cin <= kMaxPrologueCin,
+               "lf_conv2d_bf16_act_mean: a fused prologue takes at most %d input channels (got %d)", kMaxPrologueCin, cin);
+    LF_REQUIRE((size_t)(cin + 2 * 16 * kKC) * h * w * (x_bf16 ? 2 : 4) < ((size_t)1 << 31) &&
+                   lf_conv2d_bf16_weight_elems(cin, cout, ksize) * 2 < ((size_t)1 << 31),
+               "lf_conv2d_bf16_act_mean: image or weights too large for 32-bit buffer offsets");
+    LF_REQUIRE(n <= 65535, "lf_conv2d_bf16_act_mean: batch too large for grid.z");
+    LF_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wprep)) & 15) == 0,
+               "lf_conv2d_bf16_act_mean: x and wprep must be 16-byte aligned");
+    const size_t need = lf_conv2d_bf16_act_mean_workspace(n, cin, h, w, cout, ksize, x_bf16);
+    if (ws_bytes < need) {
+        lf::set_error("lf_conv2d_bf16_act_mean: workspace %zu < %zu bytes", ws_bytes, need);
+        return LF_ERR_WORKSPACE;
+    }
+    hipStream_t s = lf::as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    const float inv = 1.0f / (float)((size_t)h * w);
+    const int units = cout == 32 ? lf::conv_bf16s_units_per_image(n, cin, h, w, cout, ksize, x_bf16) : 0;
+    if (units > 0) {
+        lf::ConvBf16TrainArgs t{};
+        t.x = x; t.wprep = wprep; t.y = y; t.n = n; t.cin = cin; t.h = h; t.w = w; t.cout = cout;
+        t.in_scale = in_scale; t.in_shift = in_shift; t.in_relu = in_relu;
+        t.out_scale = out_scale; t.out_shift = out_shift; t.out_relu = out_relu;
+        t.unit_sums = part;
+        const int rc = lf::conv_bf16s_launch(t, ksize, x_bf16, s);
+        if (rc != LF_OK) return rc;
+        partial_sums_mean_kernel<<<(n * cout + 255) / 256, 256, 0, s>>>(part, means, n, cout, units, 0, inv);
+        return lf::check_launch("lf_conv2d_bf16_act_mean");
+    }
+    Bf16ConvArgs a{};
+    a.x = x; a.wprep = wprep; a.y = y; a.n = n; a.cin = cin; a.h = h; a.w = w; a.cout = cout;
+    a.chunks16 = (cin + 15) / 16;
+    a.chunks = (a.chunks16 + kKC - 1) / kKC;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+    a.out_scale = out_scale; a.out_shift = out_shift; a.out_relu = out_relu;
+    const int tiles = bf16_tiles(h, w, cout);
+    a.stat_part = part; a.stat_pivot = nullptr; a.stat_tiles = (long long)n * tiles;
+    if (x_bf16) launch_conv_bf16<true, true, true>(a, ksize, s); else launch_conv_bf16<false, true, true>(a, ksize, s);
+    partial_sums_mean_kernel<<<(n * cout + 255) / 256, 256, 0, s>>>(part, means, n, cout, tiles, 1, inv);
+    return lf::check_launch("lf_conv2d_bf16_act_mean");
 }
 
 int lf_gap_bf16(const uint16_t* x, float* out, int n, int c, int hw, const float* scale, const float* shift,

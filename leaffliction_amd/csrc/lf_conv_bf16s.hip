@@ -114,7 +114,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 31, kh = lane >> 5;
     const size_t hw = (size_t)p.h * p.w;
     const bool pro = p.in_scale != nullptr;
-    const bool stats = p.stat_part != nullptr, masked = RMW && p.stat_mask_y != nullptr;
+    const bool stats = p.stat_part != nullptr || p.unit_sums != nullptr, masked = RMW && p.stat_mask_y != nullptr;
     const bool accumulate = RMW && p.accumulate;
     // What a workgroup walks: SEGMENTS of column strips (a strip = TW columns of one image; a segment = seg_tiles
     // consecutive tiles of it, top to bottom — whole strips when the launch has enough of them to fill the chip).
@@ -123,6 +123,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     // strips share (halo columns, 128-byte lines that straddle a strip boundary) crosses the fabric once.
     // interleave = 0 (small launches): segments dealt round-robin over the grid.
     const int SG = p.tiles_x, UI = SG * p.segs;   // strips, segments per image
+    int unit_rem = 0;                             // the current segment's index inside its image
     const int xk = blockIdx.x & 7, xj = blockIdx.x >> 3, xw = gridDim.x >> 3;
     const int my_total = (p.interleave & 1) ? (p.n > xk ? (p.n - xk + 7) / 8 : 0) * UI : p.n * UI;
     const int my_first = (p.interleave & 1) ? xj : (int)blockIdx.x, my_step = (p.interleave & 1) ? xw : (int)gridDim.x;
@@ -130,6 +131,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     auto unit_of = [&](int ui, int& n, int& tx0, int& t_first, int& t_count) {
         const int q = my_first + ui * my_step;
         const int im = q / UI, rem = q - im * UI, seg = rem / SG;
+        unit_rem = rem;
         n = (p.interleave & 1) ? im * 8 + xk : im;
         tx0 = (rem - seg * SG) * TW;
         t_first = seg * p.seg_tiles;
@@ -327,6 +329,7 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
     for (int ui = 0; ui < my_units; ++ui) {
     int n, tx0, t_first, t_count;
     unit_of(ui, n, tx0, t_first, t_count);
+    const int cur_rem = unit_rem;   // (unit_of is called again for the next segment's prefetch)
     for (int tt = 0; tt < t_count; ++tt) {
         __syncthreads();  // the previous tile's operand reads are done (first pass: weights / lsc / lst staged)
         const int ty0 = (t_first + tt) * TH;
@@ -491,8 +494,28 @@ void conv_bf16s_kernel(lf::ConvBf16TrainArgs p) {
             __builtin_amdgcn_wave_barrier();   // the reads above stay in front of the next block's writes
         }
     }
+    if (p.unit_sums != nullptr) {
+        // inference: this segment's channel sums of the stored activation (the squeeze of the block's SE gate adds
+        // them up per image).  The patch is dead between segments: the reduction scratch lies over it.
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lp);   // [4 waves][COUT]
+#pragma unroll
+        for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = s1[cb][j];
+#pragma unroll
+                for (int m = 1; m < 8; m <<= 1) a += __shfl_xor(a, m, 64);
+                if ((lane & 7) == 0) red[wv * COUT + cb * 32 + 8 * j + ec] = a;
+                s1[cb][j] = s2[cb][j] = 0.f;
+            }
+        __syncthreads();
+        for (int c = tid; c < COUT; c += kT)
+            p.unit_sums[((size_t)n * UI + cur_rem) * p.cout + c] =
+                (red[c] + red[COUT + c]) + (red[2 * COUT + c] + red[3 * COUT + c]);
     }
-    if (stats) {
+    }
+    if (p.stat_part != nullptr) {
         // one partial per workgroup: a channel's pixel groups are 8 lanes (lane & 7) in each of the four waves
         __syncthreads();
         float* red = reinterpret_cast<float*>(lp);   // [4 waves][COUT][2], over the patch (dead now)
@@ -616,6 +639,11 @@ namespace lf {
 long long conv_bf16s_parts(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
     const SPlan pl = plan_s(n, cin, h, w, cout, ksize, x_bf16);
     return pl.ok ? pl.wgs : 0;
+}
+
+int conv_bf16s_units_per_image(int n, int cin, int h, int w, int cout, int ksize, int x_bf16) {
+    const SPlan pl = plan_s(n, cin, h, w, cout, ksize, x_bf16);
+    return pl.ok ? pl.tiles_x * pl.segs : 0;
 }
 
 int conv_bf16s_launch(ConvBf16TrainArgs a, int ksize, int x_bf16, hipStream_t s) {

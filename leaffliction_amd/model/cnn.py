@@ -375,7 +375,7 @@ class LeafCNN:
             self._infer_cache = {"key": key, "w": {}, "bn": {}}
         cache = self._infer_cache
 
-        def conv(x, wname, k, bn, relu):
+        def conv(x, wname, k, bn, relu, means=None):
             wt = P[wname]
             wp = cache["w"].get(wname)
             if wp is None:
@@ -383,19 +383,21 @@ class LeafCNN:
             st = cache["bn"].get(bn)
             if st is None:   # inference: scale / shift from the moving statistics (own copy: `stats` is shared)
                 st = cache["bn"][bn] = self._bn(bn, None, False).clone()
-            return nn.conv2d_bf16(x, wp, wt.shape[2], k,
-                                  out=self._buf(n, "bf16." + wname, (n, wt.shape[2], x.shape[2], x.shape[3]), bf),
-                                  out_scale=st[2], out_shift=st[3], out_relu=relu)
+            out = self._buf(n, "bf16." + wname, (n, wt.shape[2], x.shape[2], x.shape[3]), bf)
+            if means is not None:   # + the squeeze of the block's SE gate, summed in the epilogue
+                return nn.conv2d_bf16_mean(x, wp, wt.shape[2], k, out, means, out_scale=st[2], out_shift=st[3],
+                                           out_relu=relu)[0]
+            return nn.conv2d_bf16(x, wp, wt.shape[2], k, out=out, out_scale=st[2], out_shift=st[3], out_relu=relu)
 
         xin = conv(x0, "stem.w", 3, "stem.bn", True)
         cin = self.widths[0]
         for i, f in enumerate(self.widths):
             p = f"s{i}."
             a1 = conv(xin, p + "c1.w", 3, p + "bn1", True)
-            a2 = conv(a1, p + "c2.w", 3, p + "bn2", True)
+            m = self._buf(n, p + "m", (n, f)) if self.use_se else None
+            a2 = conv(a1, p + "c2.w", 3, p + "bn2", True, means=m)
             s = None
             if self.use_se:
-                m = nn.gap_bf16(a2, out=self._buf(n, p + "m", (n, f)))
                 s = nn.se_fwd(m, P[p + "se.w1"], P[p + "se.b1"], P[p + "se.w2"], P[p + "se.b2"],
                               self._buf(n, p + "z1", (n, f // 8)), self._buf(n, p + "s", (n, f)))
             sc = conv(xin, p + "proj.w", 1, p + "bnp", False) if cin != f else xin

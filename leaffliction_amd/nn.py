@@ -124,6 +124,30 @@ def conv2d_bf16(x: torch.Tensor, wprep: torch.Tensor, cout: int, ksize: int, in_
     return out
 
 
+def conv2d_bf16_mean(x: torch.Tensor, wprep: torch.Tensor, cout: int, ksize: int, out: torch.Tensor,
+                     means: torch.Tensor, in_scale=None, in_shift=None, in_relu: bool = False, out_scale=None,
+                     out_shift=None, out_relu: bool = False):
+    """conv2d_bf16 with bf16 output AND the per-image channel means of the stored activation, taken in the
+    convolution's epilogue (inference: a block's second convolution + the squeeze of its SE gate in one pass).
+    x: fp32 or bf16 NCHW; out: bf16 [N,Cout,H,W]; means: fp32 [N,Cout].  Returns (out, means)."""
+    if x.dtype not in (_F32, torch.bfloat16):
+        raise TypeError(f"conv2d_bf16_mean.x: expected float32 or bfloat16, got {x.dtype}")
+    _chk(x, x.dtype, "conv2d_bf16_mean.x", 4)
+    n, cin, h, w = x.shape
+    if wprep.dtype != torch.int16 or wprep.numel() != ((cin + 15) // 16) * ksize * ksize * cout * 16:
+        raise ValueError("conv2d_bf16_mean.wprep: not the packed weights of this convolution")
+    _chk(out, torch.bfloat16, "conv2d_bf16_mean.out", 4)
+    _chk(means, _F32, "conv2d_bf16_mean.means", 2)
+    if tuple(out.shape) != (n, cout, h, w) or tuple(means.shape) != (n, cout):
+        raise ValueError("conv2d_bf16_mean: out [N,Cout,H,W] / means [N,Cout] shape mismatch")
+    xb = 1 if x.dtype == torch.bfloat16 else 0
+    ws = _workspace(int(_lib.load().lf_conv2d_bf16_act_mean_workspace(n, cin, h, w, cout, ksize, xb)), x.device, slot=1)
+    _lib.call("lf_conv2d_bf16_act_mean", x.data_ptr(), xb, wprep.data_ptr(), out.data_ptr(), n, cin, h, w, cout, ksize,
+              _ptr(in_scale), _ptr(in_shift), 1 if in_relu else 0, _ptr(out_scale), _ptr(out_shift),
+              1 if out_relu else 0, means.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return out, means
+
+
 def gap_bf16(x: torch.Tensor, scale=None, shift=None, relu: bool = False,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[N,C] fp32 plane means of relu?(x*scale[c]+shift[c]) for a bf16 NCHW tensor (inference)."""

@@ -314,3 +314,32 @@ def test_bf16_inference_cache_follows_every_kind_of_parameter_write(cuda):
     model.set_weights([a * 0.5 for a in w])
     p3 = model.predict_device(x).clone()
     assert not torch.equal(pk, p3) and torch.equal(p3, fresh())
+
+
+@pytest.mark.parametrize("n,cin,cout,hw,xbf", [(3, 32, 32, 224, True),     # streaming kernel, whole strips
+                                               (9, 32, 32, 64, True),      # streaming kernel, strips dealt per XCD
+                                               (2, 64, 64, 112, True),     # K-chunked kernel, 16-byte epilogue
+                                               (2, 128, 128, 56, True),
+                                               (2, 256, 256, 28, True),    # K-chunked kernel, narrow rows (w % 8 != 0)
+                                               (2, 3, 32, 64, False)])     # fp32 input (the stem's shape)
+def test_conv2d_bf16_mean_equals_conv_then_gap(cuda, n, cin, cout, hw, xbf):
+    """lf_conv2d_bf16_act_mean (inference: a block's second convolution + the squeeze of its SE gate in one pass):
+    the stored activation is BIT-equal to lf_conv2d_bf16_act's, and the means equal lf_gap_bf16's means of that
+    stored tensor up to fp32 summation order (per-segment / per-tile partial sums instead of one plane sum)."""
+    from leaffliction_amd import nn
+    g = torch.Generator().manual_seed(hw + cin)
+    x = torch.randn(n, cin, hw, hw, generator=g)
+    x = (x.to(torch.bfloat16) if xbf else x).to(cuda)
+    w = (torch.randn(cin, 9, cout, generator=g) * (1.0 / (cin * 9) ** 0.5)).to(cuda)
+    osc, osh = (torch.rand(cout, generator=g) + 0.5).to(cuda), (torch.randn(cout, generator=g) * 0.3).to(cuda)
+    wp = nn.conv2d_bf16_weights(w, 3)
+    ref = nn.conv2d_bf16(x, wp, cout, 3, out_dtype=torch.bfloat16, out_scale=osc, out_shift=osh, out_relu=True)
+    ref_m = nn.gap_bf16(ref)
+    out = torch.full((n, cout, hw, hw), float("nan"), dtype=torch.bfloat16, device=cuda)
+    means = torch.full((n, cout), float("nan"), device=cuda)
+    nn.conv2d_bf16_mean(x, wp, cout, 3, out, means, out_scale=osc, out_shift=osh, out_relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    exact = ref.double().mean((2, 3))
+    assert float((means.double() - exact).abs().max()) <= 1e-5 * float(exact.abs().max()) + 1e-7
+    assert float((ref_m.double() - exact).abs().max()) <= 1e-5 * float(exact.abs().max()) + 1e-7
