@@ -205,6 +205,24 @@ long lf_jpeg_wrap_scan(const uint8_t* scan, size_t scan_len, int h, int w, int q
  *   images of one size; image i's coefficients at coef + i*coef_stride bytes, its tables at qtab + i*qtab_stride. */
 int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef, size_t coef_cap, uint16_t* qtab128,
                       int* h, int* w);
+/* The same decoding with the Huffman step on the GPU as well (jdhuff.c's decode_mcu; the balancer's input step):
+ * lf_jpeg_scan_prepare (HOST, also in libleafcodec.so): markers only.  The slot receives the quantisation tables
+ *   at [0, 256), and at lf_jpeg_scan_aux_offset(h, w) = align16(256 + 3hw) a 32-byte header, the four Huffman
+ *   tables as they stood in the file, the offsets of the restart intervals and the entropy-coded bytes with the
+ *   0xFF00 stuffing undone and the RSTn markers taken out (layout: lf_jpeg_host.cpp).  *hash = FNV-1a of the
+ *   Huffman tables: images decoded in one launch must share it.  Returns 0; 1 = decode this file on the host
+ *   (lf_jpeg_read_file / libjpeg); -1 = corrupt markers.
+ * lf_jpeg_huffman_u8 (GPU): N prepared slots of one size -> each slot's coefficient area [256, 256 + 3hw) in
+ *   lf_jpeg_read_file's layout (then lf_jpeg_idct_rgb_u8 as before).  mode 0: one workgroup per image decodes 256
+ *   subsequences of the scan at once (self-synchronising; lf_jpeg_huff.hip), and the images that kernel does not
+ *   take (restart markers, scans over 96 KB) go through the one-lane-per-image kernel; mode 1: that kernel for all.
+ *   status[i] (int32, device): 0 decoded; 1 the scan is malformed or ends early (what lf_jpeg_read_file answers
+ *   with -1: give the file to libjpeg for the reference's verdict); 2 (one-lane-per-image kernel only: it shares
+ *   one set of tables among 64 images) the image's hash differs from that of the first image of its group; 3 no
+ *   prepared scan in the slot. */
+size_t lf_jpeg_scan_aux_offset(int h, int w);
+int lf_jpeg_scan_prepare(const uint8_t* data, size_t len, uint8_t* slot, size_t cap, int* h, int* w, uint64_t* hash);
+int lf_jpeg_huffman_u8(void* slots, size_t stride, int n, int h, int w, int* status, int mode, lf_stream_t stream);
 size_t lf_jpeg_decode_workspace(int n, int h, int w);
 int lf_jpeg_idct_rgb_u8(const void* coef, size_t coef_stride, const void* qtab, size_t qtab_stride,
                         uint8_t* rgb, int n, int h, int w, void* workspace, size_t ws_bytes,

@@ -16,6 +16,8 @@ void lf_jpeg_quant_tables(int quality, uint8_t* lum64, uint8_t* chroma64);
 size_t lf_jpeg_file_bound(int h, int w);
 long lf_jpeg_write_file(const int16_t* coef, int h, int w, int quality, uint8_t* out, size_t cap);
 int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef, size_t coef_cap, uint16_t* qtab128, int* h, int* w);
+size_t lf_jpeg_scan_aux_offset(int h, int w);
+int lf_jpeg_scan_prepare(const uint8_t* data, size_t len, uint8_t* slot, size_t cap, int* h, int* w, uint64_t* hash);
 }
 
 namespace {
@@ -459,15 +461,24 @@ inline unsigned be16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
 
 }  // namespace
 
-extern "C" int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef, size_t coef_cap, uint16_t* qtab128,
-                                 int* h_out, int* w_out) {
-    if (!data || !coef || !qtab128 || !h_out || !w_out || len < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
+namespace {
+
+// Everything in front of the entropy-coded segment of a baseline 4:2:0 file: tables, frame and scan headers.
+struct Parsed {
     uint16_t qt[4][64];
     bool have_q[4] = {false, false, false, false};
     DHuff dc[4], ac[4];
+    uint8_t dht[2][4][16 + 256];   // the DHT segments as they stood in the file: 16 counts, then the symbols
     int h = 0, w = 0, restart = 0;
     int comp_id[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
+    int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
     bool have_sof = false;
+    size_t scan = 0;   // offset of the first entropy-coded byte
+};
+
+// 0: `out.scan` is where the scan's bytes start; 1: a kind of file this path does not cover; -1: corrupt.
+int parse_until_scan(const uint8_t* data, size_t len, Parsed& P) {
+    if (!data || len < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
     size_t pos = 2;
     while (pos + 4 <= len) {
         if (data[pos] != 0xFF) return -1;
@@ -491,8 +502,8 @@ extern "C" int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef,
                 if (tq > 3) return -1;
                 if (pq != 0) return 1;   // 16-bit tables: not baseline
                 if (i + 65 > n) return -1;
-                for (int k = 0; k < 64; ++k) qt[tq][kNatural[k]] = q[i + 1 + k];   // stored row-major
-                have_q[tq] = true;
+                for (int k = 0; k < 64; ++k) P.qt[tq][kNatural[k]] = q[i + 1 + k];   // stored row-major
+                P.have_q[tq] = true;
                 i += 65;
             }
         } else if (m == 0xC4) {
@@ -503,79 +514,190 @@ extern "C" int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef,
                 if (tc > 1 || th > 3) return -1;
                 int total = 0;
                 for (int k = 0; k < 16; ++k) total += q[i + 1 + k];
-                if (total > 256 || i + 17 + total > n) return -1;
-                if (!build_decoder(tc ? ac[th] : dc[th], q + i + 1, q + i + 17, total)) return -1;
+                if (total > 256 || i + 17 + (size_t)total > n) return -1;
+                if (!build_decoder(tc ? P.ac[th] : P.dc[th], q + i + 1, q + i + 17, total)) return -1;
+                memset(P.dht[tc][th], 0, sizeof(P.dht[tc][th]));
+                memcpy(P.dht[tc][th], q + i + 1, 16 + (size_t)total);
                 i += 17 + total;
             }
         } else if (m == 0xC0 || m == 0xC1) {
             if (n < 15 || q[0] != 8) return 1;
-            h = (int)be16(q + 1);
-            w = (int)be16(q + 3);
+            P.h = (int)be16(q + 1);
+            P.w = (int)be16(q + 3);
             if (q[5] != 3) return 1;   // grey or CMYK: libjpeg's business
             for (int c = 0; c < 3; ++c) {
-                comp_id[c] = q[6 + 3 * c];
+                P.comp_id[c] = q[6 + 3 * c];
                 const int hv = q[7 + 3 * c];
-                comp_q[c] = q[8 + 3 * c];
-                if (hv != (c == 0 ? 0x22 : 0x11) || comp_q[c] > 3) return 1;   // 4:2:0 only
+                P.comp_q[c] = q[8 + 3 * c];
+                if (hv != (c == 0 ? 0x22 : 0x11) || P.comp_q[c] > 3) return 1;   // 4:2:0 only
             }
-            if (h <= 0 || w <= 0 || h % 16 || w % 16) return 1;
-            have_sof = true;
+            if (P.h <= 0 || P.w <= 0 || P.h % 16 || P.w % 16) return 1;
+            P.have_sof = true;
         } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
             return 1;   // progressive, lossless, arithmetic
         } else if (m == 0xDD) {
             if (n < 2) return -1;
-            restart = (int)be16(q);
+            P.restart = (int)be16(q);
         } else if (m == 0xDA) {
-            if (!have_sof || n < 10 || q[0] != 3) return have_sof ? 1 : -1;
-            int td[3], ta[3];
+            if (!P.have_sof || n < 10 || q[0] != 3) return P.have_sof ? 1 : -1;
             for (int c = 0; c < 3; ++c) {
-                if (q[1 + 2 * c] != comp_id[c]) return 1;   // components in another order
-                td[c] = q[2 + 2 * c] >> 4;
-                ta[c] = q[2 + 2 * c] & 15;
-                if (td[c] > 3 || ta[c] > 3 || !dc[td[c]].present || !ac[ta[c]].present || !have_q[comp_q[c]]) return -1;
+                if (q[1 + 2 * c] != P.comp_id[c]) return 1;   // components in another order
+                P.td[c] = q[2 + 2 * c] >> 4;
+                P.ta[c] = q[2 + 2 * c] & 15;
+                if (P.td[c] > 3 || P.ta[c] > 3 || !P.dc[P.td[c]].present || !P.ac[P.ta[c]].present ||
+                    !P.have_q[P.comp_q[c]])
+                    return -1;
             }
             if (q[7] != 0 || q[8] != 63) return 1;
-            const long mcus = (long)(h / 16) * (w / 16);
-            if ((size_t)mcus * 384 > coef_cap) return -1;
-            for (int k = 0; k < 64; ++k) {
-                qtab128[k] = qt[comp_q[0]][k];
-                qtab128[64 + k] = qt[comp_q[1]][k];
-                if (qt[comp_q[2]][k] != qt[comp_q[1]][k]) return 1;   // Cb and Cr with different tables
-            }
-            Reader r{data + pos + seg, data + len};
-            int pred[3] = {0, 0, 0};
-            int until_restart = restart;
-            for (long mcu = 0; mcu < mcus; ++mcu) {
-                if (restart && until_restart == 0) {
-                    if (r.starved()) return -1;   // the interval before this marker ended inside an MCU
-                    // byte-align, expect RSTn
-                    const uint8_t* mp = r.p;
-                    while (mp + 1 < r.end && mp < r.p + 8 && !(mp[0] == 0xFF && mp[1] >= 0xD0 && mp[1] <= 0xD7)) ++mp;
-                    if (!(mp + 1 < r.end && mp[0] == 0xFF && mp[1] >= 0xD0 && mp[1] <= 0xD7)) return -1;
-                    r.p = mp + 2;
-                    r.reset();
-                    pred[0] = pred[1] = pred[2] = 0;
-                    until_restart = restart;
-                }
-                int16_t* b = coef + mcu * 384;
-                for (int k = 0; k < 4; ++k)
-                    if (!decode_block(r, b + 64 * k, pred[0], dc[td[0]], ac[ta[0]])) return -1;
-                if (!decode_block(r, b + 256, pred[1], dc[td[1]], ac[ta[1]])) return -1;
-                if (!decode_block(r, b + 320, pred[2], dc[td[2]], ac[ta[2]])) return -1;
-                if (restart) --until_restart;
-            }
-            // A file cut inside its scan decodes "successfully" on padding zeros; Pillow raises "image file is
-            // truncated" for it (image_utils.py:19-33 then counts the task as failed / skips the file).  Such a
-            // file — bits consumed that were never there, or no EOI behind the scan — is handed back (-1) and the
-            // caller's libjpeg path gives the reference's verdict.
-            if (r.starved() || r.next_marker() != 0xD9) return -1;
-            *h_out = h;
-            *w_out = w;
+            for (int k = 0; k < 64; ++k)
+                if (P.qt[P.comp_q[2]][k] != P.qt[P.comp_q[1]][k]) return 1;   // Cb and Cr with different tables
+            P.scan = pos + seg;
             return 0;
         }
         pos += seg;
     }
     return -1;
+}
+
+}  // namespace
+
+extern "C" int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef, size_t coef_cap, uint16_t* qtab128,
+                                 int* h_out, int* w_out) {
+    if (!data || !coef || !qtab128 || !h_out || !w_out) return -1;
+    Parsed P;
+    const int rc = parse_until_scan(data, len, P);
+    if (rc != 0) return rc;
+    const int h = P.h, w = P.w, restart = P.restart;
+    const long mcus = (long)(h / 16) * (w / 16);
+    if ((size_t)mcus * 384 > coef_cap) return -1;
+    for (int k = 0; k < 64; ++k) {
+        qtab128[k] = P.qt[P.comp_q[0]][k];
+        qtab128[64 + k] = P.qt[P.comp_q[1]][k];
+    }
+    Reader r{data + P.scan, data + len};
+    int pred[3] = {0, 0, 0};
+    int until_restart = restart;
+    for (long mcu = 0; mcu < mcus; ++mcu) {
+        if (restart && until_restart == 0) {
+            if (r.starved()) return -1;   // the interval before this marker ended inside an MCU
+            // byte-align, expect RSTn
+            const uint8_t* mp = r.p;
+            while (mp + 1 < r.end && mp < r.p + 8 && !(mp[0] == 0xFF && mp[1] >= 0xD0 && mp[1] <= 0xD7)) ++mp;
+            if (!(mp + 1 < r.end && mp[0] == 0xFF && mp[1] >= 0xD0 && mp[1] <= 0xD7)) return -1;
+            r.p = mp + 2;
+            r.reset();
+            pred[0] = pred[1] = pred[2] = 0;
+            until_restart = restart;
+        }
+        int16_t* b = coef + mcu * 384;
+        for (int k = 0; k < 4; ++k)
+            if (!decode_block(r, b + 64 * k, pred[0], P.dc[P.td[0]], P.ac[P.ta[0]])) return -1;
+        if (!decode_block(r, b + 256, pred[1], P.dc[P.td[1]], P.ac[P.ta[1]])) return -1;
+        if (!decode_block(r, b + 320, pred[2], P.dc[P.td[2]], P.ac[P.ta[2]])) return -1;
+        if (restart) --until_restart;
+    }
+    // A file cut inside its scan decodes "successfully" on padding zeros; Pillow raises "image file is
+    // truncated" for it (image_utils.py:19-33 then counts the task as failed / skips the file).  Such a
+    // file — bits consumed that were never there, or no EOI behind the scan — is handed back (-1) and the
+    // caller's libjpeg path gives the reference's verdict.
+    if (r.starved() || r.next_marker() != 0xD9) return -1;
+    *h_out = h;
+    *w_out = w;
+    return 0;
+}
+
+// The same file prepared for the GPU's Huffman decoder (lf_jpeg_huffman_u8, lf_jpeg_huff.hip) instead of being
+// decoded here.  The markers are parsed, the entropy-coded segment is freed of what a one-thread-per-image decoder
+// would stumble over — the 0xFF00 stuffing is undone and the RSTn markers are taken out, their places kept as
+// offsets — and `slot` receives
+//   [0, 256)                 the luminance and chrominance quantisation tables (64 uint16 each, row-major)
+//   [256, 256 + 3hw)         left alone: the GPU writes the coefficients there
+//   [aux, aux + 32)          aux = lf_jpeg_scan_aux_offset(h, w): magic "LFSC", h, w (uint16), restart interval,
+//                            number of restart intervals N (1 without restarts), the 64-bit FNV-1a of the four Huffman
+//                            tables, offset of the data from aux, length of the data (uint32 each)
+//   [aux + 32, aux + 1120)   the DHT segments of the luminance DC, luminance AC, chrominance DC, chrominance AC
+//                            tables: 16 counts + 256 symbols each
+//   [aux + 1120, ...)        N + 1 uint32: where each interval's bytes start in the data, and where the last one ends
+//   [aux + data offset, ...) the unstuffed bytes of all intervals, then 16 bytes of zeros
+// Returns 0; 1 when the file is to be decoded on the host (the kinds lf_jpeg_read_file hands back, Cr tables that
+// differ from the Cb tables, a restart-marker count other than the frame calls for, a scan that does not end in
+// EOI, a file that does not fit `cap`: lf_jpeg_read_file or libjpeg then gives the verdict); -1 when the markers
+// are corrupt.
+extern "C" size_t lf_jpeg_scan_aux_offset(int h, int w) { return ((size_t)256 + (size_t)3 * h * w + 15) / 16 * 16; }
+
+extern "C" int lf_jpeg_scan_prepare(const uint8_t* data, size_t len, uint8_t* slot, size_t cap, int* h_out, int* w_out,
+                                    uint64_t* hash_out) {
+    if (!data || !slot || !h_out || !w_out) return -1;
+    Parsed P;
+    const int rc = parse_until_scan(data, len, P);
+    if (rc != 0) return rc;
+    if (P.td[2] != P.td[1] || P.ta[2] != P.ta[1] || P.h > 65535 || P.w > 65535) return 1;
+    const long mcus = (long)(P.h / 16) * (P.w / 16);
+    const long nint = P.restart ? (mcus + P.restart - 1) / P.restart : 1;
+    const size_t aux = lf_jpeg_scan_aux_offset(P.h, P.w), raw_len = len - P.scan;
+    const size_t data_off = 1120 + ((size_t)4 * (nint + 1) + 15) / 16 * 16;
+    if (raw_len > 0x7FFFFFF0u || aux + data_off + raw_len + 16 > cap) return 1;
+    uint8_t* a = slot + aux;
+    uint32_t* offs = reinterpret_cast<uint32_t*>(a + 1120);
+    uint8_t* out = a + data_off;
+    const uint8_t* p = data + P.scan;
+    const uint8_t* const end = data + len;
+    size_t o = 0;
+    long iv = 0;
+    offs[0] = 0;
+    while (true) {
+        const uint8_t* f = p < end ? static_cast<const uint8_t*>(memchr(p, 0xFF, (size_t)(end - p))) : nullptr;
+        if (!f) return 1;   // the data ran out without a marker: no EOI
+        memcpy(out + o, p, (size_t)(f - p));
+        o += (size_t)(f - p);
+        if (f + 1 >= end) return 1;
+        const unsigned m = f[1];
+        if (m == 0x00) {
+            out[o++] = 0xFF;
+            p = f + 2;
+        } else if (P.restart && m >= 0xD0 && m <= 0xD7 && iv + 1 < nint) {
+            offs[++iv] = (uint32_t)o;
+            p = f + 2;
+        } else {   // the entropy-coded segment ends here; what follows must lead to EOI (Reader::next_marker)
+            const uint8_t* q = f;
+            unsigned next = 0;
+            for (; q + 1 < end; ++q)
+                if (q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF) {
+                    next = q[1];
+                    break;
+                }
+            if (next != 0xD9 || iv + 1 != nint) return 1;
+            break;
+        }
+    }
+    offs[nint] = (uint32_t)o;
+    memset(out + o, 0, 16);
+    uint16_t* qtab128 = reinterpret_cast<uint16_t*>(slot);
+    for (int k = 0; k < 64; ++k) {
+        qtab128[k] = P.qt[P.comp_q[0]][k];
+        qtab128[64 + k] = P.qt[P.comp_q[1]][k];
+    }
+    uint8_t* t = a + 32;
+    memcpy(t, P.dht[0][P.td[0]], 272);
+    memcpy(t + 272, P.dht[1][P.ta[0]], 272);
+    memcpy(t + 544, P.dht[0][P.td[1]], 272);
+    memcpy(t + 816, P.dht[1][P.ta[1]], 272);
+    uint64_t hash = 1469598103934665603ull;
+    for (int i = 0; i < 1088; ++i) hash = (hash ^ t[i]) * 1099511628211ull;
+    const uint32_t magic = 0x4353464Cu;   // "LFSC"
+    const uint16_t hw[2] = {(uint16_t)P.h, (uint16_t)P.w};
+    const uint32_t rs = (uint32_t)P.restart, ni = (uint32_t)nint, dof = (uint32_t)data_off, dl = (uint32_t)o;
+    memcpy(a, &magic, 4);
+    memcpy(a + 4, hw, 4);
+    memcpy(a + 8, &rs, 4);
+    memcpy(a + 12, &ni, 4);
+    memcpy(a + 16, &hash, 8);
+    memcpy(a + 24, &dof, 4);
+    memcpy(a + 28, &dl, 4);
+    *h_out = P.h;
+    *w_out = P.w;
+    if (hash_out) *hash_out = hash;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -331,6 +331,23 @@ def jpeg_entropy_u8(coef: torch.Tensor, h: int, w: int, out: Optional[torch.Tens
     return out
 
 
+def jpeg_huffman_u8(slots: torch.Tensor, h: int, w: int, sequential: bool = False) -> torch.Tensor:
+    """The Huffman step of Image.open for N files of one size that utils.jpeg_host.scan_prepare_into has laid into
+    `slots` (uint8 [N, slot_bytes], contiguous): each row's coefficient area [256, 256 + 3hw) is written IN PLACE
+    (then jpeg_idct_rgb_u8 as for host-decoded files).  One workgroup per image decodes 256 pieces of the scan at
+    once; files with restart markers or scans over 96 KB — or all files, with `sequential` — go through the
+    one-lane-per-image kernel, which wants one set of Huffman tables per 64 consecutive rows.
+    Returns int32 [N] on the device: 0 decoded, 1 malformed / truncated scan (hand the file to libjpeg), 2 tables
+    differ from the group's (one-lane-per-image kernel), 3 no prepared scan in the slot."""
+    _chk(slots, _U8, "jpeg_huffman.slots", 2)
+    n, stride = slots.shape
+    if h % 16 or w % 16 or stride % 16 or slots.stride(0) != stride or slots.data_ptr() % 16:
+        raise ValueError(f"jpeg_huffman: {h}x{w} images need contiguous 16-byte aligned rows (multiple of 16 bytes)")
+    status = torch.empty(n, dtype=torch.int32, device=slots.device)
+    _lib.call("lf_jpeg_huffman_u8", slots.data_ptr(), stride, n, h, w, status.data_ptr(), 1 if sequential else 0, _stream())
+    return status
+
+
 def jpeg_idct_rgb_u8(slots: torch.Tensor, h: int, w: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The pixel half of Image.open(path).convert("RGB") (image_utils.py:19-33) for N images of one size whose
     files utils.jpeg_host.read_file_into has Huffman-decoded: `slots` uint8 [N, slot_bytes], each row = the

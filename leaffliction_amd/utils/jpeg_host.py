@@ -32,6 +32,11 @@ def load() -> C.CDLL:
         lib.lf_jpeg_read_file.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.lf_jpeg_read_file.restype = C.c_int
+        lib.lf_jpeg_scan_aux_offset.argtypes = [C.c_int, C.c_int]
+        lib.lf_jpeg_scan_aux_offset.restype = C.c_size_t
+        lib.lf_jpeg_scan_prepare.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+        lib.lf_jpeg_scan_prepare.restype = C.c_int
         _LIB = lib
     return _LIB
 
@@ -71,6 +76,23 @@ def read_file_into(data: bytes, dst: np.ndarray):
     rc = lib.lf_jpeg_read_file(buf.ctypes.data, buf.size, base + QTAB_BYTES, (dst.size - QTAB_BYTES) // 2, base,
                                C.byref(h), C.byref(w))
     return (h.value, w.value) if rc == 0 else None
+
+
+def scan_prepare_into(data: bytes, dst: np.ndarray):
+    """Markers only: leave a baseline 4:2:0 file ready for the GPU's Huffman decoder (ops.jpeg_huffman_u8) in `dst`
+    (uint8 view of a slab slot; layout in csrc/lf_jpeg_host.cpp).  Returns (h, w, hash of the file's Huffman tables),
+    or None when the file is to be decoded on the host (read_file_into, then libjpeg) or does not fit."""
+    lib = load()
+    if dst.dtype != np.uint8 or not dst.flags["C_CONTIGUOUS"]:
+        return None
+    h, w, hh = C.c_int(0), C.c_int(0), C.c_uint64(0)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    rc = lib.lf_jpeg_scan_prepare(buf.ctypes.data, buf.size, dst.ctypes.data, dst.size, C.byref(h), C.byref(w), C.byref(hh))
+    return (h.value, w.value, hh.value) if rc == 0 else None
+
+
+def scan_aux_offset(h: int, w: int) -> int:
+    return int(load().lf_jpeg_scan_aux_offset(int(h), int(w)))
 
 
 def read_file(data: bytes):

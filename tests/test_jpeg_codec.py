@@ -262,3 +262,162 @@ def test_legacy_normal_equals_numpy(seed):
     out = np.empty(n, np.uint8)
     jpeg_host.legacy_normal_u8(seed, 0.0, 5.0, out)
     assert np.array_equal(out, want.astype(np.uint8))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The Huffman step on the GPU: lf_jpeg_scan_prepare (host: markers, un-stuffing) + lf_jpeg_huffman_u8 (GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+SCAN_KW = [dict(quality=95), dict(quality=60), dict(quality=95, optimize=True), dict(quality=85, restart_marker_rows=1),
+           dict(quality=90, restart_marker_blocks=3), dict(quality=100)]
+
+
+def _raw_scan(data):
+    """The entropy-coded bytes of a one-scan file, from behind the SOS header up to (not including) EOI."""
+    i = 2
+    while data[i + 1] != 0xDA:
+        i += 2 + int.from_bytes(data[i + 2:i + 4], "big")
+    i += 2 + int.from_bytes(data[i + 2:i + 4], "big")
+    assert data[-2:] == b"\xff\xd9"
+    return data[i:-2]
+
+
+def _prepared(data, h, w, extra=1 << 16):
+    from leaffliction_amd.utils import jpeg_host
+    slot = np.zeros((256 + 3 * h * w + extra + 15) // 16 * 16, np.uint8)
+    got = jpeg_host.scan_prepare_into(data, slot)
+    return slot, got
+
+
+@pytest.mark.parametrize("kw", SCAN_KW)
+def test_scan_prepare_keeps_every_bit_of_the_scan(kw):
+    """What the host leaves for the GPU decoder, put back together (0xFF re-stuffed, RSTn re-inserted at the recorded
+    offsets), is the file's own entropy-coded segment; header fields and tables are the file's."""
+    from leaffliction_amd.utils import jpeg_host
+    h, w = 64, 96
+    a = make("noise", h, w, 31) if kw["quality"] == 100 else scene(h, w, 31)
+    data = _save(a, **kw)
+    slot, got = _prepared(data, h, w)
+    assert got is not None and got[:2] == (h, w)
+    aux = jpeg_host.scan_aux_offset(h, w)
+    assert aux == (256 + 3 * h * w + 15) // 16 * 16
+    hdr = slot[aux:aux + 32]
+    assert bytes(hdr[:4]) == b"LFSC"
+    hh, ww = hdr[4:8].view(np.uint16)
+    restart, nint = (int(v) for v in hdr[8:16].view(np.uint32))
+    data_off, data_len = (int(v) for v in hdr[24:32].view(np.uint32))
+    assert (hh, ww) == (h, w) and int(hdr[16:24].view(np.uint64)[0]) == got[2]
+    mcus = (h // 16) * (w // 16)
+    assert nint == (-(-mcus // restart) if restart else 1)
+    offs = slot[aux + 1120:aux + 1120 + 4 * (nint + 1)].view(np.uint32)
+    assert offs[0] == 0 and offs[-1] == data_len and np.all(np.diff(offs.astype(np.int64)) > 0)
+    body = slot[aux + data_off:aux + data_off + data_len]
+    rebuilt = b""
+    for i in range(nint):
+        rebuilt += bytes(body[offs[i]:offs[i + 1]]).replace(b"\xff", b"\xff\x00")
+        if i + 1 < nint:
+            rebuilt += bytes([0xFF, 0xD0 + i % 8])
+    assert rebuilt == _raw_scan(data)
+    # the tables the reader would have used
+    ref = jpeg_host.read_file(data)
+    assert np.array_equal(slot[:256].view(np.uint16).reshape(2, 64), ref[1])
+    # same tables -> same hash; other tables -> another hash
+    if kw.get("optimize"):
+        assert _prepared(_save(a, quality=95), h, w)[1][2] != got[2]
+    else:
+        assert _prepared(_save(scene(h, w, 32), **kw), h, w)[1][2] == got[2]
+
+
+def test_scan_prepare_declines_what_the_host_reader_declines():
+    a = scene(64, 64, 12)
+    for data in (_save(a, quality=90, subsampling=0), _save(a, quality=90, progressive=True), _save(a[..., 0], quality=90),
+                 _save(a[:50, :60], quality=90), b"not a jpeg at all", _save(a, quality=90)[:400]):
+        assert _prepared(data, 64, 64)[1] is None
+    good = _save(a, quality=90)
+    assert _prepared(good, 64, 64)[1] is not None
+    assert _prepared(good[:-2], 64, 64)[1] is None            # no EOI behind the scan
+    assert _prepared(good[:len(good) * 3 // 4], 64, 64)[1] is None
+    assert _prepared(good + b"\x00" * 7, 64, 64)[1] is not None
+    assert _prepared(good, 64, 64, extra=256)[1] is None      # does not fit the slot
+    rst = _save(a, quality=90, restart_marker_rows=1)
+    k = rst.index(b"\xff\xd1")
+    assert _prepared(rst[:k] + rst[k + 2:], 64, 64)[1] is None   # a restart marker went missing
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,kw", [(224, 224, dict(quality=95)), (64, 96, dict(quality=70, optimize=True)),
+                                    (48, 208, dict(quality=85, restart_marker_rows=1)), (16, 16, dict(quality=95)),
+                                    (64, 64, dict(quality=90, restart_marker_blocks=3)), (32, 48, dict(quality=100)),
+                                    (256, 256, dict(quality=88)), (224, 224, dict(quality=30)),
+                                    (64, 64, dict(quality=100, optimize=True))])
+@pytest.mark.parametrize("sequential", [False, True])
+def test_gpu_huffman_decoder_recovers_the_coefficients(cuda, h, w, kw, sequential):
+    """file -> host markers -> GPU Huffman decoding == the host reader's coefficients, and on through the GPU IDCT ==
+    Image.open(file).convert("RGB"), through the workgroup-per-image kernel (256 subsequences decoded at once; files
+    with restart markers fall through to the other kernel) and through the lane-per-image kernel alone.  70 images:
+    two groups of 64 lanes, the second one ragged."""
+    import torch
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    n = 70
+    kinds = ["noise", "scene", "extremes", "flat"]
+    files = [_save(make(kinds[i % 4], h, w, 40 + i), **kw) for i in range(n)]
+    if kw.get("optimize") and sequential:   # optimised tables differ from file to file, and that kernel shares them
+        files = [files[1]] * n
+    stride = (256 + 3 * h * w + (1 << 16) + 4095) // 4096 * 4096
+    slots = np.zeros((n, stride), np.uint8)
+    for i, f in enumerate(files):
+        got = jpeg_host.scan_prepare_into(f, slots[i])
+        assert got is not None and got[:2] == (h, w), i
+    dev = torch.from_numpy(slots).to(cuda)
+    status = ops.jpeg_huffman_u8(dev, h, w, sequential=sequential).cpu().numpy()
+    assert np.all(status == 0), status
+    out = dev.cpu().numpy()
+    m = (h // 16) * (w // 16)
+    for i, f in enumerate(files):
+        coef = jpeg_host.read_file(f)[0]
+        assert np.array_equal(out[i, 256:256 + m * 768].view(np.int16).reshape(m, 6, 64), coef), i
+    rgb = ops.jpeg_idct_rgb_u8(dev, h, w).cpu().numpy()
+    for i in (0, 1, 2, 3, 63, 64, 69):
+        assert np.array_equal(rgb[i], np.asarray(Image.open(io.BytesIO(files[i])).convert("RGB"))), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sequential", [False, True])
+def test_gpu_huffman_decoder_reports_what_it_cannot_decode(cuda, sequential):
+    """status 1: a scan that ends early (bytes cut out of its middle with the EOI left in place — what a damaged
+    file looks like after the host's marker pass), a restart interval that is too short; status 2 (lane-per-image
+    kernel): tables other than the group's; status 3: a slot nothing was prepared in.  The neighbours decode all
+    the same."""
+    import torch
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    h = w = 64
+    stride = (256 + 3 * h * w + (1 << 15) + 4095) // 4096 * 4096
+    good = _save(scene(h, w, 50), quality=95)
+    cut = good[:len(good) // 2] + good[-2:]                       # half the scan gone, EOI in place
+    other = _save(scene(h, w, 51), quality=95, optimize=True)     # its own Huffman tables
+    rst = _save(scene(h, w, 52), quality=95, restart_marker_rows=1)
+    k = rst.index(b"\xff\xd1")
+    rst_short = rst[:k - 30] + rst[k:]                            # 30 bytes gone from the second interval
+    cut2 = good[:len(good) - 40] + good[-2:]                      # only the last few blocks gone
+    junk = good[:len(good) // 3] + bytes(255 - b if b not in (0, 255) else b for b in good[len(good) // 3:-2]) + good[-2:]
+    files = [good, cut, other, good, None, rst, rst_short, good, cut2, junk]
+    slots = np.zeros((len(files), stride), np.uint8)
+    for i, f in enumerate(files):
+        if f is not None:
+            assert jpeg_host.scan_prepare_into(f, slots[i]) is not None, i
+    dev = torch.from_numpy(slots).to(cuda)
+    status = ops.jpeg_huffman_u8(dev, h, w, sequential=sequential).cpu().numpy()
+    # rst / rst_short have the standard tables too (same hash as `good`), so they decode in this group; `junk` (the
+    # bits of two thirds of the scan inverted) is whatever the host reader says it is
+    junk_ok = jpeg_host.read_file(junk) is not None
+    assert status.tolist() == [0, 1, 2 if sequential else 0, 0, 3, 0, 1, 0, 1, 0 if junk_ok else 1], status
+    out = dev.cpu().numpy()
+    m = (h // 16) * (w // 16)
+    for i in (0, 3, 5, 7) + (() if sequential else (2,)) + ((9,) if junk_ok else ()):
+        assert np.array_equal(out[i, 256:256 + m * 768].view(np.int16).reshape(m, 6, 64), jpeg_host.read_file(files[i])[0])
+    for f in (cut, rst_short, cut2):   # ... the host reader declines them too: such files go to libjpeg, whose verdict
+        assert jpeg_host.read_file(f) is None   # (error, or pixels with its own concealment) is the reference's
+    # a group whose FIRST slot holds nothing: no tables to decode with
+    dev2 = torch.from_numpy(slots[[4, 0]]).to(cuda)
+    assert ops.jpeg_huffman_u8(dev2, h, w, sequential=sequential).cpu().numpy().tolist() == [3, 3 if sequential else 0]
