@@ -232,6 +232,13 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
                                                               size_t aux, int* __restrict__ status) {
     __shared__ ParLds S;
     const int tid = threadIdx.x, img = blockIdx.x;
+#ifdef LF_HUFF_STATS   // development build: cycle stamps of the phases into the first 64 bytes of the slot (over the tables)
+    uint64_t stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    stamp[0] = __builtin_readcyclecounter();
+#define LF_STAMP(i) stamp[i] = __builtin_readcyclecounter()
+#else
+#define LF_STAMP(i)
+#endif
     uint8_t* slot = slots + (size_t)img * stride;
     const uint8_t* a = slot + aux;
     const ScanHeader H = read_header(a, h, w, aux, stride);   // the same for every thread
@@ -248,6 +255,7 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
         if (tid == 0) status[img] = 3;
         return;
     }
+    LF_STAMP(1);
     // the scan into LDS; the host left 16 zero bytes behind it, and what lies behind those is never looked at as data
     const uint4* src = reinterpret_cast<const uint4*>(a + H.data_off);
     const uint32_t pieces = H.data_len / 16 + 1, room = kStreamCap / 16 + 2;
@@ -266,7 +274,9 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
     const uint32_t stop = (uint32_t)(tid + 1) * L < total_bits ? (uint32_t)(tid + 1) * L : total_bits;
     uint32_t entry = S.state[tid];
     bool dirty = mine;
-    for (int round = 0; round <= kPT; ++round) {
+    LF_STAMP(2);
+    int round = 0;
+    for (; round <= kPT; ++round) {
         uint32_t left = 0;
         bool changed = false;
         if (dirty) {
@@ -284,6 +294,7 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
             dirty = true;
         }
     }
+    LF_STAMP(3);
     // block numbers: exclusive prefix sum of the blocks each chain completed
     const uint32_t own = mine ? S.cnt[tid] : 0u;
     S.scan[0][tid] = own;
@@ -297,12 +308,14 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
     }
     const uint32_t incl = S.scan[cur][tid], first_blk = incl - own;
     int16_t* coef = reinterpret_cast<int16_t*>(slot + 256);
+    LF_STAMP(4);
     if (mine && first_blk < total) {
         uint32_t blocks;
         decode_span<true>(S.T, S.stream, entry, stop, blocks, coef, first_blk, total, total_bits, &S.fail);
     }
     if (tid == kPT - 1 && incl < total) S.fail = 1;   // the scan ended before the image did
     __syncthreads();
+    LF_STAMP(5);
     if (S.fail) {
         if (tid == 0) status[img] = 1;
         return;
@@ -328,6 +341,15 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
         }
     }
     if (tid == 0) status[img] = 0;
+#ifdef LF_HUFF_STATS
+    LF_STAMP(6);
+    if (tid == 0) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(slot);
+        for (int i = 1; i <= 6; ++i) o[i - 1] = stamp[i] - stamp[i - 1];
+        o[6] = (uint64_t)round;
+        o[7] = nsub;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

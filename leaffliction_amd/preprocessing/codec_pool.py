@@ -63,10 +63,13 @@ def _warm(_i: int) -> bool:
 
 
 def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
-    """jobs: (source path, transform, seed, input offset, noise offset, slot bytes[, want coefficients]).
-    Returns per job ("ok", shape, params) | ("coef", shape, params) | ("big", array, params) | ("err", message).
+    """jobs: (source path, transform, seed, input offset, noise offset, slot bytes[, want coefficients: 0 | 1 | 2]).
+    Returns per job ("ok", shape, params) | ("coef", shape, params) | ("scan", shape, params) | ("big", array, params)
+    | ("err", message).
     "coef": the file was a baseline 4:2:0 JPEG of whole MCUs and the slot holds its quantisation tables and
-    Huffman-decoded coefficients (libleafcodec.so); the GPU finishes the decoding (ops.jpeg_idct_rgb_u8)."""
+    Huffman-decoded coefficients (libleafcodec.so); the GPU finishes the decoding (ops.jpeg_idct_rgb_u8).
+    "scan" (asked for with 2): only the file's markers were read here; the slot holds the tables and the un-stuffed
+    scan, and the Huffman decoding is the GPU's as well (ops.jpeg_huffman_u8)."""
     from ..utils import jpeg_host
     from ..utils.image_utils import ImageLoader, _checked
     from .image_augmenter import draw_params
@@ -76,12 +79,19 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
     for job in jobs:
         path, op, seed, off, noff, cap = job[:6]
         try:
-            arr, coef_hw = None, None
+            arr, coef_hw, scan_hw = None, None, None
             if len(job) > 6 and job[6]:
                 with open(_checked(path, what="Image"), "rb") as f:   # the loader's own checks (image_utils.py:19-33)
                     data = f.read()
-                coef_hw = jpeg_host.read_file_into(data, np.frombuffer(buf_in, np.uint8, cap, off))
-            if coef_hw is None:
+                dst = np.frombuffer(buf_in, np.uint8, cap, off)
+                if job[6] == 2:
+                    got = jpeg_host.scan_prepare_into(data, dst)
+                    scan_hw = got[:2] if got is not None else None
+                if scan_hw is None:
+                    coef_hw = jpeg_host.read_file_into(data, dst)
+            if scan_hw is not None:
+                h, w = scan_hw
+            elif coef_hw is None:
                 arr = ImageLoader.load_as_array(path)
                 h, w, _c = arr.shape
             else:
@@ -111,7 +121,7 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
                     else:
                         params["noise8"] = n8
             if arr is None:
-                out.append(("coef", (h, w, 3), params))
+                out.append(("scan" if scan_hw is not None else "coef", (h, w, 3), params))
             elif arr.nbytes <= cap:
                 np.frombuffer(buf_in, np.uint8, arr.nbytes, off)[:] = arr.reshape(-1)
                 out.append(("ok", arr.shape, params))
@@ -232,7 +242,7 @@ class CodecPool:
         per = max(1, -(-len(jobs) // (pieces_per_worker * self.workers)))
         return [jobs[i:i + per] for i in range(0, len(jobs), per)]
 
-    def decode(self, tasks: Sequence[dict], first_slot: int, coefficients: bool = False,
+    def decode(self, tasks: Sequence[dict], first_slot: int, coefficients: int = 0,
                pieces_per_worker: int = 4) -> List[Future]:
         jobs = [(t.get("read_img", t["source_img"]), t["transform_name"], t["seed"], (first_slot + k) * self.slot_bytes,
                  (first_slot + k) * self.slot_bytes, self.slot_bytes, coefficients) for k, t in enumerate(tasks)]

@@ -239,7 +239,7 @@ class DatasetBalancer:
                 logger.error(f"Failed to process {payload}")
                 self.failed += 1
                 continue
-            if status == "coef":   # pixels do not exist on the host: the GPU finishes the decoding
+            if status in ("coef", "scan"):   # pixels do not exist on the host: the GPU finishes the decoding
                 img = None
                 h, w, _ = payload
             else:
@@ -254,13 +254,32 @@ class DatasetBalancer:
             images[k], params[k] = img, prm
             groups.setdefault((task["transform_name"], h, w, status), []).append(k)
         jobs: List[tuple] = []
+        huffman: List[tuple] = []   # (task indexes, device status of the GPU's Huffman decoding) per size
+        decoded_px: Dict[tuple, tuple] = {}   # (h, w, status) -> (pixels [m, h, w, 3] on the device, task index -> row)
+        if device_path:
+            # the JPEG back end once per chunk and size, not once per transform: the Huffman kernel's time is a latency
+            # (one workgroup per image, ~1 ms whether 40 images or 256), and the IDCT batches better as well
+            sizes: Dict[tuple, List[int]] = {}
+            for (op, h, w, status), ks in groups.items():
+                if status in ("coef", "scan"):
+                    sizes.setdefault((h, w, status), []).extend(ks)
+            for (h, w, status), ks in sizes.items():
+                ks.sort()
+                try:
+                    rows = dev_in[:n] if len(ks) == n else dev_in[torch.tensor(ks, dtype=torch.int64, device=dev_in.device)]
+                    if status == "scan":
+                        huffman.append((ks, ops.jpeg_huffman_u8(rows, h, w)))
+                    decoded_px[(h, w, status)] = (ops.jpeg_idct_rgb_u8(rows, h, w), {k: j for j, k in enumerate(ks)})
+                except Exception as e:  # noqa: BLE001
+                    logger.error(f"Failed to decode a batch of {len(ks)} {h}x{w} sources: {e}")
         for (op, h, w, status), ks in groups.items():
             prm = [params[k] for k in ks]
             try:
-                if device_path and status in ("ok", "coef"):
+                if device_path and status in ("ok", "coef", "scan"):
                     idx = torch.tensor(ks, dtype=torch.int64, device=dev_in.device)
-                    if status == "coef":
-                        x = ops.jpeg_idct_rgb_u8(dev_in[idx], h, w)
+                    if status in ("coef", "scan"):
+                        px, row = decoded_px[(h, w, status)]
+                        x = px[torch.tensor([row[k] for k in ks], dtype=torch.int64, device=dev_in.device)]
                     else:
                         x = dev_in[idx, :h * w * 3].view(len(ks), h, w, 3)
                     if op == "rotate":
@@ -313,9 +332,40 @@ class DatasetBalancer:
         t_ops = time.perf_counter()
         if device_path:
             pool.tensor("out", base, n).copy_(dev_out[:n])   # synchronous: the encoders may start
+        for ks, st in huffman:
+            st = st.cpu().numpy()
+            if st.any():   # scans the GPU could not decode (damaged files, mostly): libjpeg has the reference's verdict
+                jobs = self._redo_on_host(chunk, [k for k, v in zip(ks, st) if v], params, pool, base, jobs)
         t_out = time.perf_counter()
         self.timings["gpu_stage_host_ops"] = self.timings.get("gpu_stage_host_ops", 0.0) + (t_ops - t_in)
         self.timings["gpu_stage_sync_d2h"] = self.timings.get("gpu_stage_sync_d2h", 0.0) + (t_out - t_ops)
+        return jobs
+
+    def _redo_on_host(self, chunk: List[dict], ks: List[int], params: List[Optional[dict]], pool: CodecPool, base: int,
+                      jobs: List[tuple]) -> List[tuple]:
+        """Tasks whose source the GPU's Huffman decoder handed back: the file goes through Pillow here, as it would have
+        in the reference's worker (image_utils.py:19-33) — pixels or an error — and the op runs on what Pillow gives.
+        Their slots of the OUTPUT slab are written after the chunk's copy back; their encode jobs are replaced."""
+        from ..utils.image_utils import ImageLoader
+        paths = {chunk[k]["output_path"] for k in ks}
+        jobs = [j for j in jobs if j[0] not in paths]
+        for k in ks:
+            task = chunk[k]
+            try:
+                img = ImageLoader.load_as_array(task.get("read_img", task["source_img"]))
+                prm = params[k]
+                if prm is not None and "noise8" in prm and prm["noise8"] is not None and tuple(prm["noise8"].shape) != img.shape:
+                    raise ValueError("the file's pixels are not of the size its header gave")
+                r = self._run_group(task["transform_name"], [img], [prm])[0]
+            except Exception as e:  # noqa: BLE001 — the reference counts any failure
+                logger.error(f"Failed to process {task['source_img']} - {e}")
+                self.failed += 1
+                continue
+            if r.nbytes <= pool.slot_bytes:
+                pool.view("out", base + k, r.shape)[...] = r
+                jobs.append((task["output_path"], (base + k) * pool.slot_bytes, tuple(r.shape), None))
+            else:
+                jobs.append((task["output_path"], 0, tuple(r.shape), r))
         return jobs
 
     def _collect(self, futures, paths: List[str]) -> None:
@@ -353,7 +403,9 @@ class DatasetBalancer:
                 dev = torch.device("cuda", torch.cuda.current_device())
                 self._mirror = (torch.empty((n_chunk, slot), dtype=torch.uint8, device=dev),
                                 torch.empty((n_chunk, slot), dtype=torch.uint8, device=dev))
-            gpu_decode = self._mirror is not None   # workers Huffman-decode only; IDCT .. colour on the GPU
+            # 0: the workers decode to pixels; 1: they Huffman-decode only, IDCT .. colour on the GPU; 2: they read the
+            # markers only, the Huffman decoding is the GPU's too (LEAFFLICTION_GPU_HUFFMAN=0: stay with 1)
+            gpu_decode = 0 if self._mirror is None else (1 if os.environ.get("LEAFFLICTION_GPU_HUFFMAN", "1") == "0" else 2)
             # chunk i + 2 is queued for decoding before chunk i goes to the GPU: the workers always have a
             # chunk's worth of work behind the one the main thread is waiting for
             ahead = [pool.decode(chunks[0], 0, gpu_decode)]

@@ -60,6 +60,10 @@ if __name__ == "__main__":
                   f"{sub / ms * 1e3:.0f} images/s", flush=True)
     got = dev.clone()
     ops.jpeg_huffman_u8(got, h, w)
+    if os.environ.get("LF_HUFF_STATS"):   # a build with -DLF_HUFF_STATS (LEAFHIP_LIB points at it): cycles per phase
+        st = got.cpu().numpy()[:, :64].view(np.uint64).astype(np.float64)
+        names = ["tables", "stage the scan", "rounds", "block numbers", "write pass", "DC scan", "n rounds", "subsequences"]
+        print({k: (round(float(st[:, i].mean()), 1), float(st[:, i].max())) for i, k in enumerate(names)}, flush=True)
     m = 3 * h * w
     assert np.array_equal(got.cpu().numpy()[:, 256:256 + m], ref[:, 256:256 + m])
     print(f"mean file {np.mean([len(f) for f in files]):.0f} bytes; host: markers only {t_prep * 1e6:.1f} us/image, "

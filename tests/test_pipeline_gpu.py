@@ -440,3 +440,46 @@ def test_prefetched_loader_batches_equal_the_host_loader(cuda, tmp_path, monkeyp
     model.fit(seq, epochs=1, verbose=0)
     assert len(calls) == len(seq) - 1
     seq.close()
+
+
+def test_balancer_with_the_gpu_huffman_decoder_equals_the_host_decoded_run(cuda, tmp_path, monkeypatch):
+    """The balancer's input step with the Huffman decoding on the GPU (the default) against the same job with the
+    codec workers doing it (LEAFFLICTION_GPU_HUFFMAN=0, the path the reference golden above pinned in round 2): the
+    same files byte for byte and the same counts, on a class whose sources are a file with restart markers, one with
+    optimised Huffman tables, one damaged inside its scan (the GPU hands it back, Pillow conceals the damage and the
+    task goes on with Pillow's pixels, as in the reference's worker) and one cut short (Pillow raises: a failed task)."""
+    import io
+    from leaffliction_amd.preprocessing.dataset_balancer import DatasetBalancer
+    src = tmp_path / "images"
+    build_tree(src, {"Apple": {"Apple_healthy": 14}}, 64, 900)
+    d = src / "Apple" / "Apple_scab"
+    d.mkdir(parents=True)
+
+    def jpeg(seed, **kw):
+        b = io.BytesIO()
+        Image.fromarray(leaf_like(64, 64, seed)).save(b, format="JPEG", quality=95, **kw)
+        return b.getvalue()
+    whole = jpeg(950)
+    (d / "image (1).JPG").write_bytes(jpeg(951, restart_marker_rows=1))
+    (d / "image (2).JPG").write_bytes(jpeg(952, optimize=True))
+    (d / "image (3).JPG").write_bytes(whole[:len(whole) // 2] + whole[-2:])     # half the scan gone, EOI in place
+    (d / "image (4).JPG").write_bytes(jpeg(953)[:-900])                           # cut short
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LEAFFLICTION_GPU_HUFFMAN", mode)
+        work = tmp_path / f"run{mode}"
+        work.mkdir()
+        monkeypatch.chdir(work)
+        bal = DatasetBalancer(source_dir=str(src), target_dir=str(work / "augmented"), seed=42, workers=2)
+        orig = bal._images_by_class
+        bal._images_by_class = lambda orig=orig: {k: sorted(v) for k, v in orig().items()}
+        bal.run()
+        files = {str(p.relative_to(work / "augmented")): p.read_bytes() for p in sorted((work / "augmented").rglob("*.JPG"))}
+        runs[mode] = (bal.completed, bal.failed, files)
+    assert runs["1"][0] == runs["0"][0] and runs["1"][1] == runs["0"][1]
+    assert runs["1"][0] >= 6 and runs["1"][1] >= 1                        # the cut file's tasks failed, the others ran
+    assert sorted(runs["1"][2]) == sorted(runs["0"][2])
+    for name, data in runs["1"][2].items():
+        assert data == runs["0"][2][name], name
+    used = {Path(n).name.split("_aug_")[0] for n in runs["1"][2] if "Apple_scab" in n and "_aug_" in n}
+    assert {"image (1)", "image (2)", "image (3)"} <= used, used          # the odd files really were sources
