@@ -232,6 +232,12 @@ int lf_jpeg_idct_rgb_u8(const void* coef, size_t coef_stride, const void* qtab, 
  * plane (srcs/preprocessing/image_augmenter.py:121-123) — from MT19937 and numpy's legacy polar Gaussian with
  * libm's log / sqrt: out64 (optional) the float64 values, bit for bit; out8 (optional) their numpy astype(uint8). */
 int lf_legacy_normal_u8(uint32_t seed, double loc, double scale, size_t n, uint8_t* out8, double* out64);
+/* The same planes for N seeds at once on the GPU (lf_noise.hip; one workgroup per plane): out + i*out_stride receives
+ * RandomState(seeds[i]).normal(loc, scale, count).astype(uint8).  flags[i] (int32, device): 0 = the plane is numpy's
+ * byte for byte; 1 = some value lay within 1e-9 of an integer, where the last bit of log() decides the cast — make
+ * that plane with lf_legacy_normal_u8; 2 = ran out of attempts (cannot happen for count >= 16; same remedy). */
+int lf_legacy_normal_batch_u8(const uint32_t* seeds, double loc, double scale, size_t count, uint8_t* out,
+                              size_t out_stride, int n, int* flags, lf_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Geometric ops (Pillow semantics, bit-exact; coordinates in IEEE double)    */

@@ -170,6 +170,23 @@ def noise_hist_u8(x: torch.Tensor, add: Optional[torch.Tensor] = None, seed: int
     return out, hist
 
 
+def legacy_normal_u8(seeds: Sequence[int], loc: float, scale: float, count: int, device) -> tuple:
+    """np.random.RandomState(seed).normal(loc, scale, count).astype(np.uint8) for every seed (0 <= seed < 2**32), made on
+    the GPU: (planes uint8 [N, count], flags int32 [N]).  flags[i] != 0: plane i may differ from numpy's in a byte (a
+    value within 1e-9 of an integer, where the last bit of log() decides the cast) — make it with
+    utils.jpeg_host.legacy_normal_u8 instead (about one 224 x 224 x 3 plane in 3,000)."""
+    if not len(seeds) or any(not 0 <= int(v) < 2 ** 32 for v in seeds) or count <= 0:
+        raise ValueError("legacy_normal: seeds must be in [0, 2**32) and count positive")
+    n = len(seeds)
+    sd = torch.from_numpy(np.asarray(seeds, dtype=np.uint32).view(np.int32)).to(device)
+    stride = (int(count) + 15) // 16 * 16
+    out = torch.empty((n, stride), dtype=_U8, device=device)
+    flags = torch.empty(n, dtype=_I32, device=device)
+    _lib.call("lf_legacy_normal_batch_u8", sd.data_ptr(), float(loc), float(scale), int(count), out.data_ptr(), stride, n,
+              flags.data_ptr(), _stream())
+    return out[:, :count], flags
+
+
 def distortion_u8(x: torch.Tensor, cutoff: torch.Tensor, add: Optional[torch.Tensor] = None, seed: int = 0,
                   sigma: float = 5.0) -> torch.Tensor:
     """ImageAugmenter.distortion on a batch (image_augmenter.py:121-131): noise add (+ histogram in the same pass),

@@ -62,8 +62,18 @@ def _warm(_i: int) -> bool:
     return True
 
 
+def copy_files(pairs: Sequence[tuple]) -> int:
+    """shutil.copy2 for a batch of (source, destination) pairs: the balancer's copy of the originals
+    (dataset_balancer.py:70-81), done by the codec workers between their other jobs."""
+    import shutil
+    for src, dst in pairs:
+        shutil.copy2(src, dst)
+    return len(pairs)
+
+
 def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
-    """jobs: (source path, transform, seed, input offset, noise offset, slot bytes[, want coefficients: 0 | 1 | 2]).
+    """jobs: (source path, transform, seed, input offset, noise offset, slot bytes[, want coefficients: 0 | 1 | 2
+    [, noise on the GPU]]).
     Returns per job ("ok", shape, params) | ("coef", shape, params) | ("scan", shape, params) | ("big", array, params)
     | ("err", message).
     "coef": the file was a baseline 4:2:0 JPEG of whole MCUs and the slot holds its quantisation tables and
@@ -104,7 +114,9 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
                 from .image_augmenter import NOISE_LEVEL
                 params = {"cutoff": random.Random(seed).uniform(0, 2)}
                 nbytes = h * w * 3
-                if nbytes <= cap:
+                if len(job) > 7 and job[7]:
+                    params["noise_seed"] = seed   # the parent has the plane made on the GPU (ops.legacy_normal_u8)
+                elif nbytes <= cap:
                     jpeg_host.legacy_normal_u8(seed, 0.0, float(NOISE_LEVEL), np.frombuffer(buf_noise, np.uint8, nbytes, noff))
                     params["noise8"] = None      # in the noise slab, at this task's slot
                 else:
@@ -243,9 +255,9 @@ class CodecPool:
         return [jobs[i:i + per] for i in range(0, len(jobs), per)]
 
     def decode(self, tasks: Sequence[dict], first_slot: int, coefficients: int = 0,
-               pieces_per_worker: int = 4) -> List[Future]:
+               pieces_per_worker: int = 4, gpu_noise: bool = False) -> List[Future]:
         jobs = [(t.get("read_img", t["source_img"]), t["transform_name"], t["seed"], (first_slot + k) * self.slot_bytes,
-                 (first_slot + k) * self.slot_bytes, self.slot_bytes, coefficients) for k, t in enumerate(tasks)]
+                 (first_slot + k) * self.slot_bytes, self.slot_bytes, coefficients, gpu_noise) for k, t in enumerate(tasks)]
         return [self.pool.submit(_decode_jobs, self.names, part) for part in self._split(jobs, pieces_per_worker)]
 
     def encode(self, jobs: List[Tuple[str, int, Tuple[int, int, int], Optional[np.ndarray]]]) -> List[Future]:

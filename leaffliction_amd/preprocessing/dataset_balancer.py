@@ -141,11 +141,44 @@ class DatasetBalancer:
         pending += [pair for files in per_dir for pair in files]
 
         self._copy_error = None
+        self._copy_boost = False
+        pool = getattr(self, "_codec", None)
 
         def fill():
+            # The bytes are copied by the codec worker processes, a batch of files per job, a few jobs in flight (as
+            # many as there are workers once the pipeline has ended): the workers have time to spare since the Huffman
+            # decoding and the noise planes went to the GPU, and a copying thread in THIS process took the interpreter
+            # lock from the thread that drives the GPU stage.  Whatever the pool does not take (it was closed, it
+            # broke, there is none) is copied here.
+            from .codec_pool import copy_files
             try:
-                for src, dst in pending:
-                    shutil.copy2(src, dst)
+                batches = [pending[b:b + 64] for b in range(0, len(pending), 64)]
+                flying: List[tuple] = []
+                nxt = 0
+                while nxt < len(batches) or flying:
+                    window = 1
+                    if pool is not None:
+                        window = pool.workers if self._copy_boost else max(1, pool.workers // 4)
+                    while nxt < len(batches) and len(flying) < window:
+                        fut = None
+                        if pool is not None:
+                            try:
+                                fut = pool.pool.submit(copy_files, batches[nxt])
+                            except Exception:  # noqa: BLE001 — shut down or broken
+                                fut = None
+                        if fut is None:
+                            copy_files(batches[nxt])
+                        else:
+                            flying.append((fut, nxt))
+                        nxt += 1
+                    if flying:
+                        fut, b = flying.pop(0)
+                        try:
+                            fut.result()
+                        except (OSError, shutil.Error):
+                            raise
+                        except BaseException:  # noqa: BLE001 — cancelled by the pool's shutdown, or the pool broke
+                            copy_files(batches[b])
             except BaseException as e:  # noqa: BLE001 — re-raised on the main thread by _join_copy
                 self._copy_error = e
 
@@ -255,6 +288,7 @@ class DatasetBalancer:
             groups.setdefault((task["transform_name"], h, w, status), []).append(k)
         jobs: List[tuple] = []
         huffman: List[tuple] = []   # (task indexes, device status of the GPU's Huffman decoding) per size
+        noise_flags: List[tuple] = []   # (task indexes, device flags of the GPU-made noise planes) per distortion group
         decoded_px: Dict[tuple, tuple] = {}   # (h, w, status) -> (pixels [m, h, w, 3] on the device, task index -> row)
         if device_path:
             # the JPEG back end once per chunk and size, not once per transform: the Huffman kernel's time is a latency
@@ -291,7 +325,14 @@ class DatasetBalancer:
                             jobs += [(chunk[k]["output_path"], (base + k) * pool.slot_bytes, (oh, ow, 3), None)
                                      for k, (oh, ow) in zip(ks, plan["sizes"])]
                             continue
-                    res = apply_batch(op, x, prm)
+                    n8 = None
+                    if op == "distortion" and all(q is not None and "noise_seed" in q and "noise8" not in q for q in prm):
+                        from .image_augmenter import NOISE_LEVEL
+                        n8, fl = ops.legacy_normal_u8([q["noise_seed"] for q in prm], 0.0, float(NOISE_LEVEL), h * w * 3,
+                                                      dev_in.device)
+                        n8 = n8.reshape(len(ks), h, w, 3)
+                        noise_flags.append((ks, fl))
+                    res = apply_batch(op, x, prm, noise8=n8)
                     if op != "rotate":
                         y = torch.stack(res)
                         # whole-MCU images bound for .jpg files leave the GPU as finished JPEG scans (colour conversion,
@@ -332,10 +373,13 @@ class DatasetBalancer:
         t_ops = time.perf_counter()
         if device_path:
             pool.tensor("out", base, n).copy_(dev_out[:n])   # synchronous: the encoders may start
-        for ks, st in huffman:
+        redo: List[int] = []
+        for ks, st in huffman + noise_flags:
             st = st.cpu().numpy()
-            if st.any():   # scans the GPU could not decode (damaged files, mostly): libjpeg has the reference's verdict
-                jobs = self._redo_on_host(chunk, [k for k, v in zip(ks, st) if v], params, pool, base, jobs)
+            if st.any():   # scans the GPU could not decode (damaged files, mostly): libjpeg has the reference's verdict;
+                redo += [k for k, v in zip(ks, st) if v and k not in redo]   # noise planes a last bit of log() could change
+        if redo:
+            jobs = self._redo_on_host(chunk, redo, params, pool, base, jobs)
         t_out = time.perf_counter()
         self.timings["gpu_stage_host_ops"] = self.timings.get("gpu_stage_host_ops", 0.0) + (t_ops - t_in)
         self.timings["gpu_stage_sync_d2h"] = self.timings.get("gpu_stage_sync_d2h", 0.0) + (t_out - t_ops)
@@ -408,11 +452,13 @@ class DatasetBalancer:
             gpu_decode = 0 if self._mirror is None else (1 if os.environ.get("LEAFFLICTION_GPU_HUFFMAN", "1") == "0" else 2)
             # chunk i + 2 is queued for decoding before chunk i goes to the GPU: the workers always have a
             # chunk's worth of work behind the one the main thread is waiting for
-            ahead = [pool.decode(chunks[0], 0, gpu_decode)]
+            # the distortion tasks' noise planes (RandomState(seed).normal: 2.6 ms of a worker's time each) on the GPU too
+            gpu_noise = self._mirror is not None and os.environ.get("LEAFFLICTION_GPU_NOISE", "1") != "0"
+            ahead = [pool.decode(chunks[0], 0, gpu_decode, gpu_noise=gpu_noise)]
             ahead[0][0].result()   # the workers are up (spawn + imports) once the first piece is back
             self.timings["codec_pool_start"] = time.perf_counter() - t0
             if len(chunks) > 1:
-                ahead.append(pool.decode(chunks[1], n_chunk, gpu_decode))
+                ahead.append(pool.decode(chunks[1], n_chunk, gpu_decode, gpu_noise=gpu_noise))
             encoding, enc_paths = [], []
             decoded = jobs = None
             tw = {"wait_decode": 0.0, "gpu_stage": 0.0, "wait_encode": 0.0}
@@ -422,7 +468,7 @@ class DatasetBalancer:
                 ta = time.perf_counter()
                 decoded = [r for f in ahead.pop(0) for r in f.result()]
                 if i + 2 < len(chunks):
-                    ahead.append(pool.decode(chunks[i + 2], ((i + 2) % RING) * n_chunk, gpu_decode))
+                    ahead.append(pool.decode(chunks[i + 2], ((i + 2) % RING) * n_chunk, gpu_decode, gpu_noise=gpu_noise))
                 tb = time.perf_counter()
                 jobs = self._gpu_stage(chunk, decoded, pool, (i % RING) * n_chunk)
                 tc = time.perf_counter()
@@ -437,6 +483,14 @@ class DatasetBalancer:
                     logger.info(f"Progress (rank {self.ranks.rank}): {done}/{len(share)} of this share "
                                 f"({total} tasks in all) - {self.completed} success, {self.failed} failed")
             self._collect(encoding, enc_paths)
+            # what is left of the originals' copy now has every worker (the thread is joined, and its failure raised,
+            # by _join_copy)
+            tj = time.perf_counter()
+            self._copy_boost = True
+            t = getattr(self, "_copying", None)
+            if t is not None:
+                t.join()
+            self.timings["copy_originals_tail"] = time.perf_counter() - tj
         finally:
             decoded = jobs = None   # the last views of the slabs
             self._mirror = None
@@ -492,7 +546,7 @@ class DatasetBalancer:
         streams = (random.getstate(), np.random.get_state())
         t2 = time.perf_counter()
         self._run_share(self.tasks[begin:end], total)
-        self.timings["decode_kernels_encode"] = time.perf_counter() - t2
+        self.timings["decode_kernels_encode"] = time.perf_counter() - t2 - self.timings.get("copy_originals_tail", 0.0)
         random.setstate(streams[0])
         np.random.set_state(streams[1])
         self.completed, self.failed = rk.sum_ints([self.completed, self.failed])
@@ -500,7 +554,7 @@ class DatasetBalancer:
         logger.info(f"Augmentation complete: {self.completed} images generated, {self.failed} failed")
         t3 = time.perf_counter()
         self._join_copy()
-        self.timings["copy_originals_tail"] = time.perf_counter() - t3
+        self.timings["copy_originals_tail"] = self.timings.get("copy_originals_tail", 0.0) + time.perf_counter() - t3
         rk.barrier()
         t3 = time.perf_counter()
         if rk.rank == 0:

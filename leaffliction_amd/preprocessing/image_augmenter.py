@@ -53,9 +53,10 @@ def draw_params(op: str, width: int, height: int, py_rng=random, np_rng=np.rando
     raise AttributeError(op)
 
 
-def apply_batch(op: str, x, params: Sequence[Dict[str, Any]]) -> List:
+def apply_batch(op: str, x, params: Sequence[Dict[str, Any]], noise8=None) -> List:
     """Run `op` on a same-sized device batch x [N,H,W,3] u8.  Returns a list of N device
-    tensors [h_i, w_i, 3] (rotate changes the size, the others keep it)."""
+    tensors [h_i, w_i, 3] (rotate changes the size, the others keep it).  `noise8` (distortion): the batch's
+    noise planes already on the device, uint8 [N,H,W,3] (ops.legacy_normal_u8)."""
     import torch
 
     from .. import ops
@@ -72,6 +73,14 @@ def apply_batch(op: str, x, params: Sequence[Dict[str, Any]]) -> List:
         return list(ops.crop_resize_lanczos_u8(x, [p["box"] for p in params]))
     if op == "distortion":
         cutoff = torch.tensor([p["cutoff"] for p in params], dtype=torch.float64, device=dev)
+        if noise8 is not None:
+            return list(ops.distortion_u8(x, cutoff, add=noise8))
+        if "noise_seed" in params[0] and "noise8" not in params[0]:
+            # the planes were left to the GPU by the codec workers and the caller has none: made here on the host
+            from ..utils import jpeg_host
+            for p in params:
+                p["noise8"] = np.empty(tuple(x.shape[1:]), np.uint8)
+                jpeg_host.legacy_normal_u8(int(p["noise_seed"]), 0.0, float(NOISE_LEVEL), p["noise8"])
         if "noise8" in params[0]:   # the codec workers cast the noise to uint8 (numpy's own astype)
             if all(isinstance(p["noise8"], torch.Tensor) for p in params):
                 # views of the page-locked noise slab: one asynchronous copy per task, no stacking on the host

@@ -395,3 +395,28 @@ def test_gathers_stay_inside_a_batch_that_ends_its_allocation(cuda):
     boxes = [(3, 2, 110, 80), (0, 0, 102, 77), (18, 16, 110, 80), (5, 9, 120, 86)]
     assert torch.equal(ops.crop_resize_lanczos_u8(tail, boxes), ops.crop_resize_lanczos_u8(mid, boxes))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("count", [1, 2, 7, 1000, 224 * 224 * 3])
+def test_legacy_normal_planes_are_numpys(cuda, count):
+    """ops.legacy_normal_u8 == np.random.RandomState(seed).normal(0, 5, n).astype(np.uint8) (image_augmenter.py:121-123),
+    byte for byte, for every plane the kernel does not flag (a flag = a value within 1e-9 of an integer: the caller has
+    that plane made on the host); flags are rare."""
+    import torch
+    from leaffliction_amd import ops
+    seeds = [0, 1, 42, 123456, 999999, 2 ** 31, 2 ** 32 - 1] + list(range(1000, 1030))
+    planes, flags = ops.legacy_normal_u8(seeds, 0.0, 5.0, count, cuda)
+    planes, flags = planes.cpu().numpy(), flags.cpu().numpy()
+    assert planes.shape == (len(seeds), count)
+    assert (flags != 0).sum() <= 1 and not (flags == 2).any(), flags
+    for i, sd in enumerate(seeds):
+        if flags[i] == 0:
+            want = np.random.RandomState(sd).normal(0, 5, count).astype(np.uint8)
+            assert np.array_equal(planes[i], want), (sd, np.flatnonzero(planes[i] != want)[:5])
+    # another location / scale
+    p2, f2 = ops.legacy_normal_u8([7, 8], 100.0, 20.0, 5000, cuda)
+    for i, sd in enumerate([7, 8]):
+        if int(f2[i]) == 0:
+            assert np.array_equal(p2[i].cpu().numpy(), np.random.RandomState(sd).normal(100.0, 20.0, 5000).astype(np.uint8))
+    with pytest.raises(ValueError):
+        ops.legacy_normal_u8([2 ** 32], 0.0, 5.0, 10, cuda)

@@ -465,8 +465,9 @@ def test_balancer_with_the_gpu_huffman_decoder_equals_the_host_decoded_run(cuda,
     (d / "image (3).JPG").write_bytes(whole[:len(whole) // 2] + whole[-2:])     # half the scan gone, EOI in place
     (d / "image (4).JPG").write_bytes(jpeg(953)[:-900])                           # cut short
     runs = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "0"):   # "0": the codec workers also make the distortion tasks' noise planes (numpy's stream on the host)
         monkeypatch.setenv("LEAFFLICTION_GPU_HUFFMAN", mode)
+        monkeypatch.setenv("LEAFFLICTION_GPU_NOISE", mode)
         work = tmp_path / f"run{mode}"
         work.mkdir()
         monkeypatch.chdir(work)

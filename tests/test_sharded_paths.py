@@ -264,32 +264,40 @@ def test_balancer_two_ranks_equal_one_rank_gpu(cuda, tmp_path):
 
 # ------------------------------------------------------------------ failure paths of the job's preparation
 def test_a_failed_copy_of_the_originals_fails_the_job(tmp_path, monkeypatch):
-    """The originals' bytes follow on a thread behind the pipeline; when that copy fails (disk full, a source file
-    gone) the job must raise as the reference's copytree would (dataset_balancer.py:70-81), not report success over
-    a tree of zero-byte placeholders."""
-    import shutil as _sh
+    """The originals' bytes follow behind the pipeline (copied by the codec worker processes); when that copy fails
+    (disk full, a source file gone) the job must raise as the reference's copytree would (dataset_balancer.py:70-81),
+    not report success over a tree of zero-byte placeholders.  Here one source entry is a link to nothing: its
+    placeholder can be laid out, its bytes cannot be copied — the failure happens in a worker process and has to
+    travel back to the thread that raises it."""
     src = tmp_path / "images"
     build_tree(src, 16)
+    leaf = next(p for p in sorted(src.rglob("*")) if p.is_dir() and not any(c.is_dir() for c in p.iterdir()))
+    os.symlink(str(tmp_path / "nowhere.JPG"), str(leaf / "image (99).JPG"))
     bal = OracleBalancer(source_dir=str(src), target_dir=str(tmp_path / "aug"), seed=1, workers=1)
-    real = _sh.copy2
-    seen = []
-
-    def flaky(a, b, **kw):
-        seen.append(a)
-        if len(seen) == 3:
-            raise OSError(28, "No space left on device")
-        return real(a, b, **kw)
-
-    monkeypatch.setattr(_sh, "copy2", flaky)
     os.chdir(tmp_path)
     os.environ["CUDA_VISIBLE_DEVICES"] = ""
     try:
-        with pytest.raises(OSError, match="No space left"):
+        with pytest.raises(OSError, match=r"image \(99\)"):
             bal.run()
     finally:
         os.environ.pop("CUDA_VISIBLE_DEVICES", None)
     assert bal._codec is None
     assert not (tmp_path / "artifacts/datasets/manifest_augmented.json").exists()   # no manifest of a broken tree
+
+
+def test_the_copy_of_the_originals_survives_a_pool_that_is_gone(tmp_path):
+    """Batches the codec pool does not take (it was shut down under the copying thread, as after a failed pipeline)
+    are copied by the thread itself: the tree is complete."""
+    from leaffliction_amd.preprocessing.codec_pool import CodecPool
+    src = tmp_path / "images"
+    build_tree(src, 16)
+    bal = OracleBalancer(source_dir=str(src), target_dir=str(tmp_path / "aug"), seed=1, workers=1)
+    bal._codec = CodecPool(1)
+    bal._codec.close()
+    bal._fresh_target()
+    bal._join_copy()
+    for p in src.rglob("*.JPG"):
+        assert (tmp_path / "aug" / p.relative_to(src)).read_bytes() == p.read_bytes()
 
 
 def _broken_prep_worker(rank, world, port, src, dst, work):
