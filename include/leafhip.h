@@ -43,6 +43,12 @@ int lf_version(void);
 /* Thread-local description of the last error returned on this thread ("" if none). */
 const char* lf_last_error(void);
 
+/* The first `width` bytes of `rows` rows between a page-locked host slab and its device mirror (asynchronous on
+ * `stream`; to_host: 1 = device -> host, 0 = host -> device): the balancer moves the used front of each fixed-size
+ * slot, not the slot (dataset_balancer.py's pixels never left host memory; here they cross PCIe twice). */
+int lf_copy_rows(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows, int to_host,
+                 lf_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* A1 — augmentation / input side (uint8, bit-exact)                          */
 /* ------------------------------------------------------------------------- */

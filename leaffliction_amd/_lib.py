@@ -48,6 +48,7 @@ SIGNATURES = {
     "lf_jpeg_wrap_scan": [P, c_size_t, c_int, c_int, c_int, P, c_size_t],
     "lf_legacy_normal_u8": [C.c_uint32, c_double, c_double, c_size_t, P, P],
     "lf_jpeg_decode_workspace": [c_int, c_int, c_int],
+    "lf_copy_rows": [P, c_size_t, P, c_size_t, c_size_t, c_size_t, c_int, P],
     "lf_legacy_normal_batch_u8": [P, C.c_double, C.c_double, c_size_t, P, c_size_t, c_int, P, P],
     "lf_jpeg_scan_aux_offset": [c_int, c_int],
     "lf_jpeg_scan_prepare": [P, c_size_t, P, c_size_t, P, P, P],

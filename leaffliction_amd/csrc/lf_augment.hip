@@ -1329,3 +1329,16 @@ int lf_gauss_blur_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int c
 }
 
 }  // extern "C"
+
+extern "C" int lf_copy_rows(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows,
+                            int to_host, lf_stream_t stream) {
+    LF_REQUIRE(dst && src, "lf_copy_rows: null buffer");
+    LF_REQUIRE(width > 0 && rows > 0 && width <= dst_pitch && width <= src_pitch, "lf_copy_rows: bad extent");
+    const hipError_t e = hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, rows,
+                                          to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, lf::as_stream(stream));
+    if (e != hipSuccess) {
+        lf::set_error("lf_copy_rows: %s", hipGetErrorString(e));
+        return LF_ERR_LAUNCH;
+    }
+    return LF_OK;
+}

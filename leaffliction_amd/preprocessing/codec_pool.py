@@ -79,7 +79,7 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
     "coef": the file was a baseline 4:2:0 JPEG of whole MCUs and the slot holds its quantisation tables and
     Huffman-decoded coefficients (libleafcodec.so); the GPU finishes the decoding (ops.jpeg_idct_rgb_u8).
     "scan" (asked for with 2): only the file's markers were read here; the slot holds the tables and the un-stuffed
-    scan, and the Huffman decoding is the GPU's as well (ops.jpeg_huffman_u8)."""
+    scan, and the Huffman decoding is the GPU's as well (ops.jpeg_huffman_u8); shape = (h, w, 3, bytes of the slot in use)."""
     from ..utils import jpeg_host
     from ..utils.image_utils import ImageLoader, _checked
     from .image_augmenter import draw_params
@@ -96,11 +96,11 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
                 dst = np.frombuffer(buf_in, np.uint8, cap, off)
                 if job[6] == 2:
                     got = jpeg_host.scan_prepare_into(data, dst)
-                    scan_hw = got[:2] if got is not None else None
+                    scan_hw = (got[0], got[1], got[3]) if got is not None else None
                 if scan_hw is None:
                     coef_hw = jpeg_host.read_file_into(data, dst)
             if scan_hw is not None:
-                h, w = scan_hw
+                h, w = scan_hw[:2]
             elif coef_hw is None:
                 arr = ImageLoader.load_as_array(path)
                 h, w, _c = arr.shape
@@ -133,7 +133,8 @@ def _decode_jobs(names: Dict[str, str], jobs: Sequence[tuple]):
                     else:
                         params["noise8"] = n8
             if arr is None:
-                out.append(("scan" if scan_hw is not None else "coef", (h, w, 3), params))
+                # a prepared scan: the shape and, fourth, how much of the slot is in use (the parent uploads only that)
+                out.append(("scan", (h, w, 3, scan_hw[2]), params) if scan_hw is not None else ("coef", (h, w, 3), params))
             elif arr.nbytes <= cap:
                 np.frombuffer(buf_in, np.uint8, arr.nbytes, off)[:] = arr.reshape(-1)
                 out.append(("ok", arr.shape, params))

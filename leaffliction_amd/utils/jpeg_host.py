@@ -80,15 +80,20 @@ def read_file_into(data: bytes, dst: np.ndarray):
 
 def scan_prepare_into(data: bytes, dst: np.ndarray):
     """Markers only: leave a baseline 4:2:0 file ready for the GPU's Huffman decoder (ops.jpeg_huffman_u8) in `dst`
-    (uint8 view of a slab slot; layout in csrc/lf_jpeg_host.cpp).  Returns (h, w, hash of the file's Huffman tables),
-    or None when the file is to be decoded on the host (read_file_into, then libjpeg) or does not fit."""
+    (uint8 view of a slab slot; layout in csrc/lf_jpeg_host.cpp).  Returns (h, w, hash of the file's Huffman tables,
+    first byte of the slot behind what was written), or None when the file is to be decoded on the host
+    (read_file_into, then libjpeg) or does not fit."""
     lib = load()
     if dst.dtype != np.uint8 or not dst.flags["C_CONTIGUOUS"]:
         return None
     h, w, hh = C.c_int(0), C.c_int(0), C.c_uint64(0)
     buf = np.frombuffer(data, dtype=np.uint8)
     rc = lib.lf_jpeg_scan_prepare(buf.ctypes.data, buf.size, dst.ctypes.data, dst.size, C.byref(h), C.byref(w), C.byref(hh))
-    return (h.value, w.value, hh.value) if rc == 0 else None
+    if rc != 0:
+        return None
+    aux = int(lib.lf_jpeg_scan_aux_offset(h.value, w.value))
+    data_off, data_len = (int(v) for v in dst[aux + 24:aux + 32].view(np.uint32))
+    return h.value, w.value, hh.value, aux + data_off + data_len + 16
 
 
 def scan_aux_offset(h: int, w: int) -> int:

@@ -15,6 +15,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
+# LF_MODES="1:1:,0:0:" = (GPU Huffman, GPU noise, extra environment K=V[,K=V]) per run
+VARIANTS = [tuple(v.split(":")) for v in os.environ.get("LF_MODES", "1:1:,0:0:").split(";") if v] if os.environ.get("LF_MODES") \
+    else [("1", "1", ""), ("0", "0", "")]
+
 if __name__ == "__main__":
     from leaffliction_amd.preprocessing.dataset_balancer import DatasetBalancer
     from leaffliction_amd.utils.system_info import get_available_cores
@@ -27,9 +31,11 @@ if __name__ == "__main__":
         bench._e2e_make_dataset(src, dev, cores, bench._e2e_layout(generated))
         os.chdir(tmp)
         for rep in range(int(os.environ.get("LF_MODES_REPS", "1"))):
-            for mode, noise in (("1", "1"), ("0", "0")):   # more runs than two fill the box's page cache with dirty files
+            for mode, noise, extra in VARIANTS:   # (many runs fill the box's page cache with dirty files)
                 os.environ["LEAFFLICTION_GPU_HUFFMAN"] = mode
                 os.environ["LEAFFLICTION_GPU_NOISE"] = noise
+                for kv in extra.split(",") if extra else []:
+                    os.environ[kv.split("=")[0]] = kv.split("=")[1]
                 dst = tmp / "augmented"
                 bal = DatasetBalancer(source_dir=str(src), target_dir=str(dst), seed=42, workers=cores)
                 bal.analyze_distribution()
@@ -39,7 +45,7 @@ if __name__ == "__main__":
                 bal.execute_balancing()
                 sec = time.perf_counter() - t0
                 pipe = bal.timings.get("decode_kernels_encode", sec) - bal.timings.get("codec_pool_start", 0.0)
-                print(json.dumps({"gpu_huffman": mode, "gpu_noise": noise, "rep": rep, "images_per_sec": round(bal.completed / sec, 1),
+                print(json.dumps({"gpu_huffman": mode, "gpu_noise": noise, "extra": extra, "rep": rep, "images_per_sec": round(bal.completed / sec, 1),
                                   "pipeline_images_per_sec": round(bal.completed / pipe, 1), "failed": bal.failed,
                                   "seconds": round(sec, 2),
                                   "stage_seconds": {k: round(v, 2) for k, v in bal.timings.items()}}), flush=True)
