@@ -62,6 +62,14 @@ def _warm(_i: int) -> bool:
     return True
 
 
+def touch_files(paths: Sequence[str]) -> int:
+    """Empty files, in order (the balancer lays the target tree out before the bytes follow)."""
+    import os
+    for dst in paths:
+        os.close(os.open(dst, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666))
+    return len(paths)
+
+
 def copy_files(pairs: Sequence[tuple]) -> int:
     """shutil.copy2 for a batch of (source, destination) pairs: the balancer's copy of the originals
     (dataset_balancer.py:70-81), done by the codec workers between their other jobs."""
@@ -262,7 +270,7 @@ class CodecPool:
         return [self.pool.submit(_decode_jobs, self.names, part) for part in self._split(jobs, pieces_per_worker)]
 
     def encode(self, jobs: List[Tuple[str, int, Tuple[int, int, int], Optional[np.ndarray]]]) -> List[Future]:
-        return [self.pool.submit(_encode_jobs, self.names, part) for part in self._split(jobs)]
+        return [self.pool.submit(_encode_jobs, self.names, part) for part in self._split(jobs, 2)]
 
     def close(self) -> None:
         """Stop the workers and WAIT for them, then take the slabs down.

@@ -37,7 +37,7 @@ from ..utils.system_info import get_available_cores, get_optimal_worker_count
 
 logger = get_logger(__name__)
 
-CHUNK = 256  # tasks per GPU round
+CHUNK = int(os.environ.get("LEAFFLICTION_CHUNK", "256"))  # tasks per GPU round
 RING = 4    # chunks of slots: two decoding ahead, one on the GPU, one encoding
 JPEG_QUALITY = 95  # ImageLoader.save_pil_image's default (srcs/utils/image_utils.py:50)
 
@@ -133,9 +133,25 @@ class DatasetBalancer:
             for _src, dst in files:
                 touch(dst)
 
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=8) as ex:
-            list(ex.map(lay, per_dir))
+        laid = False
+        starting = getattr(self, "_codec", None)
+        if starting is not None and len(per_dir) > 1:
+            # one job per leaf directory for the codec workers that are starting up anyway: processes create files side
+            # by side, threads of this one mostly take turns at the interpreter lock
+            from .codec_pool import touch_files
+            try:
+                futs = [starting.pool.submit(touch_files, [dst for _src, dst in files]) for files in per_dir]
+                for f in futs:
+                    f.result()
+                laid = True
+            except OSError:
+                raise
+            except Exception:  # noqa: BLE001 — no usable pool: the threads below
+                laid = False
+        if not laid:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=8) as ex:
+                list(ex.map(lay, per_dir))
         for src, dst in reversed(dirs):   # copytree copies a directory's stat once its entries are in place
             shutil.copystat(src, dst)
         pending += [pair for files in per_dir for pair in files]
@@ -513,11 +529,14 @@ class DatasetBalancer:
             # chunk's worth of work behind the one the main thread is waiting for
             # the distortion tasks' noise planes (RandomState(seed).normal: 2.6 ms of a worker's time each) on the GPU too
             gpu_noise = self._mirror is not None and os.environ.get("LEAFFLICTION_GPU_NOISE", "1") != "0"
-            ahead = [pool.decode(chunks[0], 0, gpu_decode, gpu_noise=gpu_noise)]
+            # pieces per worker: four while a piece may hold several distortion tasks whose noise the worker makes, one
+            # when all the workers do per task is read a file and its markers (every future costs the parent ~20 us)
+            pieces = 1 if gpu_noise and gpu_decode == 2 else 4
+            ahead = [pool.decode(chunks[0], 0, gpu_decode, pieces, gpu_noise=gpu_noise)]
             ahead[0][0].result()   # the workers are up (spawn + imports) once the first piece is back
             self.timings["codec_pool_start"] = time.perf_counter() - t0
             if len(chunks) > 1:
-                ahead.append(pool.decode(chunks[1], n_chunk, gpu_decode, gpu_noise=gpu_noise))
+                ahead.append(pool.decode(chunks[1], n_chunk, gpu_decode, pieces, gpu_noise=gpu_noise))
             encoding, enc_paths = [], []
             decoded = jobs = None
             tw = {"wait_decode": 0.0, "gpu_stage": 0.0, "wait_encode": 0.0}
@@ -527,7 +546,7 @@ class DatasetBalancer:
                 ta = time.perf_counter()
                 decoded = [r for f in ahead.pop(0) for r in f.result()]
                 if i + 2 < len(chunks):
-                    ahead.append(pool.decode(chunks[i + 2], ((i + 2) % RING) * n_chunk, gpu_decode, gpu_noise=gpu_noise))
+                    ahead.append(pool.decode(chunks[i + 2], ((i + 2) % RING) * n_chunk, gpu_decode, pieces, gpu_noise=gpu_noise))
                 tb = time.perf_counter()
                 jobs = self._gpu_stage(chunk, decoded, pool, (i % RING) * n_chunk)
                 tc = time.perf_counter()
