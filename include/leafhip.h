@@ -201,6 +201,22 @@ size_t lf_jpeg_entropy_workspace(int n, size_t out_stride);
 int lf_jpeg_entropy_u8(const void* coef, size_t coef_stride, uint8_t* out, size_t out_stride, int n, int h,
                        int w, void* workspace, size_t ws_bytes, lf_stream_t stream);
 long lf_jpeg_wrap_scan(const uint8_t* scan, size_t scan_len, int h, int w, int quality, uint8_t* out, size_t cap);
+/* The same two GPU steps for images of DIFFERENT sizes in one launch each (the balancer's rotated canvases: a rotation
+ * with expand=True gives every output its own size; dataset_balancer.py:201-207 saves each with Image.save):
+ * items[i] (device memory) = where image i's pixels start in rgb_base (bytes; any alignment), where its coefficients
+ * go in coef_base (int16 elements, a multiple of 8), where its scan goes in out_base (bytes, a multiple of 4; the same
+ * place as its pixels is fine: the coefficients are complete before the scan is written), the number of the first of
+ * its lf_jpeg_fdct_groups(h, w) passes (running sum over the images before it), its size, and 6 x its MCUs.
+ * out_room: the bytes each scan may take (int32 length first, -1 when it did not fit), as out_stride above. */
+typedef struct {
+    int64_t rgb_off, coef_off, out_off, group_start;
+    int32_t h, w, nblocks, reserved;
+} lf_jpeg_item;
+long lf_jpeg_fdct_groups(int h, int w);
+int lf_jpeg_fdct_quant_items_u8(const uint8_t* rgb_base, int16_t* coef_base, const lf_jpeg_item* items, int n,
+                                long total_groups, int quality, lf_stream_t stream);
+int lf_jpeg_entropy_items_u8(const void* coef_base, const lf_jpeg_item* items, uint8_t* out_base, size_t out_room, int n,
+                             void* workspace, size_t ws_bytes, lf_stream_t stream);
 /* Decoding, the same split the other way round (Image.open(path).convert("RGB"), image_utils.py:19-33 — the
  * balancer's input step and the loader's):
  * lf_jpeg_read_file (HOST, also in libleafcodec.so): markers + Huffman decoding of a baseline 4:2:0 file of

@@ -46,6 +46,9 @@ SIGNATURES = {
     "lf_jpeg_entropy_workspace": [c_int, c_size_t],
     "lf_jpeg_entropy_u8": [P, c_size_t, P, c_size_t, c_int, c_int, c_int, P, c_size_t, P],
     "lf_jpeg_wrap_scan": [P, c_size_t, c_int, c_int, c_int, P, c_size_t],
+    "lf_jpeg_fdct_groups": [c_int, c_int],
+    "lf_jpeg_fdct_quant_items_u8": [P, P, P, c_int, C.c_long, c_int, P],
+    "lf_jpeg_entropy_items_u8": [P, P, P, c_size_t, c_int, P, c_size_t, P],
     "lf_legacy_normal_u8": [C.c_uint32, c_double, c_double, c_size_t, P, P],
     "lf_jpeg_decode_workspace": [c_int, c_int, c_int],
     "lf_copy_rows": [P, c_size_t, P, c_size_t, c_size_t, c_size_t, c_int, P],
@@ -135,7 +138,7 @@ _RESTYPES = {"lf_last_error": C.c_char_p, "lf_conv2d_wgrad_workspace": c_size_t,
              "lf_blur_saliency_workspace": c_size_t, "lf_inclusive_mask_workspace": c_size_t, "lf_conv2d_bf16_weight_elems": c_size_t,
              "lf_conv2d_bf16_act_mean_workspace": c_size_t,
              "lf_conv2d_bf16_stats_tiles": C.c_longlong, "lf_conv2d_wgrad_bf16_workspace": c_size_t,
-             "lf_jpeg_file_bound": c_size_t, "lf_jpeg_scan_aux_offset": c_size_t, "lf_jpeg_entropy_workspace": c_size_t, "lf_jpeg_wrap_scan": C.c_long, "lf_jpeg_decode_workspace": c_size_t, "lf_jpeg_write_file": C.c_long, "lf_jpeg_quant_tables": None}
+             "lf_jpeg_file_bound": c_size_t, "lf_jpeg_scan_aux_offset": c_size_t, "lf_jpeg_entropy_workspace": c_size_t, "lf_jpeg_wrap_scan": C.c_long, "lf_jpeg_fdct_groups": C.c_long, "lf_jpeg_decode_workspace": c_size_t, "lf_jpeg_write_file": C.c_long, "lf_jpeg_quant_tables": None}
 
 
 class LeafHipError(RuntimeError):

@@ -57,10 +57,14 @@ __device__ __forceinline__ void fdct8(int* d) {
 // full resolution, before the chroma box filter) and downwards (the last luminance row; the last chroma row), and
 // luminance blocks wholly outside the image turned into dummies (no AC, the DC of the previous block of their MCU;
 // jccoefct.c compress_data).  Byte loads instead of 12-byte groups: rows are not 4-byte aligned.
-template <bool RAGGED>
-__global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __restrict__ rgb,
-                                                             int16_t* __restrict__ coef, int h, int w, int n_images,
-                                                             JpegQuant q) {
+// MULTI: images of different sizes in one launch (the balancer's rotated canvases): `items` (device) gives every
+// image its place in the pixel buffer and in the coefficient buffer, its size and the number of the first of its
+// (MCU row, group of kGroup MCUs) passes; a pass finds its image by bisection.
+template <bool RAGGED, bool MULTI = false>
+__global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __restrict__ rgb0,
+                                                             int16_t* __restrict__ coef0, int h0, int w0, int n_images,
+                                                             JpegQuant q, const lf_jpeg_item* __restrict__ items = nullptr,
+                                                             long total_groups = 0) {
     __shared__ __attribute__((aligned(16))) uint8_t sy[16][16 * kGroup], scb[16][16 * kGroup], scr[16][16 * kGroup];
     __shared__ uint8_t sc[2][8][8 * kGroup];
     __shared__ int mid[6 * kGroup][64];
@@ -73,13 +77,36 @@ __global__ __launch_bounds__(kT) void jpeg_fdct_quant_kernel(const uint8_t* __re
         sdiv[1][tid] = q.div[1][tid];
         spos[tid] = q.pos[tid];
     }
-    const int mcu_w = (w + 15) / 16, mcu_h = (h + 15) / 16, gw = (mcu_w + kGroup - 1) / kGroup;
-    const long groups = (long)n_images * mcu_h * gw;
-    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+    int h = h0, w = w0;
+    const uint8_t* rgb = rgb0;
+    int16_t* coef = coef0;
+    int mcu_w = (w + 15) / 16, mcu_h = (h + 15) / 16, gw = (mcu_w + kGroup - 1) / kGroup;
+    const long groups = MULTI ? total_groups : (long)n_images * mcu_h * gw;
+    for (long g0 = blockIdx.x; g0 < groups; g0 += gridDim.x) {
+        long g = g0;
+        if (MULTI) {
+            int lo = 0, hi = n_images - 1;
+            while (lo < hi) {
+                const int m = (lo + hi + 1) >> 1;
+                if (items[m].group_start <= g0)
+                    lo = m;
+                else
+                    hi = m - 1;
+            }
+            const lf_jpeg_item it = items[lo];
+            h = it.h;
+            w = it.w;
+            rgb = rgb0 + it.rgb_off;
+            coef = coef0 + it.coef_off;
+            mcu_w = (w + 15) / 16;
+            mcu_h = (h + 15) / 16;
+            gw = (mcu_w + kGroup - 1) / kGroup;
+            g = g0 - it.group_start;
+        }
         const int gx = (int)(g % gw);
         const long t1 = g / gw;
         const int my = (int)(t1 % mcu_h);
-        const size_t n = (size_t)(t1 / mcu_h);
+        const size_t n = MULTI ? 0 : (size_t)(t1 / mcu_h);
         const int mx0 = gx * kGroup, nm = min(kGroup, mcu_w - mx0);
         __syncthreads();   // the previous pass is done with the planes; the tables are in place
         {   // ---- four pixels per thread: RGB -> Y, Cb, Cr (jccolor.c, SCALEBITS 16)
@@ -453,15 +480,18 @@ __device__ __forceinline__ unsigned wg_exclusive_scan(unsigned v, unsigned* lds,
 
 __global__ __launch_bounds__(kEB) void jpeg_entropy_kernel(const uint8_t* __restrict__ coef_base, size_t coef_stride,
                                                            uint32_t* __restrict__ tmp, size_t tmp_words,
-                                                           uint8_t* __restrict__ out, size_t out_stride, int nblocks,
-                                                           HuffTab tab) {
+                                                           uint8_t* __restrict__ out, size_t out_stride, int nblocks0,
+                                                           HuffTab tab, const lf_jpeg_item* __restrict__ items = nullptr) {
     __shared__ uint32_t sdc[2][16], sac[2][256];
     __shared__ unsigned scan[kEB];
     const int tid = threadIdx.x;
     const size_t n = blockIdx.x;
-    const int16_t* coef = reinterpret_cast<const int16_t*>(coef_base + n * coef_stride);
+    // items: every image its own size and places (out_stride is then the room each image's scan may take)
+    const int16_t* coef = items ? reinterpret_cast<const int16_t*>(coef_base) + items[n].coef_off
+                                : reinterpret_cast<const int16_t*>(coef_base + n * coef_stride);
+    const int nblocks = items ? items[n].nblocks : nblocks0;
     uint32_t* tw = tmp + n * tmp_words;
-    uint8_t* orow = out + n * out_stride;
+    uint8_t* orow = items ? out + items[n].out_off : out + n * out_stride;
     if (tid < 32) sdc[tid >> 4][tid & 15] = tab.dc[tid >> 4][tid & 15];
     for (int i = tid; i < 512; i += kEB) sac[i >> 8][i & 255] = tab.ac[i >> 8][i & 255];
     for (size_t i = tid; i < tmp_words; i += kEB) tw[i] = 0u;
@@ -555,6 +585,53 @@ int lf_jpeg_entropy_u8(const void* coef, size_t coef_stride, uint8_t* out, size_
                                                              static_cast<uint32_t*>(workspace), (out_stride + 3) / 4, out,
                                                              out_stride, nblocks, tab);
     return lf::check_launch("lf_jpeg_entropy");
+}
+
+long lf_jpeg_fdct_groups(int h, int w) {
+    if (h <= 0 || w <= 0) return 0;
+    return (long)((h + 15) / 16) * (((w + 15) / 16 + kGroup - 1) / kGroup);
+}
+
+int lf_jpeg_fdct_quant_items_u8(const uint8_t* rgb_base, int16_t* coef_base, const lf_jpeg_item* items, int n,
+                                long total_groups, int quality, lf_stream_t stream) {
+    LF_REQUIRE(rgb_base && coef_base && items, "lf_jpeg_fdct_quant_items: null buffer");
+    LF_REQUIRE(n > 0 && total_groups > 0, "lf_jpeg_fdct_quant_items: nothing to do");
+    LF_REQUIRE(quality >= 1 && quality <= 100, "lf_jpeg_fdct_quant_items: quality %d", quality);
+    LF_REQUIRE((reinterpret_cast<size_t>(coef_base) & 15) == 0, "lf_jpeg_fdct_quant_items: coef must be 16-byte aligned");
+    JpegQuant q;
+    uint8_t tabs[2][64];
+    lf_jpeg_quant_tables(quality, tabs[0], tabs[1]);
+    static const uint8_t natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                        41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                        30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    for (int i = 0; i < 64; ++i) {
+        q.div[0][i] = (uint16_t)(tabs[0][i] << 3);
+        q.div[1][i] = (uint16_t)(tabs[1][i] << 3);
+        q.pos[natural[i]] = (uint8_t)i;
+    }
+    const unsigned grid = (unsigned)(total_groups < 256 * 16 ? total_groups : 256 * 16);
+    jpeg_fdct_quant_kernel<true, true><<<grid, kT, 0, lf::as_stream(stream)>>>(rgb_base, coef_base, 0, 0, n, q, items,
+                                                                               total_groups);
+    return lf::check_launch("lf_jpeg_fdct_quant_items");
+}
+
+int lf_jpeg_entropy_items_u8(const void* coef_base, const lf_jpeg_item* items, uint8_t* out_base, size_t out_room, int n,
+                             void* workspace, size_t ws_bytes, lf_stream_t stream) {
+    LF_REQUIRE(coef_base && items && out_base && workspace, "lf_jpeg_entropy_items: null buffer");
+    LF_REQUIRE(n > 0 && n <= 1 << 20, "lf_jpeg_entropy_items: bad batch size %d", n);
+    LF_REQUIRE(out_room >= 1024 && out_room % 4 == 0 && (reinterpret_cast<size_t>(out_base) & 3) == 0,
+               "lf_jpeg_entropy_items: output places are 4-byte aligned and at least 1 KiB");
+    LF_REQUIRE(ws_bytes >= lf_jpeg_entropy_workspace(n, out_room) && (reinterpret_cast<size_t>(workspace) & 3) == 0,
+               "lf_jpeg_entropy_items: workspace too small");
+    static const HuffTab tab = []() {
+        HuffTab t;
+        lf_jpeg_std_huffman(&t.dc[0][0], &t.ac[0][0]);
+        return t;
+    }();
+    jpeg_entropy_kernel<<<n, kEB, 0, lf::as_stream(stream)>>>(static_cast<const uint8_t*>(coef_base), 0,
+                                                             static_cast<uint32_t*>(workspace), (out_room + 3) / 4,
+                                                             out_base, out_room, 0, tab, items);
+    return lf::check_launch("lf_jpeg_entropy_items");
 }
 
 size_t lf_jpeg_decode_workspace(int n, int h, int w) {

@@ -348,6 +348,40 @@ def jpeg_entropy_u8(coef: torch.Tensor, h: int, w: int, out: Optional[torch.Tens
     return out
 
 
+def jpeg_encode_items_u8(buf: torch.Tensor, items: Sequence[Sequence[int]], room: int, quality: int = 95) -> None:
+    """Image.save(path, quality=q) up to the markers for images of DIFFERENT sizes lying in one flat uint8 device buffer
+    (the balancer's rotated canvases in their slots of the output mirror), two launches for all of them: items[i] =
+    (byte offset of image i's pixels, h, w); the finished scan (int32 length, then the bytes; -1 when it does not fit
+    `room` bytes) REPLACES the pixels at the same offset (a multiple of 4).  utils.jpeg_host.wrap_scan puts the
+    markers around each scan: the complete file, Pillow's bytes."""
+    _chk(buf, _U8, "jpeg_encode_items.buf", 1)
+    n = len(items)
+    if n == 0:
+        return
+    lib = _lib.load()
+    desc = np.zeros((n, 6), dtype=np.int64)   # lf_jpeg_item: four int64, then h, w | nblocks, reserved as int32 pairs
+    hw = desc[:, 4:].view(np.int32)
+    groups = coef = 0
+    for i, (off, h, w) in enumerate(items):
+        off, h, w = int(off), int(h), int(w)
+        if off % 4 or off < 0 or h <= 0 or w <= 0 or off + max(h * w * 3, 4) > buf.numel() or off + room > buf.numel():
+            raise ValueError(f"jpeg_encode_items: image {i} ({h}x{w} at {off}) does not lie in the buffer")
+        mcus = -(-h // 16) * -(-w // 16)
+        desc[i, :4] = (off, coef, off, groups)
+        hw[i] = (h, w, mcus * 6, 0)
+        groups += int(lib.lf_jpeg_fdct_groups(h, w))
+        coef += mcus * 384
+    if room < 1024 or room % 4:
+        raise ValueError("jpeg_encode_items: room must be a multiple of 4 and at least 1 KiB")
+    d = torch.from_numpy(desc).to(buf.device)
+    cws = torch.empty(coef, dtype=torch.int16, device=buf.device)
+    nbytes = int(lib.lf_jpeg_entropy_workspace(n, room))
+    ews = torch.empty(nbytes, dtype=_U8, device=buf.device)
+    _lib.call("lf_jpeg_fdct_quant_items_u8", buf.data_ptr(), cws.data_ptr(), d.data_ptr(), n, groups, int(quality), _stream())
+    _lib.call("lf_jpeg_entropy_items_u8", cws.data_ptr(), d.data_ptr(), buf.data_ptr(), int(room), n, ews.data_ptr(), nbytes,
+              _stream())
+
+
 def jpeg_huffman_u8(slots: torch.Tensor, h: int, w: int, sequential: bool = False) -> torch.Tensor:
     """The Huffman step of Image.open for N files of one size that utils.jpeg_host.scan_prepare_into has laid into
     `slots` (uint8 [N, slot_bytes], contiguous): each row's coefficient area [256, 256 + 3hw) is written IN PLACE

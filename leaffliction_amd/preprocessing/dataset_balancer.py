@@ -336,8 +336,17 @@ class DatasetBalancer:
                                                       offsets=[k * pool.slot_bytes for k in ks], limit=pool.slot_bytes)
                         if plan is not None:
                             ops.rotate_expand_apply(x, plan, 255, out=dev_out.view(-1))
-                            jobs += [(chunk[k]["output_path"], (base + k) * pool.slot_bytes, (oh, ow, 3), None)
-                                     for k, (oh, ow) in zip(ks, plan["sizes"])]
+                            if all(chunk[k]["output_path"].lower().endswith((".jpg", ".jpeg")) for k in ks):
+                                # every canvas has a size of its own: the encoder takes them all in one launch per step
+                                # and leaves the finished scans where the pixels were
+                                ops.jpeg_encode_items_u8(dev_out.view(-1), [(k * pool.slot_bytes, oh, ow) for k, (oh, ow)
+                                                                            in zip(ks, plan["sizes"])], pool.slot_bytes,
+                                                         JPEG_QUALITY)
+                                jobs += [(chunk[k]["output_path"], (base + k) * pool.slot_bytes, (oh, ow, 3), None, "scan")
+                                         for k, (oh, ow) in zip(ks, plan["sizes"])]
+                            else:
+                                jobs += [(chunk[k]["output_path"], (base + k) * pool.slot_bytes, (oh, ow, 3), None)
+                                         for k, (oh, ow) in zip(ks, plan["sizes"])]
                             continue
                     n8 = None
                     if op == "distortion" and all(q is not None and "noise_seed" in q and "noise8" not in q for q in prm):

@@ -421,3 +421,32 @@ def test_gpu_huffman_decoder_reports_what_it_cannot_decode(cuda, sequential):
     # a group whose FIRST slot holds nothing: no tables to decode with
     dev2 = torch.from_numpy(slots[[4, 0]]).to(cuda)
     assert ops.jpeg_huffman_u8(dev2, h, w, sequential=sequential).cpu().numpy().tolist() == [3, 3 if sequential else 0]
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_takes_images_of_different_sizes_in_one_launch(cuda):
+    """ops.jpeg_encode_items_u8: the balancer's rotated canvases — every one its own size, whole MCUs or not — lie in
+    slots of one buffer and leave as finished scans in the same places; with the markers around them the files are
+    Pillow's, byte for byte."""
+    import torch
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    sizes = [(224, 224), (241, 263), (17, 9), (16, 16), (300, 187), (1, 1), (64, 95), (256, 256), (33, 48), (224, 224)]
+    room = (2 * 224 * 224 * 3 + 4095) // 4096 * 4096
+    imgs = [make(["scene", "noise", "extremes", "flat"][i % 4], h, w, 70 + i) for i, (h, w) in enumerate(sizes)]
+    host = np.zeros((len(sizes), room), np.uint8)
+    for i, a in enumerate(imgs):
+        host[i, :a.size] = a.reshape(-1)
+    dev = torch.from_numpy(host).to(cuda)
+    ops.jpeg_encode_items_u8(dev.view(-1), [(i * room, h, w) for i, (h, w) in enumerate(sizes)], room, 95)
+    out = dev.cpu().numpy()
+    for i, ((h, w), a) in enumerate(zip(sizes, imgs)):
+        n = int(out[i, :4].view(np.int32)[0])
+        assert n > 0, (i, n)
+        assert jpeg_host.wrap_scan(out[i, 4:4 + n], h, w, 95) == pil_bytes(a, 95), (i, h, w)
+    # a place that is too small for its scan reports it
+    small = torch.from_numpy(host[1:2].copy()).to(cuda)
+    ops.jpeg_encode_items_u8(small.view(-1), [(0, 241, 263)], 2048, 95)
+    assert int(small.cpu().numpy()[0, :4].view(np.int32)[0]) == -1
+    with pytest.raises(ValueError):
+        ops.jpeg_encode_items_u8(dev.view(-1), [(2, 16, 16)], room, 95)
