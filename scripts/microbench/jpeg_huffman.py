@@ -66,5 +66,35 @@ if __name__ == "__main__":
         print({k: (round(float(st[:, i].mean()), 1), float(st[:, i].max())) for i, k in enumerate(names)}, flush=True)
     m = 3 * h * w
     assert np.array_equal(got.cpu().numpy()[:, 256:256 + m], ref[:, 256:256 + m])
+    # the other two codec-edge kernels of the balancer, at a chunk's size: the noise planes of its distortion tasks
+    # (one in six of 256) and the encoder over rotated canvases of different sizes
+    def timed(fn, reps=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    seeds = list(range(1000, 1043))
+    ms = timed(lambda: ops.legacy_normal_u8(seeds, 0.0, 5.0, h * w * 3, dev.device))
+    print(f"noise planes: {len(seeds)} x {h * w * 3} bytes in {ms:.3f} ms = {len(seeds) / ms * 1e3:.0f} planes/s "
+          f"(host: 2.6 ms per plane and core)", flush=True)
+    rng = np.random.RandomState(1)
+    sizes = [(int(a), int(b)) for a, b in zip(rng.randint(224, 307, 43), rng.randint(224, 307, 43))]
+    room = stride
+    canv = torch.randint(0, 256, (len(sizes), room), dtype=torch.uint8, device=dev.device)
+    items = [(i * room, a, b) for i, (a, b) in enumerate(sizes)]
+
+    def enc():
+        c = canv.clone()
+        ops.jpeg_encode_items_u8(c.view(-1), items, room, 95)
+    ms_clone = timed(lambda: canv.clone())
+    ms = timed(enc) - ms_clone
+    print(f"encoder, {len(sizes)} canvases of 224..306 pixels a side (noise: the longest scans): {ms:.3f} ms = "
+          f"{len(sizes) / ms * 1e3:.0f} images/s", flush=True)
     print(f"mean file {np.mean([len(f) for f in files]):.0f} bytes; host: markers only {t_prep * 1e6:.1f} us/image, "
           f"markers + Huffman {t_host * 1e6:.1f} us/image (one core)")
