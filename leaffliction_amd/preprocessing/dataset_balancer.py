@@ -116,7 +116,7 @@ class DatasetBalancer:
             mixed = any(e.is_dir() for e in entries)   # files next to directories: strictly in order, here
             files: List[tuple] = []
             for e in entries:
-                d = os.path.join(dst, e.name)
+                d = dst + os.sep + e.name
                 if e.is_dir():
                     walk(e.path, d)
                 elif mixed:
@@ -237,14 +237,24 @@ class DatasetBalancer:
                 continue
             source_images = images_by_class[class_name]
             class_dir_s = str(source_images[0].parent)
+            # what a task needs of its source, worked out once per source that is drawn (pathlib's stem / suffix cost
+            # more than the draw): (path, path to read from, stem, suffix).  `random.choice(range(n))` draws what
+            # `random.choice(source_images)` draws (one `_randbelow(n)`), so the streams are the reference's.
+            picks = range(len(source_images))
+            info: Dict[int, tuple] = {}
             for transform_name, count in transforms.items():
                 for i in range(count):
-                    source_img = random.choice(source_images)
-                    new_name = source_img.stem + f"_aug_{transform_name}_{i + 1}" + source_img.suffix
-                    src = str(source_img)   # strings from here on: pathlib costs 10 us per operation, 11,500 times
+                    j = random.choice(picks)
+                    got = info.get(j)
+                    if got is None:
+                        source_img = source_images[j]
+                        src = str(source_img)   # strings from here on: pathlib costs 10 us per operation, 11,500 times
+                        got = info[j] = (src, src_root + src[len(dst_root):] if src.startswith(dst_root + os.sep) else src,
+                                         source_img.stem, source_img.suffix)
+                    src, read, stem, suffix = got
                     tasks.append({"source_img": src,
-                                  "read_img": src_root + src[len(dst_root):] if src.startswith(dst_root + os.sep) else src,
-                                  "output_path": os.path.join(class_dir_s, new_name),
+                                  "read_img": read,
+                                  "output_path": os.path.join(class_dir_s, stem + f"_aug_{transform_name}_{i + 1}" + suffix),
                                   "transform_name": transform_name,
                                   "class_name": class_name,
                                   "seed": random.randint(0, 1000000)})
@@ -652,10 +662,10 @@ class DatasetBalancer:
     def _generate_augmented_manifest(self):
         self.manifest_generator = ManifestGenerator(self.analyzer.original_manifest, self.source_dir,
                                                     self.target_dir, self.workers)
-        manifest = self.manifest_generator.generate_augmented_manifest()
         out_dir = self.manifest_path.parent if self.manifest_path is not None else Path("artifacts/datasets")
         out_dir.mkdir(parents=True, exist_ok=True)
-        self.manifest_generator.save_manifest(manifest, out_dir / "manifest_augmented.json")
+        # = save_manifest(generate_augmented_manifest(), ...), byte for byte, without 172,000 dictionaries on the way
+        self.manifest_generator.write_augmented_manifest(out_dir / "manifest_augmented.json")
 
     def run(self):
         logger.info("=== Dataset Balancing System ===")

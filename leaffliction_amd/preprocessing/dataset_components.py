@@ -156,6 +156,44 @@ class ManifestGenerator:
         recs = ["    {\n      " + json.dumps(r, ensure_ascii=False, separators=sep)[1:-1] + "\n    }" for r in items]
         return head[:-2] + ',\n  "items": [\n' + ",\n".join(recs) + "\n  ]\n}"
 
+    def write_augmented_manifest(self, output_path) -> int:
+        """`save_manifest(generate_augmented_manifest(), output_path)` without the record dictionaries in between: the
+        same bytes (tests/test_host_logic.py), the text of each record put together from its class's constant lines and
+        the two strings that vary (the C encoder escapes them).  Returns the number of items."""
+        parts, n_items, n_aug = [], 0, 0
+        enc = json.JSONEncoder(ensure_ascii=False).encode
+        for plant_dir, class_dir in _class_dirs(self.target_dir):
+            plant, cls = plant_dir.name, class_dir.name
+            base, rel = str(class_dir) + os.sep, plant + os.sep + cls + os.sep
+            head = ('    {\n      "plant": ' + enc(plant) + ',\n      "class": ' + enc(cls) + ',\n      "label": ' +
+                    enc(f"{plant}__{cls}") + ',\n      "split": "train",\n      "src": ')
+            with os.scandir(class_dir) as entries:
+                for e in entries:
+                    if e.is_file():
+                        name = e.name
+                        aug = "_aug_" in os.path.splitext(name)[0]
+                        n_aug += aug
+                        parts.append(head + enc(base + name) + ',\n      "id": ' + enc(rel + name) +
+                                     (',\n      "augmented": true\n    }' if aug else ',\n      "augmented": false\n    }'))
+            n_items = len(parts)
+        if not parts:   # an empty list is written by the general encoder
+            self.save_manifest(self.generate_augmented_manifest(), output_path)
+            return 0
+        upstream = self.original_manifest.get("meta", {}) if isinstance(self.original_manifest, dict) else {}
+        meta = {"created_at": upstream.get("created_at"),
+                "augmented_at": datetime.now(timezone.utc).isoformat(),
+                "original_seed": upstream.get("seed"),
+                "augmentation_seed": 42,
+                "workers": self.workers,
+                "src_root": str(self.target_dir),
+                "total_images": n_items,
+                "original_images": n_items - n_aug,
+                "augmented_images": n_aug}
+        head = json.dumps({"meta": meta}, indent=2, ensure_ascii=False)
+        Path(output_path).write_text(head[:-2] + ',\n  "items": [\n' + ",\n".join(parts) + "\n  ]\n}", encoding="utf-8")
+        logger.info(f"Augmented manifest saved: {output_path}")
+        return n_items
+
     def save_manifest(self, manifest, output_path):
         Path(output_path).write_text(self._dumps(manifest), encoding="utf-8")
         logger.info(f"Augmented manifest saved: {output_path}")

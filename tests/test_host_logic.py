@@ -312,3 +312,36 @@ def test_codec_pool_job_splitting():
     assert [len(p) for p in pool._split(list(range(32)), 1)] == [3] * 10 + [2]
     assert len(pool._split(list(range(32)), 4)) == 32
     assert pool._split([], 2) == []
+
+
+def test_fast_manifest_writer_writes_the_same_bytes(tmp_path):
+    """ManifestGenerator.write_augmented_manifest == save_manifest(generate_augmented_manifest()) byte for byte (the
+    reference's json.dumps(manifest, indent=2, ensure_ascii=False), dataset_components.py), on names that need
+    escaping, non-ASCII names, dotted names and an `_aug_` in the extension only."""
+    import re
+    from leaffliction_amd.preprocessing.dataset_components import ManifestGenerator
+    root = tmp_path / "aug"
+    names = ["image (1).JPG", "image (1)_aug_flip_1.JPG", 'we"ird\\name.jpg', "feuille_é_ü.JPG", "a.b.c_aug_x.png",
+             "noext_aug_", "plain._aug_", ".hidden_aug_.JPG"]
+    for plant, cls in (("Apple", "Apple_healthy"), ("Gr\u00e4pe", 'cl"ass')):
+        d = root / plant / cls
+        d.mkdir(parents=True)
+        for n in names:
+            (d / n).write_bytes(b"x")
+    (root / "stray.txt").write_text("not a plant directory")
+    gen = ManifestGenerator({"meta": {"created_at": "2024-01-01T00:00:00", "seed": 7}}, tmp_path / "images", root, 3)
+    a, b = tmp_path / "a.json", tmp_path / "b.json"
+    gen.save_manifest(gen.generate_augmented_manifest(), a)
+    assert gen.write_augmented_manifest(b) == 2 * len(names)
+    stamp = re.compile(r'"augmented_at": "[^"]*"')
+    ta, tb = stamp.sub("", a.read_text(encoding="utf-8")), stamp.sub("", b.read_text(encoding="utf-8"))
+    assert ta == tb
+    import json
+    assert json.loads(b.read_text(encoding="utf-8"))["meta"]["augmented_images"] == json.loads(a.read_text(encoding="utf-8"))["meta"]["augmented_images"]
+    # an empty tree
+    empty = tmp_path / "empty"
+    (empty / "P" / "c").mkdir(parents=True)
+    g2 = ManifestGenerator({}, tmp_path, empty, 1)
+    g2.save_manifest(g2.generate_augmented_manifest(), a)
+    assert g2.write_augmented_manifest(b) == 0
+    assert stamp.sub("", a.read_text()) == stamp.sub("", b.read_text())
