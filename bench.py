@@ -292,6 +292,73 @@ def augment_throughput(dev, n=4096, iters=5, only=None):
     return out
 
 
+def codec_edge_throughput(dev, n=256):
+    """The kernels at the JPEG edge of the balancer, at one chunk's size (256 tasks): Huffman decoding of the sources
+    (Pillow-written 224x224 quality-95 files; the host reader it replaces timed beside it on one core), the noise planes
+    of the chunk's distortion tasks (numpy's legacy stream), and the encoder over rotated canvases of different sizes."""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    from leaffliction_amd import ops
+    from leaffliction_amd.utils import jpeg_host
+    rng = np.random.RandomState(7)
+    yy, xx = np.mgrid[0:IMG, 0:IMG]
+    files = []
+    for i in range(n):
+        img = np.stack([128 + 100 * np.sin(xx / 17.0 + i) * np.cos(yy / 23.0), 90 + 80 * np.cos(xx / 9.0),
+                        140 + 60 * np.sin((xx + yy) / 31.0)], -1) + rng.normal(0, 3 + 4 * (i % 3), (IMG, IMG, 3))
+        b = io.BytesIO()
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(b, format="JPEG", quality=95)
+        files.append(b.getvalue())
+    stride = (2 * IMG * IMG * 3 + 4095) // 4096 * 4096
+    slots = np.zeros((n, stride), np.uint8)
+    for i, f in enumerate(files):
+        if jpeg_host.scan_prepare_into(f, slots[i]) is None:
+            raise RuntimeError("codec_edge: a Pillow-written file was not taken")
+    ref = np.zeros(stride, np.uint8)
+    t0 = time.perf_counter()
+    for f in files[:64]:
+        jpeg_host.read_file_into(f, ref)
+    host = 64 / (time.perf_counter() - t0)
+    d = torch.from_numpy(slots).to(dev)
+
+    def timed(fn, reps=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    sec = timed(lambda: ops.jpeg_huffman_u8(d, IMG, IMG))
+    if int(ops.jpeg_huffman_u8(d, IMG, IMG).abs().sum()):
+        raise RuntimeError("codec_edge: the GPU decoder handed a file back")
+    out = {"huffman_decode": {"files_per_sec": round(n / sec), "ms_per_launch": round(sec * 1e3, 3), "files": n,
+                              "mean_file_bytes": round(float(np.mean([len(f) for f in files]))),
+                              "host_reader_files_per_sec_one_core": round(host)}}
+    seeds = list(range(1000, 1000 + n // 6))
+    sec = timed(lambda: ops.legacy_normal_u8(seeds, 0.0, 5.0, IMG * IMG * 3, dev))
+    out["noise_planes"] = {"planes_per_sec": round(len(seeds) / sec), "ms_per_launch": round(sec * 1e3, 3),
+                           "planes": len(seeds), "host_ms_per_plane_one_core": 2.6}
+    sizes = [(int(a), int(b)) for a, b in zip(rng.randint(IMG, 307, n // 6), rng.randint(IMG, 307, n // 6))]
+    canv = torch.randint(0, 256, (len(sizes), stride), dtype=torch.uint8, device=dev)
+    items = [(i * stride, a, b) for i, (a, b) in enumerate(sizes)]
+    work = torch.empty_like(canv)
+
+    def enc():
+        work.copy_(canv)
+        ops.jpeg_encode_items_u8(work.view(-1), items, stride, 95)
+    sec = timed(enc) - timed(lambda: work.copy_(canv))
+    out["encode_mixed_sizes"] = {"images_per_sec": round(len(sizes) / sec), "ms_per_launch_pair": round(sec * 1e3, 3),
+                                 "images": len(sizes), "content": "uniform noise (the longest scans)"}
+    return out
+
+
 # ---- end to end: `Augmentation.py` over synthetic 224x224 JPEGs (BASELINE configs[2]) -----------
 # class counts per 1,000 generated images: the balancer tops every class of a plant up to the plant's largest
 # (x 100 = BASELINE configs[2]'s 100,000 generated files from 72,000 originals)
@@ -887,6 +954,7 @@ def main() -> None:
             del model
             torch.cuda.empty_cache()
             out["augment"] = augment_throughput(dev)
+            out["augment"]["codec_edge"] = codec_edge_throughput(dev)
             if not args.no_cpu_baseline:
                 out["augment"]["cpu_baseline"] = cpu_augment_baseline()
             if not args.no_e2e:

@@ -45,12 +45,15 @@ struct HuffTab {
 };
 
 // All `nthr` threads of the workgroup call this with the same arguments.  dht: four times 16 counts + 256 symbols.
+// A workgroup of four waves builds the four tables side by side (one wave each), a single wave one after the other.
 __device__ bool build_tables(HuffTab& T, const uint8_t* dht, int tid, int nthr) {
     for (int i = tid; i < 4 * (1 << kLook); i += nthr) (&T.fast[0][0])[i] = 0;
     for (int i = tid; i < 4 * kSub * 16; i += nthr) (&T.sub[0][0])[i] = 0;
     __syncthreads();
+    const bool split = nthr >= 256;
+    const int lanes = split ? 64 : nthr, lid = split ? (tid & 63) : tid, tstep = split ? nthr / 64 : 1;
     bool ok = true;
-    for (int t = 0; t < 4 && ok; ++t) {
+    for (int t = split ? (tid >> 6) : 0; t < 4 && ok; t += tstep) {
         const uint8_t* bits = dht + t * 272;
         int code = 0, k = 0, nsub = 0, last_prefix = -1;
         for (int l = 1; l <= 16 && ok; ++l) {
@@ -63,7 +66,7 @@ __device__ bool build_tables(HuffTab& T, const uint8_t* dht, int tid, int nthr) 
                 const uint16_t e = (uint16_t)((l << 8) | bits[16 + k]);
                 if (l <= kLook) {
                     const int first = code << (kLook - l), span = 1 << (kLook - l);
-                    for (int f = tid; f < span; f += nthr) T.fast[t][first + f] = e;
+                    for (int f = lid; f < span; f += lanes) T.fast[t][first + f] = e;
                 } else {
                     const int rem = l - kLook, prefix = code >> rem;
                     if (prefix != last_prefix) {   // codes come in increasing order: a new prefix is a new second level
@@ -72,18 +75,17 @@ __device__ bool build_tables(HuffTab& T, const uint8_t* dht, int tid, int nthr) 
                             break;
                         }
                         last_prefix = prefix;
-                        if (tid == 0) T.fast[t][prefix] = (uint16_t)(0x8000 | nsub);
+                        if (lid == 0) T.fast[t][prefix] = (uint16_t)(0x8000 | nsub);
                         ++nsub;
                     }
                     const int first = (code & ((1 << rem) - 1)) << (4 - rem), span = 1 << (4 - rem);
-                    if (tid < span) T.sub[t][(nsub - 1) * 16 + first + tid] = e;
+                    if (lid < span) T.sub[t][(nsub - 1) * 16 + first + lid] = e;
                 }
             }
             code <<= 1;
         }
     }
-    __syncthreads();
-    return ok;
+    return __syncthreads_and(ok) != 0;
 }
 
 __device__ __forceinline__ unsigned lookup(const HuffTab& T, int t, uint64_t buf) {
@@ -150,6 +152,45 @@ __device__ __forceinline__ uint64_t stream8_be(const uint64_t* stream, uint32_t 
 // (no such code, a run past the end of the block) is stepped over, only the state it leaves with and the blocks it
 // completed matter.  WRITE = true: the true chain; coefficients go to coef[block][index], anything that cannot be
 // sets *fail, and the chain ends with block `total`.  On a well-formed stream both walk through the same states.
+// A speculative chain from `entry` while symbols START before bit `stop`: only where it ends up and how many blocks it
+// completed matter, so a trip is a table lookup and a handful of selects — the code's length plus its value bits to step
+// over, and how far the index in the block moves (DC: to 1; run/size: run + 1; ZRL: 16; end of block: to 64).  What cannot
+// be (no such code) is stepped over by a bit.  On a well-formed stream it walks through the states decode_span<true> does.
+__device__ __forceinline__ uint32_t spec_span(const HuffTab& T, const uint64_t* stream, uint32_t entry, uint32_t stop,
+                                              uint32_t& blocks) {
+    uint32_t p = entry >> 9;
+    int k = (int)((entry >> 3) & 63u), b6 = (int)(entry & 7u);
+    uint32_t bytepos = p >> 3;
+    uint64_t buf = stream8_be(stream, bytepos) << (p & 7u);
+    int nb = 64 - (int)(p & 7u);
+    bytepos += 8;
+    uint32_t done = 0;
+    while (p < stop) {
+        if (nb < 32) {
+            const int take = (64 - nb) >> 3;
+            const uint64_t v = stream8_be(stream, bytepos);
+            buf |= (take == 8 ? v : v & ~(~0ull >> (8 * take))) >> nb;
+            bytepos += (uint32_t)take;
+            nb += 8 * take;
+        }
+        const unsigned e = lookup(T, (b6 < 4 ? 0 : 2) + (k > 0 ? 1 : 0), buf);
+        const int size = (int)(e & 15u), run = (int)((e >> 4) & 15u);
+        const int adv = e ? (int)(e >> 8) + size : 1;
+        const int dk = !e ? 0 : (k == 0 ? 1 : (size ? run + 1 : (run == 15 ? 16 : 64)));
+        buf <<= adv;
+        nb -= adv;
+        k += dk;
+        p = bytepos * 8u - (uint32_t)nb;
+        if (k >= 64) {
+            k = 0;
+            b6 = b6 == 5 ? 0 : b6 + 1;
+            ++done;
+        }
+    }
+    blocks = done;
+    return (p << 9) | ((uint32_t)k << 3) | (uint32_t)b6;
+}
+
 template <bool WRITE>
 __device__ __forceinline__ uint32_t decode_span(const HuffTab& T, const uint64_t* stream, uint32_t entry, uint32_t stop,
                                                 uint32_t& blocks, int16_t* coef, uint32_t blk, uint32_t total,
@@ -281,7 +322,7 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
         bool changed = false;
         if (dirty) {
             uint32_t blocks;
-            left = decode_span<false>(S.T, S.stream, entry, stop, blocks, nullptr, 0, 0, 0, nullptr);
+            left = spec_span(S.T, S.stream, entry, stop, blocks);
             S.cnt[tid] = blocks;
             dirty = false;
             changed = (uint32_t)(tid + 1) < nsub && left != S.state[tid + 1];
