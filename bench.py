@@ -596,7 +596,7 @@ def _fit_from_files(files, dev, batch=BATCH):
 
 def predict_end_to_end(dev, n_files=4096):
     """BASELINE configs[4] as a user of `predict -batch` sees it: JPEG files -> labels (Predictor.predict_batch: codec
-    worker processes Huffman-decode, the GPU does the rest of the decoding and the bf16 forward pass), next to the
+    worker processes read the files' markers, the GPU does the decoding and the bf16 forward pass), next to the
     reference's way of feeding the same model — `ImageLoader.load_as_array` in a loop on one core (predictor.py's own
     loop, srcs/predict/predictor.py) — on a bounded sample."""
     import shutil

@@ -50,7 +50,7 @@ class DeviceDecoder:
         return self._codec
 
     @staticmethod
-    def _probe_slot(paths: Sequence[str], fallback: int) -> int:
+    def _probe_slot(paths: Sequence[str], fallback: int, scan: bool = False) -> int:
         from PIL import Image
         w0 = h0 = fallback
         for p in paths[:8]:   # slot size from the first readable file (larger images travel as pickled arrays)
@@ -60,9 +60,15 @@ class DeviceDecoder:
                 break
             except Exception:  # noqa: BLE001
                 continue
-        return (256 + h0 * w0 * 3 + 4095) // 4096 * 4096
+        # tables + coefficients (or pixels), and behind them room for a prepared scan (header, Huffman tables and the
+        # un-stuffed entropy-coded bytes: ~0.16 of the pixel bytes at quality 95; a file that does not fit takes the
+        # host's Huffman pass)
+        return (256 + h0 * w0 * 3 + ((1136 + h0 * w0 * 3 // 2) if scan else 0) + 4095) // 4096 * 4096
 
-    def _submit(self, part: Sequence[str], third: int):
+    def _submit(self, part: Sequence[str], third: int, scan: bool = False):
+        """`scan`: the workers read the markers only and the GPU decodes the Huffman stream as well — for callers that
+        can wait for the chunk's GPU work before they use its pixels (`chunks`); the prefetching path (`submit` /
+        `collect`, which never waits) keeps the Huffman pass in the workers."""
         pool = self._codec[0]
         ev = self._uploaded[third]   # the last upload out of this slab third must be over before it is rewritten
         if ev is not None:
@@ -71,9 +77,10 @@ class DeviceDecoder:
         tasks = [{"source_img": p, "transform_name": "", "seed": 0} for p in part]
         # every future costs the parent ~0.1-0.2 ms to send and collect: one job per worker for a small batch (a
         # 32-file batch as 32 one-file jobs ran at half the rate), two for a full chunk (some slack for a slow core)
-        return pool.decode(tasks, third * self.CHUNK, True, pieces_per_worker=1 if len(part) <= 64 else 2)
+        return pool.decode(tasks, third * self.CHUNK, 2 if scan else 1, pieces_per_worker=1 if len(part) <= 64 else 2)
 
-    def _finish(self, futures, third: int, n: int, img_size: int, keep_native: bool, pos0: int):
+    def _finish(self, futures, third: int, n: int, img_size: int, keep_native: bool, pos0: int,
+                paths: Optional[Sequence[str]] = None):
         """The device half of one chunk whose worker jobs are `futures`: upload, the JPEG back end, the resize.
         Returns (kept positions, x, natives, errors); the slab third is free again once `_uploaded[third]` has passed."""
         import torch
@@ -87,7 +94,19 @@ class DeviceDecoder:
         # behind whatever the stream is doing — a training step — and the host goes on to prepare the next one.
         # The one staging buffer is safe to reuse: uploads and the kernels that read it are ordered on the stream.
         dev_in = dev_in[:n]
-        dev_in.copy_(host if pinned else host.clone(), non_blocking=pinned)
+        live = [d for d in decoded if d[0] != "err"]
+        if pinned and live and all(d[0] == "scan" for d in live):
+            # prepared scans only: the tables at the front of each slot and the scan behind the (device-only)
+            # coefficient area are all that has to cross PCIe
+            from .. import _lib
+            from ..utils import jpeg_host
+            lo = min(jpeg_host.scan_aux_offset(hh, ww) for hh, ww in {(d[1][0], d[1][1]) for d in live})
+            hi = min(_slot, (max(d[1][3] for d in live) + 15) // 16 * 16)
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.call("lf_copy_rows", dev_in.data_ptr(), _slot, host.data_ptr(), _slot, 256, n, 0, stream)
+            _lib.call("lf_copy_rows", dev_in.data_ptr() + lo, _slot, host.data_ptr() + lo, _slot, hi - lo, n, 0, stream)
+        else:
+            dev_in.copy_(host if pinned else host.clone(), non_blocking=pinned)
         if pinned:
             ev = torch.cuda.Event()
             ev.record()
@@ -109,10 +128,15 @@ class DeviceDecoder:
                 groups.setdefault((status,) + tuple(payload[:2]), []).append(k)
         natives: Optional[Dict[int, np.ndarray]] = {} if keep_native else None
         x = torch.empty((n, S, S, 3), dtype=torch.uint8, device=dev)
+        huffman: List[tuple] = []   # (positions in the chunk, device status of the GPU's Huffman decoding)
         for (status, h, w), ks in groups.items():
             whole = len(ks) == n   # one group holds the whole chunk (the usual case): no gather, no scatter
             idx = None if whole else index(ks)
-            if status == "coef":
+            if status == "scan":
+                rows = dev_in if whole else dev_in[idx]
+                huffman.append((ks, ops.jpeg_huffman_u8(rows, h, w)))
+                px = ops.jpeg_idct_rgb_u8(rows, h, w)
+            elif status == "coef":
                 px = ops.jpeg_idct_rgb_u8(dev_in if whole else dev_in[idx], h, w)
             elif status == "ok":
                 px = (dev_in if whole else dev_in[idx])[:, :h * w * 3].view(len(ks), h, w, 3)
@@ -128,6 +152,23 @@ class DeviceDecoder:
                 for j, k in enumerate(ks):
                     natives[pos0 + k] = host_px[j]
         kept = sorted(k for ks in groups.values() for k in ks)
+        for ks, st in huffman:
+            st = st.cpu().numpy()   # waits for the chunk's device half: only `chunks` asks for prepared scans
+            for k in (k for k, v in zip(ks, st) if v):
+                # a scan the GPU handed back (damaged, cut short): Pillow has the reference's verdict
+                # (image_utils.py:19-33) — pixels, with libjpeg's concealment, or an error
+                try:
+                    from ..utils.image_utils import ImageLoader
+                    arr = ImageLoader.load_as_array(paths[k])
+                    one = torch.from_numpy(np.ascontiguousarray(arr)).to(dev).unsqueeze(0)
+                    x[k] = (one if tuple(arr.shape[:2]) == (S, S) else ops.resize_lanczos_u8(one, S))[0]
+                    if natives is not None:
+                        natives[pos0 + k] = arr
+                except Exception as e:  # noqa: BLE001
+                    errors.append((pos0 + k, f"{paths[k]} - {e}"))
+                    kept.remove(k)
+                    if natives is not None:
+                        natives.pop(pos0 + k, None)
         if len(kept) < n:
             x = x[index(kept)] if kept else x[:0]
         return [pos0 + k for k in kept], x, natives, errors
@@ -150,17 +191,17 @@ class DeviceDecoder:
         C = self.CHUNK
         paths = [str(p) for p in paths]
         self.drop_pending()
-        self._ensure(self._probe_slot(paths, int(img_size)))
+        self._ensure(self._probe_slot(paths, int(img_size), scan=True))
         parts = [paths[b:b + C] for b in range(0, len(paths), C)]
         try:
-            ahead = [self._submit(parts[i], i % 3) for i in range(min(2, len(parts)))]
+            ahead = [self._submit(parts[i], i % 3, scan=True) for i in range(min(2, len(parts)))]
             for i, part in enumerate(parts):
                 futures = ahead.pop(0)
                 for f in futures:
                     f.result()
                 if i + 2 < len(parts):   # into the slab third chunk i-1 used: its upload was waited for
-                    ahead.append(self._submit(parts[i + 2], (i + 2) % 3))
-                kept, x, natives, errors = self._finish(futures, i % 3, len(part), img_size, keep_native, i * C)
+                    ahead.append(self._submit(parts[i + 2], (i + 2) % 3, scan=True))
+                kept, x, natives, errors = self._finish(futures, i % 3, len(part), img_size, keep_native, i * C, part)
                 yield i * C, kept, x, natives, errors
         except BaseException:
             self.close()   # a failed chunk may leave jobs in flight on the slabs: start afresh next time

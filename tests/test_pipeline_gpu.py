@@ -340,12 +340,19 @@ def test_pooled_predict_batch_equals_the_sequential_loop(cuda, tmp_path, monkeyp
         paths.append(str(p))
     (files / "broken.jpg").write_bytes(b"\xff\xd8 not really a jpeg")
     paths.insert(17, str(files / "broken.jpg"))
+    # a file damaged inside its scan with the EOI in place (the GPU's Huffman decoder hands it back; Pillow conceals the
+    # damage and both loops go on with Pillow's pixels) and one cut short (an error in both loops)
+    whole = Path(paths[4]).read_bytes()
+    (files / "damaged.jpg").write_bytes(whole[:len(whole) // 2] + whole[-2:])
+    (files / "cut.jpg").write_bytes(whole[:-300])
+    paths.insert(40, str(files / "damaged.jpg"))
+    paths.insert(70, str(files / "cut.jpg"))
     pred = Predictor(tmp_path / "artifacts/models")
     pred.load()
     pooled = pred.predict_batch(paths)
     monkeypatch.setattr(Predictor, "POOL_MIN", 10 ** 9)
     serial = pred.predict_batch(paths)
-    assert len(pooled) == len(serial) == 90
+    assert len(pooled) == len(serial) == 91   # 90 files + the damaged one (Pillow reads it); broken and cut are skipped
     for a, b in zip(pooled, serial):
         assert str(a["image_path"]) == str(b["image_path"]) and a["top_prediction"] == b["top_prediction"]
         assert np.array_equal(a["original_array"], b["original_array"])
