@@ -3,9 +3,12 @@
 The reference decodes one file after the other with Pillow and resizes on the host
 (`ImageLoader.load_as_array` / `resize_array`, srcs/utils/image_utils.py:19-59,109-114, called from
 srcs/dataio/sequence.py:74-125 and srcs/predict/predictor.py).  Here codec worker processes read the
-files and Huffman-decode baseline 4:2:0 JPEGs of whole MCUs into page-locked slabs (libleafcodec.so; any
-other file is decoded whole by Pillow in the worker), a chunk crosses PCIe as one copy, and the GPU does
-dequantisation / IDCT / fancy upsampling / colour conversion (`ops.jpeg_idct_rgb_u8`) and the Pillow-exact
+files and, of baseline 4:2:0 JPEGs of whole MCUs, either the markers only (`chunks`: the un-stuffed scan goes into the
+page-locked slab and the GPU decodes the Huffman stream too, `ops.jpeg_huffman_u8`) or the markers and the Huffman
+stream (the prefetching `submit` / `collect`, which never waits for the GPU and so cannot ask it for a verdict on a
+damaged scan); any other file is decoded whole by Pillow in the worker.  A chunk crosses PCIe as one copy (its used
+parts only when every file is a prepared scan), and the GPU does dequantisation / IDCT / fancy upsampling / colour
+conversion (`ops.jpeg_idct_rgb_u8`) and the Pillow-exact
 LANCZOS resize, chunk after chunk with the next two chunks' files already being read.  The pixels are
 Pillow's bit for bit (tests/test_jpeg_codec.py), so everything downstream sees what the reference's loop
 would have produced.

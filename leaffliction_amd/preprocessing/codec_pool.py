@@ -9,11 +9,13 @@ reference's own process pool at 10.8 k images/s.  So the codec work goes to proc
 pixels cross the process boundary through shared memory, never through pickles:
 
   decode worker: JPEG -> RGB uint8 written straight into the task's slot of the INPUT slab — or, for a
-      baseline 4:2:0 file of whole MCUs when the GPU path is on, only its Huffman decoding: quantisation tables
-      + coefficients into the slot, the IDCT / upsampling / colour conversion being the GPU's; the
+      baseline 4:2:0 file of whole MCUs when the GPU path is on, only its markers (tables + the un-stuffed scan into
+      the slot: Huffman decoding, IDCT, upsampling and colour conversion are the GPU's) or its markers and Huffman
+      decoding (tables + coefficients into the slot); the
       task's random parameters are drawn there too (a fresh seeded RNG per task, exactly what the
-      reference's worker does), including the distortion's 150 k normal deviates, which are cast to
-      uint8 by numpy itself (image_augmenter.py:121-123) into the NOISE slab;
+      reference's worker does); the distortion's 150 k normal deviates are either left to the GPU (the worker hands
+      the seed on) or made here, cast to uint8 by numpy's own rule (image_augmenter.py:121-123), into the NOISE slab;
+      the workers also copy the originals into the target tree, a batch of files per job;
   main process:  one H2D per (transform, size) group, batched kernels, D2H into the OUTPUT slab;
   encode worker: slot of the OUTPUT slab -> JPEG quality 95 -> the task's output path.  Images of whole
       16x16 MCUs arrive as finished JPEG scans (colour conversion, 4:2:0 downsampling, DCT, quantisation,
