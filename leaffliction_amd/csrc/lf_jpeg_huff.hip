@@ -9,7 +9,7 @@
 // A scan is one serial bit stream: where a code starts depends on every code before it.  Two kernels:
 //
 // jpeg_huffman_par_kernel — one workgroup per image, 256 threads, the stream staged in LDS and cut into 256
-//   subsequences of equal bit length.  Huffman streams re-synchronise by themselves: a decoder started at a wrong
+//   subsequences of equal bit length (a scan over 96 KB stays in global memory and is read through the L2).  Huffman streams re-synchronise by themselves: a decoder started at a wrong
 //   bit, in a wrong place of a block, falls into step with the true sequence of codes after a few dozen symbols.
 //   So every thread decodes its own subsequence from a GUESSED entry state (bit position, index in the block,
 //   block of the MCU) and hands the state it leaves with to its right-hand neighbour as that one's entry state;
@@ -287,10 +287,14 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
         if (tid == 0) status[img] = 3;
         return;
     }
-    if (H.restart != 0 || H.data_len > kStreamCap) {   // the sequential kernel's
+    // A scan that does not fit the LDS stage is read where it lies (through the L2: slower trips, the same walk); restart
+    // intervals, and scans too long for the 23 bits a state has for its bit position, are the sequential kernel's.
+    const bool in_lds = H.data_len <= kStreamCap;
+    if (H.restart != 0 || (!in_lds && (H.data_len >= (1u << 20) - 64u || aux + H.data_off + (size_t)H.data_len + 48 > stride))) {
         if (tid == 0) status[img] = 4;
         return;
     }
+    const uint64_t* gstream = reinterpret_cast<const uint64_t*>(a + H.data_off);
     if (tid == 0) S.fail = 0;
     if (!build_tables(S.T, a + 32, tid, kPT)) {
         if (tid == 0) status[img] = 3;
@@ -300,8 +304,9 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
     // the scan into LDS; the host left 16 zero bytes behind it, and what lies behind those is never looked at as data
     const uint4* src = reinterpret_cast<const uint4*>(a + H.data_off);
     const uint32_t pieces = H.data_len / 16 + 1, room = kStreamCap / 16 + 2;
-    for (uint32_t i = tid; i < room; i += kPT)
-        reinterpret_cast<uint4*>(S.stream)[i] = i < pieces ? src[i] : make_uint4(0, 0, 0, 0);
+    if (in_lds)
+        for (uint32_t i = tid; i < room; i += kPT)
+            reinterpret_cast<uint4*>(S.stream)[i] = i < pieces ? src[i] : make_uint4(0, 0, 0, 0);
     const uint32_t total_bits = H.data_len * 8u;
     const uint32_t mcus = (uint32_t)(h / 16) * (uint32_t)(w / 16), total = mcus * 6u;
     uint32_t L = ((total_bits + kPT - 1) / kPT + 31u) & ~31u;
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
         bool changed = false;
         if (dirty) {
             uint32_t blocks;
-            left = spec_span(S.T, S.stream, entry, stop, blocks);
+            left = in_lds ? spec_span(S.T, S.stream, entry, stop, blocks) : spec_span(S.T, gstream, entry, stop, blocks);
             S.cnt[tid] = blocks;
             dirty = false;
             changed = (uint32_t)(tid + 1) < nsub && left != S.state[tid + 1];
@@ -352,7 +357,10 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
     LF_STAMP(4);
     if (mine && first_blk < total) {
         uint32_t blocks;
-        decode_span<true>(S.T, S.stream, entry, stop, blocks, coef, first_blk, total, total_bits, &S.fail);
+        if (in_lds)
+            decode_span<true>(S.T, S.stream, entry, stop, blocks, coef, first_blk, total, total_bits, &S.fail);
+        else
+            decode_span<true>(S.T, gstream, entry, stop, blocks, coef, first_blk, total, total_bits, &S.fail);
     }
     if (tid == kPT - 1 && incl < total) S.fail = 1;   // the scan ended before the image did
     __syncthreads();

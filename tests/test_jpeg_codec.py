@@ -348,7 +348,8 @@ def test_scan_prepare_declines_what_the_host_reader_declines():
                                     (48, 208, dict(quality=85, restart_marker_rows=1)), (16, 16, dict(quality=95)),
                                     (64, 64, dict(quality=90, restart_marker_blocks=3)), (32, 48, dict(quality=100)),
                                     (256, 256, dict(quality=88)), (224, 224, dict(quality=30)),
-                                    (64, 64, dict(quality=100, optimize=True))])
+                                    (64, 64, dict(quality=100, optimize=True)),
+                                    (320, 336, dict(quality=100))])   # noise at quality 100: scans over the 96 KB LDS stage
 @pytest.mark.parametrize("sequential", [False, True])
 def test_gpu_huffman_decoder_recovers_the_coefficients(cuda, h, w, kw, sequential):
     """file -> host markers -> GPU Huffman decoding == the host reader's coefficients, and on through the GPU IDCT ==
@@ -363,11 +364,13 @@ def test_gpu_huffman_decoder_recovers_the_coefficients(cuda, h, w, kw, sequentia
     files = [_save(make(kinds[i % 4], h, w, 40 + i), **kw) for i in range(n)]
     if kw.get("optimize") and sequential:   # optimised tables differ from file to file, and that kernel shares them
         files = [files[1]] * n
-    stride = (256 + 3 * h * w + (1 << 16) + 4095) // 4096 * 4096
+    stride = (256 + 3 * h * w + max(1 << 16, max(len(f) for f in files) + 4096) + 4095) // 4096 * 4096
     slots = np.zeros((n, stride), np.uint8)
     for i, f in enumerate(files):
         got = jpeg_host.scan_prepare_into(f, slots[i])
         assert got is not None and got[:2] == (h, w), i
+    if (h, w) == (320, 336):
+        assert max(len(f) for f in files) > 100 * 1024
     dev = torch.from_numpy(slots).to(cuda)
     status = ops.jpeg_huffman_u8(dev, h, w, sequential=sequential).cpu().numpy()
     assert np.all(status == 0), status
