@@ -148,14 +148,10 @@ __device__ __forceinline__ uint64_t stream8_be(const uint64_t* stream, uint32_t 
     return __builtin_bswap64(v);
 }
 
-// Decode from `entry` while symbols START before bit `stop`.  WRITE = false: a speculative chain; whatever cannot be
-// (no such code, a run past the end of the block) is stepped over, only the state it leaves with and the blocks it
-// completed matter.  WRITE = true: the true chain; coefficients go to coef[block][index], anything that cannot be
-// sets *fail, and the chain ends with block `total`.  On a well-formed stream both walk through the same states.
 // A speculative chain from `entry` while symbols START before bit `stop`: only where it ends up and how many blocks it
 // completed matter, so a trip is a table lookup and a handful of selects — the code's length plus its value bits to step
 // over, and how far the index in the block moves (DC: to 1; run/size: run + 1; ZRL: 16; end of block: to 64).  What cannot
-// be (no such code) is stepped over by a bit.  On a well-formed stream it walks through the states decode_span<true> does.
+// be (no such code) is stepped over by a bit.  On a well-formed stream it walks through the states decode_span does.
 __device__ __forceinline__ uint32_t spec_span(const HuffTab& T, const uint64_t* stream, uint32_t entry, uint32_t stop,
                                               uint32_t& blocks) {
     uint32_t p = entry >> 9;
@@ -191,7 +187,9 @@ __device__ __forceinline__ uint32_t spec_span(const HuffTab& T, const uint64_t* 
     return (p << 9) | ((uint32_t)k << 3) | (uint32_t)b6;
 }
 
-template <bool WRITE>
+// The true chain from `entry` while symbols START before bit `stop`: coefficients go to coef[block][index] (DC terms as
+// differences), anything that cannot be (no such code, a DC size over 11, a run past the end of the block, a last
+// block that ends behind the file's bits) sets *fail, and the chain ends with block `total`.
 __device__ __forceinline__ uint32_t decode_span(const HuffTab& T, const uint64_t* stream, uint32_t entry, uint32_t stop,
                                                 uint32_t& blocks, int16_t* coef, uint32_t blk, uint32_t total,
                                                 uint32_t total_bits, int* fail) {
@@ -203,7 +201,7 @@ __device__ __forceinline__ uint32_t decode_span(const HuffTab& T, const uint64_t
     bytepos += 8;
     uint32_t done = 0;
     bool bad = false;
-    while (p < stop && (!WRITE || (blk < total && !bad))) {
+    while (p < stop && blk < total && !bad) {
         if (nb < 32) {   // a code (<= 16 bits) and its value bits (<= 15) per refill
             const int take = (64 - nb) >> 3;   // 4..8 whole bytes
             const uint64_t v = stream8_be(stream, bytepos);
@@ -213,8 +211,8 @@ __device__ __forceinline__ uint32_t decode_span(const HuffTab& T, const uint64_t
         }
         const int t = (b6 < 4 ? 0 : 2) + (k > 0 ? 1 : 0);
         const unsigned e = lookup(T, t, buf);
-        if (e == 0) {   // no such code: the true chain ends here, a speculative one moves on by a bit
-            if (WRITE) bad = true;
+        if (e == 0) {   // no such code: the chain ends here
+            bad = true;
             buf <<= 1;
             nb -= 1;
         } else {
@@ -224,30 +222,28 @@ __device__ __forceinline__ uint32_t decode_span(const HuffTab& T, const uint64_t
             int size = k == 0 ? sym : (sym & 15);
             const int run = k == 0 ? 0 : sym >> 4;
             if (k == 0 && size > 11) {
-                if (WRITE) bad = true;
+                bad = true;
                 size &= 7;
             }
             int val = 0;
             if (size) {   // receive + extend
-                if (WRITE) {
-                    const int v = (int)((buf >> 1) >> (63 - size));
-                    val = v < (1 << (size - 1)) ? v - (1 << size) + 1 : v;
-                }
+                const int v = (int)((buf >> 1) >> (63 - size));
+                val = v < (1 << (size - 1)) ? v - (1 << size) + 1 : v;
                 buf <<= size;
                 nb -= size;
             }
             if (k == 0) {
-                if (WRITE && val && !bad) coef[(size_t)blk * 64] = (int16_t)val;   // a DC difference for now
+                if (val && !bad) coef[(size_t)blk * 64] = (int16_t)val;   // a DC difference for now
                 k = 1;
             } else if (size == 0) {
                 k = run == 15 ? k + 16 : 64;   // ZRL | end of block
             } else {
                 k += run;
                 if (k > 63) {
-                    if (WRITE) bad = true;
+                    bad = true;
                     k = 64;
                 } else {
-                    if (WRITE && !bad) coef[(size_t)blk * 64 + k] = (int16_t)val;
+                    if (!bad) coef[(size_t)blk * 64 + k] = (int16_t)val;
                     ++k;
                 }
             }
@@ -257,15 +253,13 @@ __device__ __forceinline__ uint32_t decode_span(const HuffTab& T, const uint64_t
             k = 0;
             b6 = b6 == 5 ? 0 : b6 + 1;
             ++done;
-            if (WRITE) {
-                ++blk;
-                // the last block must have ended inside the file's bits (lf_jpeg_read_file's Reader::starved)
-                if (blk == total && p > total_bits) bad = true;
-            }
+            ++blk;
+            // the last block must have ended inside the file's bits (lf_jpeg_read_file's Reader::starved)
+            if (blk == total && p > total_bits) bad = true;
         }
     }
     blocks = done;
-    if (WRITE && bad) *fail = 1;
+    if (bad) *fail = 1;
     return (p << 9) | ((uint32_t)k << 3) | (uint32_t)b6;
 }
 
@@ -358,9 +352,9 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
     if (mine && first_blk < total) {
         uint32_t blocks;
         if (in_lds)
-            decode_span<true>(S.T, S.stream, entry, stop, blocks, coef, first_blk, total, total_bits, &S.fail);
+            decode_span(S.T, S.stream, entry, stop, blocks, coef, first_blk, total, total_bits, &S.fail);
         else
-            decode_span<true>(S.T, gstream, entry, stop, blocks, coef, first_blk, total, total_bits, &S.fail);
+            decode_span(S.T, gstream, entry, stop, blocks, coef, first_blk, total, total_bits, &S.fail);
     }
     if (tid == kPT - 1 && incl < total) S.fail = 1;   // the scan ended before the image did
     __syncthreads();
