@@ -237,8 +237,8 @@ int lf_jpeg_read_file(const uint8_t* data, size_t len, int16_t* coef, size_t coe
  * lf_jpeg_huffman_u8 (GPU): N prepared slots of one size -> each slot's coefficient area [256, 256 + 3hw) in
  *   lf_jpeg_read_file's layout (then lf_jpeg_idct_rgb_u8 as before).  mode 0: one workgroup per image decodes 256
  *   subsequences of the scan at once (self-synchronising; lf_jpeg_huff.hip), and the images that kernel does not
- *   take (restart markers, scans of a megabyte and more) go through the one-lane-per-image kernel; mode 1: that kernel
- *   for all.  (A scan up to 96 KB is staged in LDS, a longer one is read where it lies.)
+ *   take (scans of a megabyte and more) go through the one-lane-per-image kernel; mode 1: that kernel for all.  (A scan
+ *   up to 96 KB is staged in LDS, a longer one is read where it lies; restart intervals are decoded one per thread.)
  *   status[i] (int32, device): 0 decoded; 1 the scan is malformed or ends early (what lf_jpeg_read_file answers
  *   with -1: give the file to libjpeg for the reference's verdict); 2 (one-lane-per-image kernel only: it shares
  *   one set of tables among 64 images) the image's hash differs from that of the first image of its group; 3 no

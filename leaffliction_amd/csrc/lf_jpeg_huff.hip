@@ -17,10 +17,11 @@
 //   first r subsequences are certainly right, and in practice everything is after a few (Weissenberger & Schmidt's
 //   scheme, ICPP 2018, restated as a fixed point per workgroup).  Then the blocks each subsequence completed are
 //   prefix-summed into block numbers, a last decode writes the coefficients where they belong (DC terms still as
-//   differences), and three waves turn the DC differences into values with a scan per component.
+//   differences), and three waves turn the DC differences into values with a scan per component.  A file with restart
+//   markers needs none of the guessing: its intervals start at known states, one thread decodes each.
 //
 // jpeg_huffman_seq_kernel — one LANE per image, every trip of the loop one Huffman symbol whatever the lane is in
-//   the middle of.  Correct for everything the host prepares (restart intervals, scans longer than the LDS stage),
+//   the middle of.  Correct for everything the host prepares (restart intervals, scans of any length),
 //   but a wave executes the union of its lanes' paths at one instruction every ~8 cycles: 28 ms for 64..256 images
 //   of 224 x 224 whether the bytes come straight from global memory or through an LDS ring (both were measured:
 //   9 M instructions per wave, 0.6 M cycles of waiting in 68 M — issue-bound, not latency-bound).  It takes the
@@ -263,6 +264,77 @@ __device__ __forceinline__ uint32_t decode_span(const HuffTab& T, const uint64_t
     return (p << 9) | ((uint32_t)k << 3) | (uint32_t)b6;
 }
 
+// One restart interval, whole, by one thread: its start is a byte boundary with fresh predictions, so its state is known
+// and it is decoded for real at once (DC terms as values).  The interval must be used up to its padding bits (fewer
+// than eight left, none taken from behind it): anything else goes back to the host decoder for its verdict, as in
+// the sequential kernel.
+__device__ __forceinline__ void decode_interval(const HuffTab& T, const uint64_t* stream, uint32_t byte_begin,
+                                                uint32_t byte_end, int16_t* coef, uint32_t blk, uint32_t nblocks, int* fail) {
+    const uint32_t end_bits = byte_end * 8u, last = blk + nblocks;
+    uint32_t bytepos = byte_begin;
+    uint64_t buf = stream8_be(stream, bytepos);
+    int nb = 64;
+    bytepos += 8;
+    int k = 0, b6 = 0, pred0 = 0, pred1 = 0, pred2 = 0;
+    bool bad = false;
+    while (blk < last && !bad) {
+        if (nb < 32) {
+            const int take = (64 - nb) >> 3;
+            const uint64_t v = stream8_be(stream, bytepos);
+            buf |= (take == 8 ? v : v & ~(~0ull >> (8 * take))) >> nb;
+            bytepos += (uint32_t)take;
+            nb += 8 * take;
+        }
+        const unsigned e = lookup(T, (b6 < 4 ? 0 : 2) + (k > 0 ? 1 : 0), buf);
+        if (e == 0) {
+            bad = true;
+            break;
+        }
+        const int l = (int)(e >> 8), sym = (int)(e & 255u);
+        buf <<= l;
+        nb -= l;
+        const int size = k == 0 ? sym : (sym & 15), run = k == 0 ? 0 : sym >> 4;
+        if (k == 0 && size > 11) {
+            bad = true;
+            break;
+        }
+        int val = 0;
+        if (size) {
+            const int v = (int)((buf >> 1) >> (63 - size));
+            val = v < (1 << (size - 1)) ? v - (1 << size) + 1 : v;
+            buf <<= size;
+            nb -= size;
+        }
+        if (k == 0) {
+            const int comp = b6 < 4 ? 0 : b6 - 3;
+            int pr = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
+            pr += val;
+            pred0 = comp == 0 ? pr : pred0;
+            pred1 = comp == 1 ? pr : pred1;
+            pred2 = comp == 2 ? pr : pred2;
+            if (pr) coef[(size_t)blk * 64] = (int16_t)pr;
+            k = 1;
+        } else if (size == 0) {
+            k = run == 15 ? k + 16 : 64;
+        } else {
+            k += run;
+            if (k > 63) {
+                bad = true;
+                break;
+            }
+            coef[(size_t)blk * 64 + k] = (int16_t)val;
+            ++k;
+        }
+        if (k >= 64) {
+            k = 0;
+            b6 = b6 == 5 ? 0 : b6 + 1;
+            ++blk;
+        }
+    }
+    const uint32_t p = bytepos * 8u - (uint32_t)nb;
+    if (bad || p > end_bits || end_bits - p >= 8u) *fail = 1;
+}
+
 __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restrict__ slots, size_t stride, int h, int w,
                                                               size_t aux, int* __restrict__ status) {
     __shared__ ParLds S;
@@ -281,10 +353,10 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
         if (tid == 0) status[img] = 3;
         return;
     }
-    // A scan that does not fit the LDS stage is read where it lies (through the L2: slower trips, the same walk); restart
-    // intervals, and scans too long for the 23 bits a state has for its bit position, are the sequential kernel's.
+    // A scan that does not fit the LDS stage is read where it lies (through the L2: slower trips, the same walk); scans
+    // too long for the 23 bits a state has for its bit position are the sequential kernel's.
     const bool in_lds = H.data_len <= kStreamCap;
-    if (H.restart != 0 || (!in_lds && (H.data_len >= (1u << 20) - 64u || aux + H.data_off + (size_t)H.data_len + 48 > stride))) {
+    if (!in_lds && (H.data_len >= (1u << 20) - 64u || aux + H.data_off + (size_t)H.data_len + 48 > stride)) {
         if (tid == 0) status[img] = 4;
         return;
     }
@@ -303,6 +375,28 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
             reinterpret_cast<uint4*>(S.stream)[i] = i < pieces ? src[i] : make_uint4(0, 0, 0, 0);
     const uint32_t total_bits = H.data_len * 8u;
     const uint32_t mcus = (uint32_t)(h / 16) * (uint32_t)(w / 16), total = mcus * 6u;
+    int16_t* coef = reinterpret_cast<int16_t*>(slot + 256);
+    if (H.restart != 0) {
+        // restart intervals are where the file itself says a decoder may start: one thread per interval, no guessing
+        const uint32_t* offs = reinterpret_cast<const uint32_t*>(a + 1120);
+        __syncthreads();   // the staged scan
+        for (uint32_t i = tid; i < H.nint; i += kPT) {
+            const uint32_t b = offs[i], e = offs[i + 1];
+            const uint32_t first_mcu = i * H.restart;
+            const uint32_t nm = mcus - first_mcu < H.restart ? mcus - first_mcu : H.restart;
+            if (b > e || e > H.data_len || (i == 0 && b != 0)) {
+                S.fail = 1;
+                continue;
+            }
+            if (in_lds)
+                decode_interval(S.T, S.stream, b, e, coef, first_mcu * 6u, nm * 6u, &S.fail);
+            else
+                decode_interval(S.T, gstream, b, e, coef, first_mcu * 6u, nm * 6u, &S.fail);
+        }
+        __syncthreads();
+        if (tid == 0) status[img] = S.fail ? 1 : 0;
+        return;
+    }
     uint32_t L = ((total_bits + kPT - 1) / kPT + 31u) & ~31u;
     if (L < 128u) L = 128u;
     const uint32_t nsub = (total_bits + L - 1) / L;   // <= kPT
@@ -347,7 +441,6 @@ __global__ __launch_bounds__(kPT) void jpeg_huffman_par_kernel(uint8_t* __restri
         __syncthreads();
     }
     const uint32_t incl = S.scan[cur][tid], first_blk = incl - own;
-    int16_t* coef = reinterpret_cast<int16_t*>(slot + 256);
     LF_STAMP(4);
     if (mine && first_blk < total) {
         uint32_t blocks;

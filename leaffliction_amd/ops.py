@@ -386,7 +386,8 @@ def jpeg_huffman_u8(slots: torch.Tensor, h: int, w: int, sequential: bool = Fals
     """The Huffman step of Image.open for N files of one size that utils.jpeg_host.scan_prepare_into has laid into
     `slots` (uint8 [N, slot_bytes], contiguous): each row's coefficient area [256, 256 + 3hw) is written IN PLACE
     (then jpeg_idct_rgb_u8 as for host-decoded files).  One workgroup per image decodes 256 pieces of the scan at
-    once; files with restart markers or scans of a megabyte and more — or all files, with `sequential` — go through the
+    once (the restart intervals of a file that has them: one each); scans of a megabyte and more — or all files, with
+    `sequential` — go through the
     one-lane-per-image kernel, which wants one set of Huffman tables per 64 consecutive rows.
     Returns int32 [N] on the device: 0 decoded, 1 malformed / truncated scan (hand the file to libjpeg), 2 tables
     differ from the group's (one-lane-per-image kernel), 3 no prepared scan in the slot."""
