@@ -140,7 +140,9 @@ class DatasetBalancer:
             # by side, threads of this one mostly take turns at the interpreter lock
             from .codec_pool import touch_files
             try:
-                futs = [starting.pool.submit(touch_files, [dst for _src, dst in files]) for files in per_dir]
+                # (the largest directories first: they are what the layout waits for)
+                futs = [starting.pool.submit(touch_files, [dst for _src, dst in files])
+                        for files in sorted(per_dir, key=len, reverse=True)]
                 for f in futs:
                     f.result()
                 laid = True
