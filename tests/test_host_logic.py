@@ -345,3 +345,21 @@ def test_fast_manifest_writer_writes_the_same_bytes(tmp_path):
     g2.save_manifest(g2.generate_augmented_manifest(), a)
     assert g2.write_augmented_manifest(b) == 0
     assert stamp.sub("", a.read_text()) == stamp.sub("", b.read_text())
+
+
+def test_codec_workers_are_the_ranks_share_of_the_node(monkeypatch):
+    """One process per GPU on a node: every rank starts its own codec workers, so the ceiling is the node's cores
+    divided among the ranks on it (LOCAL_WORLD_SIZE under torch.distributed.run)."""
+    from leaffliction_amd.preprocessing.dataset_balancer import DatasetBalancer
+    from leaffliction_amd.utils.system_info import get_available_cores
+    cores = get_available_cores()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    alone = DatasetBalancer._host_threads(10 ** 6)
+    assert alone == cores
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert DatasetBalancer._host_threads(10 ** 6) == max(1, cores // 4)
+    assert DatasetBalancer._host_threads(1) == 1
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert DatasetBalancer._host_threads(10 ** 6) == max(1, cores // 2)
