@@ -33,10 +33,7 @@ class DeviceDecoder:
 
     def __init__(self, workers: Optional[int] = None) -> None:
         from ..utils.system_info import get_optimal_worker_count
-        import os
-        # (one process per GPU on a node: the ranks share its cores)
-        ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
-        self.workers = int(workers or max(1, get_optimal_worker_count() // ranks_here))
+        self.workers = int(workers or get_optimal_worker_count())   # (already the rank's share of the node's cores)
         self._codec = None   # (CodecPool, slot_bytes, pinned, device staging)
         self._pending: List[dict] = []   # submitted, not yet collected batches (at most two)
         self._uploaded = [None, None, None]   # per slab third: event behind its last (asynchronous) upload

@@ -69,9 +69,6 @@ class DatasetBalancer:
         to the cores the process may use (the reference caps it at the optimal count, 3/4 of them: its workers
         compete with a busy parent, these with one that mostly waits for the GPU)."""
         ceiling = get_optimal_worker_count() if requested is None else get_available_cores()
-        # one process per GPU on a node: the ranks share the node's cores, each starts its own codec workers
-        ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
-        ceiling = max(1, ceiling // ranks_here)
         n = max(1, ceiling // 2) if requested is None else max(1, int(requested))
         if n > ceiling:
             logger.warning(f"Requested {n} workers, but only {ceiling} CPUs available; using {ceiling}")

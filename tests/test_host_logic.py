@@ -349,17 +349,13 @@ def test_fast_manifest_writer_writes_the_same_bytes(tmp_path):
 
 def test_codec_workers_are_the_ranks_share_of_the_node(monkeypatch):
     """One process per GPU on a node: every rank starts its own codec workers, so the ceiling is the node's cores
-    divided among the ranks on it (LOCAL_WORLD_SIZE under torch.distributed.run)."""
+    divided among the ranks on it (LOCAL_WORLD_SIZE under torch.distributed.run; utils.system_info)."""
     from leaffliction_amd.preprocessing.dataset_balancer import DatasetBalancer
     from leaffliction_amd.utils.system_info import get_available_cores
-    cores = get_available_cores()
-    monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
-    alone = DatasetBalancer._host_threads(10 ** 6)
-    assert alone == cores
+    cores = get_available_cores()
+    assert DatasetBalancer._host_threads(10 ** 6) == cores
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert get_available_cores() == max(1, cores // 4)
     assert DatasetBalancer._host_threads(10 ** 6) == max(1, cores // 4)
     assert DatasetBalancer._host_threads(1) == 1
-    monkeypatch.delenv("LOCAL_WORLD_SIZE")
-    monkeypatch.setenv("WORLD_SIZE", "2")
-    assert DatasetBalancer._host_threads(10 ** 6) == max(1, cores // 2)
